@@ -1,0 +1,32 @@
+"""In-tree native builds: libarvx.so (hipcc, gfx950), the C++ host layer, and --
+as test infrastructure only -- the CPU oracle (gcc)."""
+from __future__ import annotations
+
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _make(directory: str, *targets: str) -> None:
+    cmd = ["make", "-C", os.path.join(ROOT, directory), *targets]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"{' '.join(cmd)} failed:\n{res.stdout}")
+
+
+def build_library() -> str:
+    """hipcc --offload-arch=gfx950 -> ar_voxel_project_amd/lib/libarvx.so"""
+    _make("ar_voxel_project_amd/csrc")
+    return os.path.join(ROOT, "ar_voxel_project_amd", "lib", "libarvx.so")
+
+
+def build_oracle() -> str:
+    """gcc -> oracle/libarvx_oracle.so (checker for tests/smoke/cpu_baseline only)"""
+    _make("oracle")
+    return os.path.join(ROOT, "oracle", "libarvx_oracle.so")
+
+
+if __name__ == "__main__":
+    print(build_library())
+    print(build_oracle())

@@ -1,0 +1,266 @@
+"""ctypes binding of libarvx.so (include/arvx/arvx.h).
+
+This is plumbing: every call goes straight to the C-ABI, which launches the
+gfx950 kernels.  There is no Python or CPU fallback -- if the shared library is
+missing or the GPU is unusable the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libarvx.so")
+
+OCC = 1
+SEEN = 2
+CARVE_NO_CULL = 1
+CARVE_STATS = 2
+COLOR_CLOSEST = 0
+COLOR_AVERAGE = 1
+
+# every symbol include/arvx/arvx.h declares
+SYMBOLS = [
+    "arvx_version", "arvx_last_error", "arvx_device_count",
+    "arvx_ctx_create", "arvx_ctx_create_slab", "arvx_ctx_destroy",
+    "arvx_ctx_set_stream", "arvx_ctx_synchronize", "arvx_ctx_voxels",
+    "arvx_compose_projection", "arvx_set_views", "arvx_set_views_device",
+    "arvx_set_images", "arvx_state_reset", "arvx_state_upload",
+    "arvx_state_download", "arvx_state_device_ptr", "arvx_state_bind",
+    "arvx_pack_occupancy", "arvx_carve", "arvx_carve_views", "arvx_fast_carve",
+    "arvx_color", "arvx_surface_count", "arvx_surface_download",
+    "arvx_export_model", "arvx_get_stats",
+]
+
+
+class ArvxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"arvx error {code}: {msg}")
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("subtiles", C.c_uint64),
+        ("subtiles_carved", C.c_uint64),
+        ("subtile_views_mixed", C.c_uint64),
+        ("subtile_views_total", C.c_uint64),
+        ("surface_voxels", C.c_uint64),
+        ("reserved", C.c_uint64 * 3),
+    ]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load libarvx.so (built in-tree by ar_voxel_project_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or make -C ar_voxel_project_amd/csrc); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    p = C.c_void_p
+    f32p = C.POINTER(C.c_float)
+    u8p = C.POINTER(C.c_uint8)
+    lib.arvx_version.restype = C.c_int
+    lib.arvx_last_error.restype = C.c_char_p
+    lib.arvx_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.arvx_ctx_create.argtypes = [C.POINTER(p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
+    lib.arvx_ctx_create_slab.argtypes = [C.POINTER(p), C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_float, C.c_int, C.c_int]
+    lib.arvx_ctx_destroy.argtypes = [p]
+    lib.arvx_ctx_set_stream.argtypes = [p, p]
+    lib.arvx_ctx_synchronize.argtypes = [p]
+    lib.arvx_ctx_voxels.argtypes = [p, C.POINTER(C.c_int64)]
+    lib.arvx_compose_projection.argtypes = [f32p, f32p, f32p]
+    lib.arvx_set_views.argtypes = [p, C.c_int, f32p, f32p, C.POINTER(C.c_void_p), C.c_int,
+                                   C.c_int, C.c_int, C.c_size_t]
+    lib.arvx_set_views_device.argtypes = [p, C.c_int, f32p, f32p, p, C.c_int, C.c_int, C.c_int]
+    lib.arvx_set_images.argtypes = [p, C.POINTER(C.c_void_p), C.c_size_t]
+    lib.arvx_state_reset.argtypes = [p]
+    lib.arvx_state_upload.argtypes = [p, u8p]
+    lib.arvx_state_download.argtypes = [p, u8p]
+    lib.arvx_state_device_ptr.argtypes = [p, C.POINTER(p), C.POINTER(C.c_size_t)]
+    lib.arvx_state_bind.argtypes = [p, p]
+    lib.arvx_pack_occupancy.argtypes = [p, p]
+    lib.arvx_carve.argtypes = [p, C.c_uint]
+    lib.arvx_carve_views.argtypes = [p, C.c_int, C.c_int, C.c_uint]
+    lib.arvx_fast_carve.argtypes = [p]
+    lib.arvx_color.argtypes = [p, C.c_int]
+    lib.arvx_surface_count.argtypes = [p, C.POINTER(C.c_int64)]
+    lib.arvx_surface_download.argtypes = [p, C.POINTER(C.c_int64), f32p]
+    lib.arvx_export_model.argtypes = [p, f32p, C.c_int]
+    lib.arvx_get_stats.argtypes = [p, C.POINTER(Stats)]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("arvx_last_error",):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise ArvxError(rc, load_library().arvx_last_error().decode("utf-8", "replace"))
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def compose_projection(K, Rt) -> np.ndarray:
+    """M = K * Rt as the reference's `intr * pose` (fp32, unfused, left to right)."""
+    K = _f32(K).reshape(9)
+    Rt = _f32(Rt).reshape(12)
+    M = np.empty(12, np.float32)
+    _check(load_library().arvx_compose_projection(_fp(K), _fp(Rt), _fp(M)))
+    return M.reshape(3, 4)
+
+
+class Context:
+    """One voxel grid (or Z slab) on one GPU: thin wrapper of arvx_ctx."""
+
+    def __init__(self, X: int, Y: int, Z: int, voxel_size: float, device: int = 0,
+                 z_range: Optional[Sequence[int]] = None):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.X, self.Y, self.Z = int(X), int(Y), int(Z)
+        self.voxel_size = float(np.float32(voxel_size))
+        z0, z1 = (0, Z) if z_range is None else (int(z_range[0]), int(z_range[1]))
+        self.z_range = (z0, z1)
+        _check(self._lib.arvx_ctx_create_slab(C.byref(self._h), device, X, Y, Z,
+                                              C.c_float(voxel_size), z0, z1))
+        self.shape = (z1 - z0, Y, X)  # numpy view of the state plane: [z][y][x]
+        self.nvox = (z1 - z0) * Y * X
+        self._keep = []
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.arvx_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- views --
+    def set_views(self, M, masks, campos=None) -> None:
+        """M: (V,3,4) float32. masks: (V,H,W) or (V,H,W,C) uint8 host array."""
+        M = _f32(M).reshape(-1, 12)
+        masks = np.ascontiguousarray(masks, dtype=np.uint8)
+        if masks.ndim == 3:
+            masks = masks[..., None]
+        V, H, W, Cn = masks.shape
+        assert M.shape[0] == V
+        ptrs = (C.c_void_p * V)(*[masks[i].ctypes.data for i in range(V)])
+        cp = None
+        if campos is not None:
+            campos = _f32(campos).reshape(V, 3)
+            cp = _fp(campos)
+        _check(self._lib.arvx_set_views(self._h, V, _fp(M), cp, ptrs, W, H, Cn, W * Cn))
+        self.V, self.W, self.H = V, W, H
+
+    def set_views_device(self, M, dev_masks_ptr: int, W: int, H: int, Cn: int,
+                         campos=None) -> None:
+        M = _f32(M).reshape(-1, 12)
+        V = M.shape[0]
+        cp = None
+        if campos is not None:
+            campos = _f32(campos).reshape(V, 3)
+            cp = _fp(campos)
+        self._keep = [M, campos]
+        _check(self._lib.arvx_set_views_device(self._h, V, _fp(M), cp,
+                                               C.c_void_p(dev_masks_ptr), W, H, Cn))
+        self.V, self.W, self.H = V, W, H
+
+    def set_images(self, images) -> None:
+        """images: (V,H,W,3) uint8 BGR, undistorted."""
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        V, H, W, Cn = images.shape
+        assert Cn == 3 and V == self.V and H == self.H and W == self.W
+        ptrs = (C.c_void_p * V)(*[images[i].ctypes.data for i in range(V)])
+        _check(self._lib.arvx_set_images(self._h, ptrs, W * 3))
+
+    # -- state --
+    def reset(self) -> None:
+        _check(self._lib.arvx_state_reset(self._h))
+
+    def upload_state(self, state) -> None:
+        state = np.ascontiguousarray(state, dtype=np.uint8).reshape(-1)
+        assert state.size == self.nvox
+        _check(self._lib.arvx_state_upload(self._h, state.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def download_state(self) -> np.ndarray:
+        out = np.empty(self.nvox, np.uint8)
+        _check(self._lib.arvx_state_download(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out.reshape(self.shape)
+
+    def state_device_ptr(self) -> int:
+        ptr = C.c_void_p()
+        n = C.c_size_t()
+        _check(self._lib.arvx_state_device_ptr(self._h, C.byref(ptr), C.byref(n)))
+        return int(ptr.value)
+
+    def bind_state(self, dev_ptr: int) -> None:
+        _check(self._lib.arvx_state_bind(self._h, C.c_void_p(dev_ptr)))
+
+    def pack_occupancy(self, dev_words_ptr: int) -> None:
+        _check(self._lib.arvx_pack_occupancy(self._h, C.c_void_p(dev_words_ptr)))
+
+    def set_stream(self, stream_ptr: int) -> None:
+        _check(self._lib.arvx_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self) -> None:
+        _check(self._lib.arvx_ctx_synchronize(self._h))
+
+    # -- hot path --
+    def carve(self, flags: int = 0) -> None:
+        _check(self._lib.arvx_carve(self._h, flags))
+
+    def carve_views(self, first: int, count: int, flags: int = 0) -> None:
+        _check(self._lib.arvx_carve_views(self._h, first, count, flags))
+
+    def fast_carve(self) -> None:
+        _check(self._lib.arvx_fast_carve(self._h))
+
+    def color(self, mode: int) -> None:
+        _check(self._lib.arvx_color(self._h, mode))
+
+    def surface(self):
+        n = C.c_int64()
+        _check(self._lib.arvx_surface_count(self._h, C.byref(n)))
+        idx = np.empty(n.value, np.int64)
+        rgb = np.empty((n.value, 3), np.float32)
+        if n.value:
+            _check(self._lib.arvx_surface_download(
+                self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)), _fp(rgb)))
+        return idx, rgb
+
+    def export_model(self, apply_unseen: bool = False) -> np.ndarray:
+        out = np.empty((self.nvox, 4), np.float32)
+        _check(self._lib.arvx_export_model(self._h, _fp(out), int(apply_unseen)))
+        return out
+
+    def stats(self) -> dict:
+        s = Stats()
+        _check(self._lib.arvx_get_stats(self._h, C.byref(s)))
+        return {k: int(getattr(s, k)) for k, _ in Stats._fields_ if k != "reserved"}

@@ -1,0 +1,394 @@
+// arvx_capi.hip -- host side of libarvx.so: the C-ABI declared in
+// include/arvx/arvx.h over the gfx950 kernels.  No CPU compute path exists
+// here: every entry point that does work launches HIP kernels and fails with
+// ARVX_ERR_HIP when no device is usable.
+#include "arvx/arvx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "arvx_ctx.h"
+#include "carve_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+}  // namespace
+
+namespace arvx {
+int fail_hip(hipError_t e, const char *what, const char *file, int line) {
+    return fail(ARVX_ERR_HIP, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+}
+int fail_msg(int code, const char *msg) { return fail(code, "%s", msg); }
+}  // namespace arvx
+
+using arvx::Ctx;
+
+#define ARVX_CHECK_CTX(ctx)                                          \
+    do {                                                             \
+        if (!(ctx)) return fail(ARVX_ERR_INVALID, "null context");   \
+        ARVX_HIP(hipSetDevice((ctx)->device));                       \
+    } while (0)
+
+extern "C" {
+
+int arvx_version(void) { return ARVX_VERSION; }
+
+const char *arvx_last_error(void) { return g_last_error.c_str(); }
+
+int arvx_device_count(int *count) {
+    if (!count) return fail(ARVX_ERR_INVALID, "null count");
+    *count = 0;
+    ARVX_HIP(hipGetDeviceCount(count));
+    return ARVX_OK;
+}
+
+int arvx_compose_projection(const float K[9], const float Rt[12], float M[12]) {
+    if (!K || !Rt || !M) return fail(ARVX_ERR_INVALID, "null matrix");
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) {
+            // cv::gemm small-matrix branch: float, left to right, unfused
+            float t = K[3 * r] * Rt[c];
+            t = t + K[3 * r + 1] * Rt[4 + c];
+            t = t + K[3 * r + 2] * Rt[8 + c];
+            M[4 * r + c] = t;
+        }
+    return ARVX_OK;
+}
+
+int arvx_ctx_create_slab(arvx_ctx **out, int device, int X, int Y, int Z, float voxel_size,
+                         int z_begin, int z_end) {
+    if (!out) return fail(ARVX_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (X < 1 || Y < 1 || Z < 1) return fail(ARVX_ERR_INVALID, "grid dims must be >= 1");
+    if ((int64_t)X * Y * Z > (int64_t)INT32_MAX)
+        return fail(ARVX_ERR_INVALID, "X*Y*Z exceeds INT_MAX (Model::flatten returns int)");
+    if (!(voxel_size > 0.f)) return fail(ARVX_ERR_INVALID, "voxel size must be > 0");
+    if (z_begin < 0 || z_end > Z || z_begin >= z_end)
+        return fail(ARVX_ERR_INVALID, "bad slab [%d,%d) of Z=%d", z_begin, z_end, Z);
+    int ndev = 0;
+    ARVX_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return fail(ARVX_ERR_INVALID, "device %d of %d", device, ndev);
+    ARVX_HIP(hipSetDevice(device));
+    arvx_ctx *c = new (std::nothrow) arvx_ctx();
+    if (!c) return fail(ARVX_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    c->X = X;
+    c->Y = Y;
+    c->Z = Z;
+    c->z0 = z_begin;
+    c->z1 = z_end;
+    c->s = voxel_size;
+    c->nvox = (size_t)X * Y * (size_t)(z_end - z_begin);
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return arvx::fail_hip(e, "hipStreamCreate", __FILE__, __LINE__);
+    }
+    c->stream = c->own_stream;
+    e = hipMalloc(&c->d_state_own, c->nvox);
+    if (e == hipSuccess) e = hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        arvx_ctx_destroy(c);
+        return arvx::fail_hip(e, "hipMalloc(state)", __FILE__, __LINE__);
+    }
+    c->d_state = c->d_state_own;
+    e = hipMemsetAsync(c->d_state, 0x01, c->nvox, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_stats, 0, 64, c->stream);
+    if (e != hipSuccess) {
+        arvx_ctx_destroy(c);
+        return arvx::fail_hip(e, "hipMemsetAsync", __FILE__, __LINE__);
+    }
+    *out = c;
+    return ARVX_OK;
+}
+
+int arvx_ctx_create(arvx_ctx **out, int device, int X, int Y, int Z, float voxel_size) {
+    return arvx_ctx_create_slab(out, device, X, Y, Z, voxel_size, 0, Z);
+}
+
+int arvx_ctx_destroy(arvx_ctx *ctx) {
+    if (!ctx) return ARVX_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    ctx->free_views();
+    ctx->free_color();
+    if (ctx->d_state_own) (void)hipFree(ctx->d_state_own);
+    if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return ARVX_OK;
+}
+
+int arvx_ctx_set_stream(arvx_ctx *ctx, void *hip_stream) {
+    ARVX_CHECK_CTX(ctx);
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return ARVX_OK;
+}
+
+int arvx_ctx_synchronize(arvx_ctx *ctx) {
+    ARVX_CHECK_CTX(ctx);
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    return ARVX_OK;
+}
+
+int arvx_ctx_voxels(const arvx_ctx *ctx, int64_t *count) {
+    if (!ctx || !count) return fail(ARVX_ERR_INVALID, "null argument");
+    *count = (int64_t)ctx->nvox;
+    return ARVX_OK;
+}
+
+// ---- views -------------------------------------------------------------------
+
+static int views_common(Ctx *ctx, int V, const float *M, const float *campos, int W, int H,
+                        int C) {
+    if (V < 1 || V > 4096) return fail(ARVX_ERR_INVALID, "V=%d out of range [1,4096]", V);
+    if (!M) return fail(ARVX_ERR_INVALID, "null M");
+    if (W < 1 || H < 1 || W > arvx::kMaxImageDim || H > arvx::kMaxImageDim)
+        return fail(ARVX_ERR_INVALID, "image size %dx%d out of range", W, H);
+    if (C < 1 || C > 4) return fail(ARVX_ERR_INVALID, "channels=%d out of range [1,4]", C);
+    ctx->free_views();
+    ctx->free_color();
+    ctx->V = V;
+    ctx->W = W;
+    ctx->H = H;
+    ctx->bgWords = (int)(((size_t)W * H + 31) / 32);
+    ctx->satStride = (W + 1) * (H + 1);
+    ARVX_HIP(hipMalloc(&ctx->d_M, (size_t)V * 12 * sizeof(float)));
+    ARVX_HIP(hipMalloc(&ctx->d_campos, (size_t)V * 3 * sizeof(float)));
+    ARVX_HIP(hipMalloc(&ctx->d_bg, (size_t)V * ctx->bgWords * sizeof(uint32_t)));
+    ARVX_HIP(hipMalloc(&ctx->d_sat, (size_t)V * ctx->satStride * sizeof(int)));
+    ctx->h_M.assign(M, M + (size_t)V * 12);
+    ARVX_HIP(hipMemcpyAsync(ctx->d_M, ctx->h_M.data(), (size_t)V * 12 * sizeof(float),
+                            hipMemcpyHostToDevice, ctx->stream));
+    ctx->has_campos = campos != nullptr;
+    if (campos) {
+        ctx->h_campos.assign(campos, campos + (size_t)V * 3);
+        ARVX_HIP(hipMemcpyAsync(ctx->d_campos, ctx->h_campos.data(),
+                                (size_t)V * 3 * sizeof(float), hipMemcpyHostToDevice,
+                                ctx->stream));
+    }
+    return ARVX_OK;
+}
+
+static int views_preprocess(Ctx *ctx, const uint8_t *d_masks, int C) {
+    const int npix = ctx->W * ctx->H;
+    dim3 g1((npix + 255) / 256, ctx->V);
+    hipLaunchKernelGGL(arvx::mask_to_bits_kernel, g1, dim3(256), 0, ctx->stream, d_masks, C, npix,
+                       ctx->d_bg, ctx->bgWords);
+    dim3 g2(ctx->H, ctx->V);
+    hipLaunchKernelGGL(arvx::sat_rows_kernel, g2, dim3(64), 0, ctx->stream, ctx->d_bg,
+                       ctx->bgWords, ctx->W, ctx->H, ctx->d_sat, ctx->satStride);
+    dim3 g3((ctx->W + 1 + 255) / 256, ctx->V);
+    hipLaunchKernelGGL(arvx::sat_cols_kernel, g3, dim3(256), 0, ctx->stream, ctx->W, ctx->H,
+                       ctx->d_sat, ctx->satStride);
+    ARVX_HIP(hipGetLastError());
+    ctx->views_ready = true;
+    return ARVX_OK;
+}
+
+int arvx_set_views(arvx_ctx *ctx, int V, const float *M, const float *campos,
+                   const uint8_t *const *masks, int W, int H, int C, size_t stride) {
+    ARVX_CHECK_CTX(ctx);
+    if (!masks) return fail(ARVX_ERR_INVALID, "null masks");
+    if (W >= 1 && C >= 1 && stride < (size_t)W * C)
+        return fail(ARVX_ERR_INVALID, "stride %zu < W*C", stride);
+    for (int i = 0; i < V; ++i)
+        if (!masks[i]) return fail(ARVX_ERR_INVALID, "null mask %d", i);
+    int rc = views_common(ctx, V, M, campos, W, H, C);
+    if (rc) return rc;
+    const size_t img = (size_t)W * H * C;
+    uint8_t *d_raw = nullptr;
+    ARVX_HIP(hipMalloc(&d_raw, img * V));
+    for (int i = 0; i < V; ++i) {
+        hipError_t e = hipMemcpy2DAsync(d_raw + img * i, (size_t)W * C, masks[i], stride,
+                                        (size_t)W * C, H, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(d_raw);
+            return arvx::fail_hip(e, "hipMemcpy2DAsync(mask)", __FILE__, __LINE__);
+        }
+    }
+    rc = views_preprocess(ctx, d_raw, C);
+    hipError_t e = hipStreamSynchronize(ctx->stream);  // host buffers may go away
+    (void)hipFree(d_raw);
+    if (rc) return rc;
+    if (e != hipSuccess) return arvx::fail_hip(e, "hipStreamSynchronize", __FILE__, __LINE__);
+    return ARVX_OK;
+}
+
+int arvx_set_views_device(arvx_ctx *ctx, int V, const float *M, const float *campos,
+                          const void *dev_masks, int W, int H, int C) {
+    ARVX_CHECK_CTX(ctx);
+    if (!dev_masks) return fail(ARVX_ERR_INVALID, "null dev_masks");
+    const bool same = ctx->views_ready && ctx->V == V && ctx->W == W && ctx->H == H;
+    if (same) {
+        // keep the allocations: refresh matrices and re-derive the planes, all async
+        if (!M) return fail(ARVX_ERR_INVALID, "null M");
+        ctx->h_M.assign(M, M + (size_t)V * 12);
+        ARVX_HIP(hipMemcpyAsync(ctx->d_M, ctx->h_M.data(), (size_t)V * 12 * sizeof(float),
+                                hipMemcpyHostToDevice, ctx->stream));
+        ctx->has_campos = campos != nullptr;
+        if (campos) {
+            ctx->h_campos.assign(campos, campos + (size_t)V * 3);
+            ARVX_HIP(hipMemcpyAsync(ctx->d_campos, ctx->h_campos.data(),
+                                    (size_t)V * 3 * sizeof(float), hipMemcpyHostToDevice,
+                                    ctx->stream));
+        }
+    } else {
+        int rc = views_common(ctx, V, M, campos, W, H, C);
+        if (rc) return rc;
+    }
+    return views_preprocess(ctx, (const uint8_t *)dev_masks, C);
+}
+
+// ---- state -------------------------------------------------------------------
+
+int arvx_state_reset(arvx_ctx *ctx) {
+    ARVX_CHECK_CTX(ctx);
+    ARVX_HIP(hipMemsetAsync(ctx->d_state, 0x01, ctx->nvox, ctx->stream));
+    return ARVX_OK;
+}
+
+int arvx_state_upload(arvx_ctx *ctx, const uint8_t *state) {
+    ARVX_CHECK_CTX(ctx);
+    if (!state) return fail(ARVX_ERR_INVALID, "null state");
+    ARVX_HIP(hipMemcpyAsync(ctx->d_state, state, ctx->nvox, hipMemcpyHostToDevice, ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    return ARVX_OK;
+}
+
+int arvx_state_download(arvx_ctx *ctx, uint8_t *state) {
+    ARVX_CHECK_CTX(ctx);
+    if (!state) return fail(ARVX_ERR_INVALID, "null state");
+    ARVX_HIP(hipMemcpyAsync(state, ctx->d_state, ctx->nvox, hipMemcpyDeviceToHost, ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    return ARVX_OK;
+}
+
+int arvx_state_device_ptr(arvx_ctx *ctx, void **ptr, size_t *bytes) {
+    if (!ctx || !ptr) return fail(ARVX_ERR_INVALID, "null argument");
+    *ptr = ctx->d_state;
+    if (bytes) *bytes = ctx->nvox;
+    return ARVX_OK;
+}
+
+int arvx_state_bind(arvx_ctx *ctx, void *dev_state) {
+    ARVX_CHECK_CTX(ctx);
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->d_state = dev_state ? (uint8_t *)dev_state : ctx->d_state_own;
+    return ARVX_OK;
+}
+
+int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
+    ARVX_CHECK_CTX(ctx);
+    if (!dev_words) return fail(ARVX_ERR_INVALID, "null dev_words");
+    const size_t nround = (ctx->nvox + 255) / 256;
+    const unsigned grid = (unsigned)(nround < 8192 ? (nround ? nround : 1) : 8192);
+    hipLaunchKernelGGL(arvx::pack_occupancy_kernel, dim3(grid), dim3(256), 0, ctx->stream,
+                       ctx->d_state, ctx->nvox, (uint32_t *)dev_words);
+    ARVX_HIP(hipGetLastError());
+    return ARVX_OK;
+}
+
+// ---- carve -------------------------------------------------------------------
+
+int arvx_carve_views(arvx_ctx *ctx, int first, int count, unsigned flags) {
+    ARVX_CHECK_CTX(ctx);
+    if (!ctx->views_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
+    if (first < 0 || count < 0 || first + count > ctx->V)
+        return fail(ARVX_ERR_INVALID, "view range [%d,%d) outside [0,%d)", first, first + count,
+                    ctx->V);
+    if (count == 0) return ARVX_OK;
+    arvx::CarveParams p;
+    p.state = ctx->d_state;
+    p.M = ctx->d_M;
+    p.bg = ctx->d_bg;
+    p.sat = ctx->d_sat;
+    p.stats = ctx->d_stats;
+    p.X = ctx->X;
+    p.Y = ctx->Y;
+    p.Z = ctx->z1 - ctx->z0;
+    p.zoff = ctx->z0;
+    p.s = ctx->s;
+    p.W = ctx->W;
+    p.H = ctx->H;
+    p.bgWords = ctx->bgWords;
+    p.satStride = ctx->satStride;
+    p.v0 = first;
+    p.v1 = first + count;
+    p.flags = flags;
+    p.tilesX = (p.X + arvx::kTileX - 1) / arvx::kTileX;
+    p.tilesY = (p.Y + arvx::kTileY - 1) / arvx::kTileY;
+    p.tilesZ = (p.Z + arvx::kTileZ - 1) / arvx::kTileZ;
+    const size_t ntiles = (size_t)p.tilesX * p.tilesY * p.tilesZ;
+    const unsigned grid = (unsigned)(((ntiles + 7) / 8) * 8);
+    if (flags & ARVX_CARVE_STATS) ARVX_HIP(hipMemsetAsync(ctx->d_stats, 0, 32, ctx->stream));
+    const bool aligned = (p.X % 4 == 0) && (((uintptr_t)p.state & 3u) == 0);
+    if (aligned)
+        hipLaunchKernelGGL(arvx::carve_fused_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream,
+                           p);
+    else
+        hipLaunchKernelGGL(arvx::carve_fused_kernel<false>, dim3(grid), dim3(256), 0,
+                           ctx->stream, p);
+    ARVX_HIP(hipGetLastError());
+    return ARVX_OK;
+}
+
+int arvx_carve(arvx_ctx *ctx, unsigned flags) {
+    if (!ctx) return fail(ARVX_ERR_INVALID, "null context");
+    return arvx_carve_views(ctx, 0, ctx->V, flags);
+}
+
+int arvx_get_stats(arvx_ctx *ctx, arvx_stats *out) {
+    ARVX_CHECK_CTX(ctx);
+    if (!out) return fail(ARVX_ERR_INVALID, "null out");
+    unsigned long long h[8];
+    ARVX_HIP(hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    memset(out, 0, sizeof *out);
+    out->subtiles = h[0];
+    out->subtiles_carved = h[1];
+    out->subtile_views_mixed = h[2];
+    out->subtile_views_total = h[3];
+    out->surface_voxels = h[4];
+    return ARVX_OK;
+}
+
+// ---- not yet built -------------------------------------------------------------
+
+int arvx_set_images(arvx_ctx *, const uint8_t *const *, size_t) {
+    return fail(ARVX_ERR_STATE, "arvx_set_images: not implemented yet");
+}
+int arvx_fast_carve(arvx_ctx *) { return fail(ARVX_ERR_STATE, "arvx_fast_carve: not implemented yet"); }
+int arvx_color(arvx_ctx *, int) { return fail(ARVX_ERR_STATE, "arvx_color: not implemented yet"); }
+int arvx_surface_count(arvx_ctx *, int64_t *) {
+    return fail(ARVX_ERR_STATE, "arvx_surface_count: not implemented yet");
+}
+int arvx_surface_download(arvx_ctx *, int64_t *, float *) {
+    return fail(ARVX_ERR_STATE, "arvx_surface_download: not implemented yet");
+}
+int arvx_export_model(arvx_ctx *, float *, int) {
+    return fail(ARVX_ERR_STATE, "arvx_export_model: not implemented yet");
+}
+
+}  // extern "C"

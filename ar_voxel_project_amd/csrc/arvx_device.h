@@ -1,0 +1,59 @@
+// arvx_device.h -- shared device-side definitions for the gfx950 kernels.
+//
+// Arithmetic contract (must match what the reference computes per voxel,
+// reference src/VoxelCarving.cpp:18-21,41-54 and src/Model.h:134-140):
+//   w    = (float(y)*s, float(x)*s, float(-z)*s, 1)              fp32
+//   p_k  = double(M[r][k]) * double(w[k])                        exact in fp64
+//   a_r  = float(((p0 + p1) + p2) + p3)                          cv::gemm generic path
+//   u,v  = a_0 / a_2, a_1 / a_2                                  IEEE fp32 divide
+//   px   = (int)roundf(u), py = (int)roundf(v); inside iff 0<=px<W, 0<=py<H
+// The library is built with -ffp-contract=off so only explicit fma() fuses.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace arvx {
+
+constexpr int kTileX = 64, kTileY = 8, kTileZ = 8;  // voxels per workgroup
+constexpr int kSubX = 16;                           // x extent of one wave's sub-tile
+constexpr uint32_t kDone4 = 0x02020202u;            // 4 voxels carved+seen
+constexpr int kMaxImageDim = 16384;
+
+enum : int { kClsOut = 0, kClsFg = 1, kClsCarved = 2, kClsMixed = 3 };
+
+struct CarveParams {
+    uint8_t *state;         // slab state plane
+    const float *M;         // V x 12
+    const uint32_t *bg;     // V x bgWords, bit = 1 where the mask pixel is background
+    const int *sat;         // V x satStride, summed-area table of foreground pixels
+    unsigned long long *stats;
+    int X, Y, Z;            // slab extent in voxels (Z = planes held)
+    int zoff;               // global z of slab plane 0
+    float s;                // voxel edge
+    int W, H;
+    int bgWords, satStride;
+    int v0, v1;             // view range [v0, v1)
+    unsigned flags;
+    int tilesX, tilesY, tilesZ;
+};
+
+// Rounded pixel of one projected voxel.  a0,a1,a2 are the fp32 row results.
+// Returns false (outside) for non-finite quotients as x86's cvttss2si does.
+__device__ __forceinline__ bool pixel_of(float a0, float a1, float a2, int W, int H,
+                                         int &pix) {
+    float u = a0 / a2;
+    float v = a1 / a2;
+    float ru = roundf(u);
+    float rv = roundf(v);
+    // W,H <= 16384 are exact in fp32; ru,rv are integral, NaN fails every test.
+    bool in = (ru >= 0.f) && (ru < (float)W) && (rv >= 0.f) && (rv < (float)H);
+    pix = in ? (int)rv * W + (int)ru : 0;
+    return in;
+}
+
+__device__ __forceinline__ float row_sum(double p01, double p2, double p3) {
+    return (float)((p01 + p2) + p3);
+}
+
+}  // namespace arvx

@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py -- dense carve throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one synthetic batch: a fresh model
+(all voxels occupied) is carved by all V silhouette views (sphere
+of radius 0.35E, ring cameras, 640x480 masks).  Masks, matrices and the state
+plane are resident in HBM before the timed region starts.
+
+metric  Mvoxel-views/s = voxels x views / carve time  (BASELINE.json)
+N = 1   512^3 grid x 36 views (the configuration the metric is quoted on)
+N > 1   one rank per GPU; rank r carves Z slab r of a grid that holds N x 512^3
+        voxels (weak scaling), then ONE collective over RCCL merges the
+        bit-packed occupancy of all slabs.
+
+The JSON line also carries `roofline` (algorithmic HBM bytes of SURVEY 8d / the
+carve kernel's launch time measured with HIP events on its own stream) and
+`cpu_baseline` (the CPU oracle's reference-shaped port, one thread, timed on this
+host on a bounded slab of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def grid_for(world: int, base: int):
+    """Grid (X, Y, Z) holding ~world x base^3 voxels, cubic, multiple of 8 per axis."""
+    if world == 1:
+        return base, base, base
+    n = int(round(base * world ** (1.0 / 3.0) / 8.0)) * 8
+    return n, n, n
+
+
+def slab_of(Z: int, world: int, rank: int):
+    """Contiguous Z slab of rank: planes split as evenly as 8-plane tiles allow."""
+    tiles = (Z + 7) // 8
+    lo = (tiles * rank) // world * 8
+    hi = min(Z, (tiles * (rank + 1)) // world * 8)
+    if rank == world - 1:
+        hi = Z
+    return lo, hi
+
+
+def cpu_baseline(sc, X, Y, Z, budget_s=12.0):
+    """The CPU oracle timed on this host, on a bounded sample of the same workload.
+    Primary figure: the reference-shaped port (AoS float voxels, x->y->z loops, M
+    recomputed per voxel as the reference does), ONE thread -- the reference is
+    single-threaded.  Side figure: the x-fastest OpenMP variant on all cores."""
+    from ar_voxel_project_amd import build
+    build.build_oracle()
+    from oracle import pyoracle
+    zc = Z // 2
+    t0 = time.perf_counter()
+    pyoracle.carve_ref(X, Y, Z, sc.voxel_size, sc.K, sc.Rt, sc.masks, zc, zc + 1)
+    t1 = time.perf_counter() - t0  # one plane, to size the sample
+    planes = int(max(1, min(Z, budget_s / max(t1, 1e-6))))
+    zlo = max(0, zc - planes // 2)
+    zhi = min(Z, zlo + planes)
+    t0 = time.perf_counter()
+    pyoracle.carve_ref(X, Y, Z, sc.voxel_size, sc.K, sc.Rt, sc.masks, zlo, zhi)
+    dt = time.perf_counter() - t0
+    out = {"value": X * Y * (zhi - zlo) * sc.V / dt / 1e6, "unit": "Mvoxel-views/s",
+           "cores": 1, "kind": "port",
+           "sample": f"reference-shaped oracle port, planes z={zlo}..{zhi - 1} of "
+                     f"{X}x{Y}x{Z} x {sc.V} views ({dt:.1f} s)",
+           "published_reference": {"value": 0.71, "unit": "Mvoxel-views/s",
+                                   "note": "Report.pdf Fig. 4, i7 @ 4.5 GHz, real reference "
+                                           "incl. cv::Mat overhead (BASELINE.md)"}}
+    ncores = os.cpu_count() or 1
+    mt_planes = int(min(Z, max(8, planes * min(ncores, 32) // 4)))
+    t0 = time.perf_counter()
+    pyoracle.carve(X, Y, mt_planes, sc.voxel_size, sc.M, sc.masks, threads=0)
+    dmt = time.perf_counter() - t0
+    out["all_cores"] = {"value": X * Y * mt_planes * sc.V / dmt / 1e6,
+                        "unit": "Mvoxel-views/s", "cores": ncores, "kind": "port",
+                        "sample": f"x-fastest OpenMP oracle, planes z=0..{mt_planes - 1} "
+                                  f"({dmt:.1f} s)"}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=512, help="base grid edge per GPU")
+    ap.add_argument("--views", type=int, default=36)
+    ap.add_argument("--no-cull", action="store_true", help="evaluate every voxel in every view")
+    ap.add_argument("--collective", default="allreduce", choices=["allreduce", "allgather", "none"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--extra-grid", type=int, default=1024,
+                    help="also time this grid at N=1 (0 = skip); reported under 'extra'")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from ar_voxel_project_amd import capi, synthetic
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def run_config(base, V, steps, warmup, collective):
+        X, Y, Z = grid_for(world, base)
+        sc = synthetic.sphere_scene(max(X, Y, Z), V)
+        sc.X, sc.Y, sc.Z = X, Y, Z
+        zlo, zhi = slab_of(Z, world, rank)
+        nvox_global = X * Y * Z
+        flags = capi.CARVE_NO_CULL if args.no_cull else 0
+        ctx = capi.Context(X, Y, Z, sc.voxel_size, device=local_rank, z_range=(zlo, zhi))
+        stream = torch.cuda.current_stream()
+        ctx.set_stream(stream.cuda_stream)
+        d_masks = torch.from_numpy(sc.masks).to(dev)  # resident before timing
+        ctx.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
+        nwords_global = (nvox_global + 31) // 32
+        occ_bits = None
+        if world > 1 and collective != "none":
+            occ_bits = torch.zeros(nwords_global, dtype=torch.int32, device=dev)
+            off_words = (X * Y * zlo) // 32  # X*Y*8 planes granularity -> multiple of 32
+            my_words = (X * Y * (zhi - zlo) + 31) // 32
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(steps)]
+
+        def step(i=None):
+            ctx.reset()
+            if i is not None:
+                ev[i][0].record(stream)
+            ctx.carve(flags)
+            if i is not None:
+                ev[i][1].record(stream)
+            if occ_bits is not None:
+                if collective == "allreduce":
+                    occ_bits.zero_()
+                    ctx.pack_occupancy(occ_bits.data_ptr() + 4 * off_words)
+                    dist.all_reduce(occ_bits, op=dist.ReduceOp.MAX)
+                else:
+                    ctx.pack_occupancy(occ_bits.data_ptr() + 4 * off_words)
+                    parts = [occ_bits[(X * Y * slab_of(Z, world, r)[0]) // 32:
+                                      (X * Y * slab_of(Z, world, r)[1] + 31) // 32]
+                             for r in range(world)]
+                    dist.all_gather(parts, parts[rank])
+
+        for _ in range(warmup):
+            step()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        occ = None
+        if rank == 0:
+            st = ctx.download_state()
+            occ = float((st & 1).mean())
+        ctx.close()
+        del d_masks
+        return dict(X=X, Y=Y, Z=Z, V=V, dt=dt, kern_ms=kern_ms, sc=sc, occ=occ,
+                    slab=(zlo, zhi), nvox=nvox_global)
+
+    r = run_config(args.grid, args.views, args.steps, args.warmup, args.collective)
+    vv = r["nvox"] * r["V"]
+    value = vv * args.steps / r["dt"] / 1e6
+    ms_per_step = r["dt"] / args.steps * 1e3
+
+    # roofline of the carve kernel: SURVEY 8(d) algorithmic bytes, HBM-read side:
+    # N*V (one state byte per voxel-view) + V*W*H (one mask byte per pixel), for the
+    # voxels THIS rank's launch processes.
+    nv_rank = r["X"] * r["Y"] * (r["slab"][1] - r["slab"][0])
+    alg_bytes = nv_rank * r["V"] + r["V"] * r["sc"].W * r["sc"].H
+    achieved = alg_bytes / (r["kern_ms"] * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = f"{r['X']}x{r['Y']}x{r['Z']}x{r['V']}" + ("_nocull" if args.no_cull else "")
+            traffic = tj.get(key)
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "carve_fused_kernel", "kernel_ms": r["kern_ms"],
+                "algorithmic_bytes": alg_bytes,
+                "note": "algorithmic = N*V + V*W*H read bytes of the per-view streaming "
+                        "formulation (SURVEY 8d); the fused kernel reads the state once and "
+                        "decides most 16x8x8 sub-tiles from a pixel-rectangle test, so this "
+                        "is an EFFECTIVE rate and may exceed the physical peak; `traffic` "
+                        "is the rocprofv3 PMC HBM byte count per launch (profiles/)"}
+
+    out = {
+        "metric": "Mvoxel-views/s (voxels x views / s) + carve wall-time, 512^3 grid x 36 views",
+        "value": value, "unit": "Mvoxel-views/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"synthetic sphere silhouettes, {r['X']}x{r['Y']}x{r['Z']} grid, "
+                               f"{r['V']} views 640x480, dense carve (all views fused)",
+                   "grid": [r["X"], r["Y"], r["Z"]], "views": r["V"],
+                   "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
+                   "collective": args.collective if world > 1 else "none",
+                   "cull": not args.no_cull},
+        "carve_kernel_ms": r["kern_ms"], "occupied_fraction": r["occ"],
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and args.extra_grid and args.extra_grid != args.grid:
+        try:
+            e = run_config(args.extra_grid, args.views, max(3, args.steps // 4), 1, "none")
+            evv = e["nvox"] * e["V"]
+            eb = evv + e["V"] * e["sc"].W * e["sc"].H
+            out["extra"] = {
+                "workload": f"{e['X']}^3 x {e['V']} views (north-star target config)",
+                "value": evv / (e["dt"] / max(3, args.steps // 4)) / 1e6,
+                "unit": "Mvoxel-views/s", "carve_kernel_ms": e["kern_ms"],
+                "roofline_frac": eb / (e["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "occupied_fraction": e["occ"]}
+        except Exception as ex:  # e.g. not enough memory on a shared box
+            out["extra"] = {"error": str(ex)}
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(r["sc"], r["X"], r["Y"], r["Z"])
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+/*
+ * arvx.h -- C-ABI of the MI355X (gfx950) voxel-carving library, libarvx.so.
+ *
+ * This is the drop-in boundary for ONE path of alxfox/AR_Voxel_Project: the
+ * dense silhouette carve, the greedy carve and the per-voxel colour vote,
+ * i.e. the bodies of
+ *     carve(...)                    reference src/VoxelCarving.h:19
+ *     fastCarve(...)                reference src/VoxelCarving.h:31
+ *     reconstructClosestColor(...)  reference src/ColorReconstruction.h:131
+ *     reconstructAvgColor(...)      reference src/ColorReconstruction.h:142
+ *     Model::handleUnseen()         reference src/Model.cpp:36-47
+ * The reference's third-party pre-processing (ChArUco pose estimation,
+ * cv::undistort, cv::imread) stays on the caller's side: the boundary takes
+ * the world->camera matrices and the already undistorted u8 images that the
+ * reference feeds its voxel loops (src/VoxelCarving.cpp:25-36).
+ *
+ * Plain C types only.  Every call returns ARVX_OK or an error code and never
+ * throws; arvx_last_error() gives the text.  A context owns one voxel grid (or
+ * one Z slab of a grid) on one GPU; calls on one context are not thread safe.
+ *
+ * State plane: one byte per voxel, index x + X*(y + Y*z) (Model::flatten,
+ * reference src/Model.h:104-106), bit0 = occupied (voxels[i].w != 0),
+ * bit1 = seen (seen[i]).
+ */
+#ifndef ARVX_H
+#define ARVX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARVX_VERSION 100
+
+enum {
+    ARVX_OK = 0,
+    ARVX_ERR_INVALID = 1, /* bad argument (null pointer, size, range) */
+    ARVX_ERR_HIP = 2,     /* a HIP runtime call failed */
+    ARVX_ERR_STATE = 3,   /* call order (e.g. carve before set_views) */
+    ARVX_ERR_NOMEM = 4
+};
+
+#define ARVX_OCC 1u
+#define ARVX_SEEN 2u
+
+/* flags of arvx_carve / arvx_carve_views */
+#define ARVX_CARVE_NO_CULL 1u /* evaluate every voxel in every view (ablation) */
+#define ARVX_CARVE_STATS 2u   /* fill the counters read by arvx_get_stats */
+
+/* colour modes: reference -color=1 / -color=2 (src/main.cpp:276-288) */
+#define ARVX_COLOR_CLOSEST 0
+#define ARVX_COLOR_AVERAGE 1
+
+typedef struct arvx_ctx arvx_ctx;
+
+typedef struct arvx_stats {
+    uint64_t subtiles;        /* 16x8x8 sub-tiles visited */
+    uint64_t subtiles_carved; /* decided "all carved" by one view's rectangle test */
+    uint64_t subtile_views_mixed; /* (sub-tile, view) pairs evaluated per voxel */
+    uint64_t subtile_views_total; /* (sub-tile, view) pairs classified */
+    uint64_t surface_voxels;  /* colour pass: occupied non-inner voxels */
+    uint64_t reserved[3];
+} arvx_stats;
+
+int arvx_version(void);
+const char *arvx_last_error(void);
+int arvx_device_count(int *count);
+
+/* ---- context --------------------------------------------------------- */
+
+/* Grid X*Y*Z voxels of edge `voxel_size` on HIP device `device`: the
+ * arguments of the reference's Model constructor (src/Model.cpp:9). */
+int arvx_ctx_create(arvx_ctx **out, int device, int X, int Y, int Z,
+                    float voxel_size);
+/* Same grid, but this context holds only planes z_begin <= z < z_end
+ * (one Z slab of a multi-GPU split). State buffers cover the slab only. */
+int arvx_ctx_create_slab(arvx_ctx **out, int device, int X, int Y, int Z,
+                         float voxel_size, int z_begin, int z_end);
+int arvx_ctx_destroy(arvx_ctx *ctx);
+/* Launch on a caller-owned hipStream_t (borrowed); NULL = context's own. */
+int arvx_ctx_set_stream(arvx_ctx *ctx, void *hip_stream);
+int arvx_ctx_synchronize(arvx_ctx *ctx);
+/* Voxels held by this context (slab). */
+int arvx_ctx_voxels(const arvx_ctx *ctx, int64_t *count);
+
+/* ---- views ------------------------------------------------------------ */
+
+/* M = K(3x3) * Rt(3x4), float, each element a0*b0 + a1*b1 + a2*b2 evaluated
+ * left to right without FMA: what `intr * pose` yields through cv::gemm in
+ * the reference (src/VoxelCarving.cpp:19).  Host helper; callers that have
+ * OpenCV should pass OpenCV's own product instead. */
+int arvx_compose_projection(const float K[9], const float Rt[12], float M[12]);
+
+/* The V camera views.
+ *   M      V*12 floats, row-major 3x4, M = intr * pose[0:3,:]  (world->pixel)
+ *   campos V*3 floats, the translation column of the world->camera matrix
+ *          (what the reference's colour pass calls `cameras[i]`,
+ *          src/ColorReconstruction.h:21); may be NULL if arvx_color is unused
+ *   masks  V host pointers; each an undistorted mask, H rows of `stride`
+ *          bytes, C interleaved u8 channels (reference: 3, BGR); a pixel is
+ *          background iff all C bytes are 0 (src/VoxelCarving.cpp:49-50)
+ * Copies everything to the device; the host buffers may be freed on return. */
+int arvx_set_views(arvx_ctx *ctx, int V, const float *M, const float *campos,
+                   const uint8_t *const *masks, int W, int H, int C,
+                   size_t stride);
+/* Same, masks already in device memory: V images back to back, tightly
+ * packed (stride = W*C).  No host synchronisation. */
+int arvx_set_views_device(arvx_ctx *ctx, int V, const float *M,
+                          const float *campos, const void *dev_masks, int W,
+                          int H, int C);
+/* Undistorted colour images for arvx_color: V host pointers, BGR u8, H rows
+ * of `stride` bytes, same W/H as the masks. */
+int arvx_set_images(arvx_ctx *ctx, const uint8_t *const *images, size_t stride);
+
+/* ---- state ------------------------------------------------------------ */
+
+/* All voxels occupied, none seen: the state a fresh Model has. */
+int arvx_state_reset(arvx_ctx *ctx);
+int arvx_state_upload(arvx_ctx *ctx, const uint8_t *state);
+int arvx_state_download(arvx_ctx *ctx, uint8_t *state);
+/* Device address of the state plane (slab), for zero-copy consumers. */
+int arvx_state_device_ptr(arvx_ctx *ctx, void **ptr, size_t *bytes);
+/* Use caller-owned device memory (>= slab voxels bytes) as the state plane. */
+int arvx_state_bind(arvx_ctx *ctx, void *dev_state);
+/* Pack bit0 (occupied) of the slab into 32-bit words, voxel i -> bit i%32 of
+ * word i/32, written to device memory dev_words (>= ceil(n/32) words). */
+int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words);
+
+/* ---- hot path --------------------------------------------------------- */
+
+/* Dense carve over all views: reference carve(), src/VoxelCarving.cpp:60-72. */
+int arvx_carve(arvx_ctx *ctx, unsigned flags);
+/* Views first <= i < first+count only; count = 1 is the reference's
+ * single-view carve (src/VoxelCarving.cpp:23-58), used for its per-view
+ * intermediate meshes (:65-68). */
+int arvx_carve_views(arvx_ctx *ctx, int first, int count, unsigned flags);
+/* Greedy carve: reference fastCarve(), src/VoxelCarving.cpp:74-167.
+ * Needs the whole grid in one context (no slab). */
+int arvx_fast_carve(arvx_ctx *ctx);
+/* Colour vote on the occupied surface voxels (reference
+ * reconstructClosestColor / reconstructAvgColor). Result stays on the device
+ * until arvx_export_model / arvx_surface_download. */
+int arvx_color(arvx_ctx *ctx, int mode);
+/* Number of coloured voxels of the last arvx_color, then their flat indices
+ * and RGB values (3 floats each, integral), ascending index order. */
+int arvx_surface_count(arvx_ctx *ctx, int64_t *count);
+int arvx_surface_download(arvx_ctx *ctx, int64_t *index, float *rgb);
+/* Model::voxels as the reference would hold it after carve [+ colour]
+ * [+ handleUnseen]: n*4 floats (RGBA), n = slab voxels. */
+int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen);
+
+int arvx_get_stats(arvx_ctx *ctx, arvx_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

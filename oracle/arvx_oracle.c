@@ -1,0 +1,443 @@
+/*
+ * arvx_oracle.c -- CPU restatement of the AR_Voxel_Project carving hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see arvx_oracle.h).  PARITY UNPINNED: no reference
+ * golden vectors exist for this path and the reference cannot be built here.
+ *
+ * Every function cites the reference lines it follows (paths relative to the
+ * reference checkout).  Two third-party calls sit on the path; their
+ * arithmetic is restated from the published OpenCV 4.x sources
+ * (modules/core/src/matmul.dispatch.cpp, matmul.simd.hpp, and
+ * include/opencv2/core/base.hpp), version unpinned by the reference
+ * (CMakeLists.txt:16; README badge 4.6.0):
+ *
+ *  (G1) `intr * pose` (3x3 * 3x4, CV_32F): cv::gemm's small-matrix branch
+ *       (flags==0, 2<=len<=4, len==d_size.height).  Each output is
+ *       t = a0*b0 + a1*b1 + a2*b2 evaluated in float, left to right, then
+ *       (float)(t*alpha + c*beta) with alpha=1.0, c=0, beta=0 in double,
+ *       which returns t unchanged.  Unfused here (-ffp-contract=off); an
+ *       OpenCV build whose AVX2 dispatch contracts to FMA can differ in the
+ *       last ulp, so the product's C-ABI takes M itself.
+ *  (G2) `M * world` (3x4 * 4x1, CV_32F): len==4 matches neither d_size
+ *       dimension, so the generic GEMMSingleMul<float,double> runs; with
+ *       d_size.width==1 and B continuous it takes the A*Bt branch:
+ *       s0..s3 (double) each hold one exact product M[r][k]*w[k] and the
+ *       row result is float((s0+s1+s2+s3)*alpha), i.e. ((p0+p1)+p2)+p3
+ *       in double, alpha = 1.0.  (SURVEY.md 8c recalls the grouping
+ *       p0+((p1+p2)+p3); define ARVX_ORACLE_ASSOC_SURVEY to get that one.)
+ *  (N1) cv::norm(Vec4f) = sqrt(normL2Sqr<float,double>): one 4-way unrolled
+ *       step, s += v0*v0 + v1*v1 + v2*v2 + v3*v3 in double, s starting at 0.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, no fast-math).
+ */
+#include "arvx_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- reference constants: src/Model.h:90-91 ---------------------------- */
+static const float MODEL_COLOR[4] = {50.f, 168.f, 141.f, 1.f};
+static const float UNSEEN_COLOR[4] = {204.f, 0.f, 0.f, 1.f};
+
+static inline long flatten(int X, int Y, int x, int y, int z) {
+    /* src/Model.h:104-106 */
+    return (long)x + (long)X * ((long)y + (long)Y * (long)z);
+}
+
+/* (G1)  src/VoxelCarving.cpp:19 `intr * pose` */
+void arvx_oracle_compose(const float K[9], const float Rt[12], float M[12]) {
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 4; ++c) {
+            float t = K[r * 3 + 0] * Rt[0 * 4 + c];
+            t = t + K[r * 3 + 1] * Rt[1 * 4 + c];
+            t = t + K[r * 3 + 2] * Rt[2 * 4 + c];
+            M[r * 4 + c] = (float)((double)t * 1.0 + 0.0 * 0.0);
+        }
+    }
+}
+
+/* src/Model.h:134-140  toWord: (y*s, x*s, -1*z*s, 1) -- x/y swapped, z negated */
+static inline void to_word(float s, int x, int y, int z, float w[4]) {
+    w[0] = (float)y * s;
+    w[1] = (float)x * s;
+    w[2] = (float)(-1 * z) * s;
+    w[3] = 1.f;
+}
+
+/* (G2)  src/VoxelCarving.cpp:18-21 worldToCamera, the `* world` factor */
+static inline void mat_vec(const float M[12], const float w[4], float proj[3]) {
+    for (int r = 0; r < 3; ++r) {
+        double p0 = (double)M[r * 4 + 0] * (double)w[0];
+        double p1 = (double)M[r * 4 + 1] * (double)w[1];
+        double p2 = (double)M[r * 4 + 2] * (double)w[2];
+        double p3 = (double)M[r * 4 + 3] * (double)w[3];
+#ifdef ARVX_ORACLE_ASSOC_SURVEY
+        double s0 = p0 + ((p1 + p2) + p3);
+#else
+        double s0 = ((p0 + p1) + p2) + p3;
+#endif
+        s0 = s0 * 1.0; /* alpha */
+        proj[r] = (float)s0;
+    }
+}
+
+void arvx_oracle_project_raw(const float M[12], float s, int x, int y, int z,
+                             float out[5]) {
+    float w[4], proj[3];
+    to_word(s, x, y, z, w);
+    mat_vec(M, w, proj);
+    out[0] = proj[0];
+    out[1] = proj[1];
+    out[2] = proj[2];
+    out[3] = proj[0] / proj[2]; /* src/VoxelCarving.cpp:20, IEEE f32 divide */
+    out[4] = proj[1] / proj[2];
+}
+
+/* src/VoxelCarving.cpp:44 `(int)std::round(u)`.  The cast is undefined for
+ * non-finite or out-of-int-range values; x86 cvttss2si yields INT_MIN there,
+ * which Rect::contains rejects -- restated as "outside". */
+static inline int round_to_pixel(float u, int *ok) {
+    float r = roundf(u);
+    if (!(r >= -2147483648.0f && r < 2147483648.0f)) { /* also false for NaN */
+        *ok = 0;
+        return 0;
+    }
+    *ok = 1;
+    return (int)r;
+}
+
+int arvx_oracle_project(const float M[12], float s, int x, int y, int z,
+                        int W, int H, int *px, int *py) {
+    float o[5];
+    arvx_oracle_project_raw(M, s, x, y, z, o);
+    int oku, okv;
+    int iu = round_to_pixel(o[3], &oku);
+    int iv = round_to_pixel(o[4], &okv);
+    if (!oku || !okv) return 0;
+    /* src/VoxelCarving.cpp:45 Point::inside(Rect(0,0,W,H)) */
+    if (iu < 0 || iu >= W || iv < 0 || iv >= H) return 0;
+    *px = iu;
+    *py = iv;
+    return 1;
+}
+
+static inline int mask_is_background(const uint8_t *mask, int C, long stride,
+                                     int px, int py) {
+    /* src/VoxelCarving.cpp:49-50: all channel bytes == 0 */
+    const uint8_t *p = mask + (long)py * stride + (long)px * C;
+    for (int c = 0; c < C; ++c)
+        if (p[c] != 0) return 0;
+    return 1;
+}
+
+/* src/VoxelCarving.cpp:38-55 -- loop order of for_each_voxel (src/Model.h:10-35):
+ * x outer, y, z inner.  Order does not change the result. */
+void arvx_oracle_carve_view(int X, int Y, int Z, float s, const float M[12],
+                            const uint8_t *mask, int W, int H, int C,
+                            long stride, uint8_t *state) {
+    for (int x = 0; x < X; ++x)
+        for (int y = 0; y < Y; ++y)
+            for (int z = 0; z < Z; ++z) {
+                int px, py;
+                if (!arvx_oracle_project(M, s, x, y, z, W, H, &px, &py))
+                    continue; /* :45-48 -- not seen */
+                long i = flatten(X, Y, x, y, z);
+                if (mask_is_background(mask, C, stride, px, py))
+                    state[i] &= (uint8_t)~ARVX_ORACLE_OCC; /* :50-53 set(0,0,0,0) */
+                state[i] |= ARVX_ORACLE_SEEN;              /* :54 see() */
+            }
+}
+
+/* src/VoxelCarving.cpp:60-72 */
+void arvx_oracle_carve(int X, int Y, int Z, float s, int V, const float *M,
+                       const uint8_t *masks, int W, int H, int C, long stride,
+                       uint8_t *state) {
+    for (int i = 0; i < V; ++i)
+        arvx_oracle_carve_view(X, Y, Z, s, M + 12 * i,
+                               masks + (long)i * H * stride, W, H, C, stride,
+                               state);
+}
+
+void arvx_oracle_carve_mt(int X, int Y, int Z, float s, int V, const float *M,
+                          const uint8_t *masks, int W, int H, int C,
+                          long stride, uint8_t *state, int threads) {
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int z = 0; z < Z; ++z)
+        for (int y = 0; y < Y; ++y)
+            for (int x = 0; x < X; ++x) {
+                long i = flatten(X, Y, x, y, z);
+                uint8_t st = state[i];
+                for (int v = 0; v < V; ++v) {
+                    int px, py;
+                    if (!arvx_oracle_project(M + 12 * v, s, x, y, z, W, H, &px,
+                                             &py))
+                        continue;
+                    if (mask_is_background(masks + (long)v * H * stride, C,
+                                           stride, px, py))
+                        st &= (uint8_t)~ARVX_ORACLE_OCC;
+                    st |= ARVX_ORACLE_SEEN;
+                }
+                state[i] = st;
+            }
+}
+
+/* Reference-shaped CPU baseline (timing only): src/VoxelCarving.cpp:23-58
+ * with its per-voxel `intr * pose * world`, AoS Vector4f voxels
+ * (src/Model.h:100) and bit-packed seen (std::vector<bool>, :102).
+ * rgba / seen_bits hold planes zlo..zhi-1 only (a bounded sample of the grid). */
+void arvx_oracle_carve_ref(int X, int Y, int Z, float s, int V,
+                           const float K[9], const float *Rt,
+                           const uint8_t *masks, int W, int H, int C,
+                           long stride, float *rgba, uint64_t *seen_bits,
+                           int zlo, int zhi) {
+    (void)Z;
+    for (int v = 0; v < V; ++v) {
+        const float *rt = Rt + 12 * v;
+        const uint8_t *mask = masks + (long)v * H * stride;
+        for (int x = 0; x < X; ++x)
+            for (int y = 0; y < Y; ++y)
+                for (int z = zlo; z < zhi; ++z) {
+                    float M[12];
+                    arvx_oracle_compose(K, rt, M); /* recomputed per voxel */
+                    int px, py;
+                    if (!arvx_oracle_project(M, s, x, y, z, W, H, &px, &py))
+                        continue;
+                    long i = flatten(X, Y, x, y, z - zlo);
+                    if (mask_is_background(mask, C, stride, px, py)) {
+                        rgba[4 * i + 0] = 0.f;
+                        rgba[4 * i + 1] = 0.f;
+                        rgba[4 * i + 2] = 0.f;
+                        rgba[4 * i + 3] = 0.f;
+                    }
+                    seen_bits[i >> 6] |= (uint64_t)1 << (i & 63);
+                }
+    }
+}
+
+/* src/VoxelCarving.cpp:74-167 fastCarve.  visited()==seen (src/Model.h:154-160). */
+void arvx_oracle_fast_carve(int X, int Y, int Z, float s, int V,
+                            const float *M, const uint8_t *masks, int W,
+                            int H, int C, long stride, uint8_t *state) {
+    long N = (long)X * Y * Z;
+    /* std::queue<Vec3i>: a voxel can be pushed by several neighbours before it
+     * is popped, at most 6 times, plus the seed. */
+    long cap = 6 * N + 8;
+    int32_t *q = (int32_t *)malloc((size_t)cap * 3 * sizeof(int32_t));
+    long head = 0, tail = 0;
+    q[0] = q[1] = q[2] = 0;
+    tail = 1;
+    while (head < tail) {
+        int cx = q[3 * head], cy = q[3 * head + 1], cz = q[3 * head + 2];
+        ++head;
+        long i = flatten(X, Y, cx, cy, cz);
+        if (state[i] & ARVX_ORACLE_SEEN) continue; /* :105-107 */
+        state[i] |= ARVX_ORACLE_SEEN;              /* :108 visit */
+        int carved = 0;
+        for (int v = 0; v < V; ++v) { /* :111-130 */
+            int px, py;
+            if (!arvx_oracle_project(M + 12 * v, s, cx, cy, cz, W, H, &px, &py))
+                continue;
+            if (mask_is_background(masks + (long)v * H * stride, C, stride, px,
+                                   py)) {
+                state[i] &= (uint8_t)~ARVX_ORACLE_OCC;
+                carved = 1;
+                break;
+            }
+        }
+        if (!carved) continue;
+        /* :132-163 push unvisited 6-neighbours */
+        static const int d[6][3] = {{-1, 0, 0}, {1, 0, 0},  {0, -1, 0},
+                                    {0, 1, 0},  {0, 0, -1}, {0, 0, 1}};
+        for (int k = 0; k < 6; ++k) {
+            int nx = cx + d[k][0], ny = cy + d[k][1], nz = cz + d[k][2];
+            if (nx < 0 || nx >= X || ny < 0 || ny >= Y || nz < 0 || nz >= Z)
+                continue;
+            if (state[flatten(X, Y, nx, ny, nz)] & ARVX_ORACLE_SEEN) continue;
+            q[3 * tail] = nx;
+            q[3 * tail + 1] = ny;
+            q[3 * tail + 2] = nz;
+            ++tail;
+        }
+    }
+    free(q);
+}
+
+/* src/Model.cpp:9-14 */
+void arvx_oracle_model_init(float *rgba, long N) {
+    for (long i = 0; i < N; ++i) memcpy(rgba + 4 * i, MODEL_COLOR, 16);
+}
+
+/* carve writes (0,0,0,0), src/VoxelCarving.cpp:52; untouched voxels keep
+ * MODEL_COLOR.  Rebuilds the AoS array a fresh Model would hold after carve. */
+void arvx_oracle_state_to_model(const uint8_t *state, float *rgba, long N) {
+    for (long i = 0; i < N; ++i) {
+        if (state[i] & ARVX_ORACLE_OCC)
+            memcpy(rgba + 4 * i, MODEL_COLOR, 16);
+        else
+            memset(rgba + 4 * i, 0, 16);
+    }
+}
+
+void arvx_oracle_model_to_state(const float *rgba, uint8_t *state, long N) {
+    for (long i = 0; i < N; ++i)
+        state[i] = (uint8_t)((state[i] & ARVX_ORACLE_SEEN) |
+                             (rgba[4 * i + 3] != 0.f ? ARVX_ORACLE_OCC : 0));
+}
+
+/* src/Model.cpp:36-47 */
+void arvx_oracle_handle_unseen(const uint8_t *state, float *rgba, long N) {
+    for (long i = 0; i < N; ++i)
+        if (!(state[i] & ARVX_ORACLE_SEEN)) memcpy(rgba + 4 * i, UNSEEN_COLOR, 16);
+}
+
+/* src/Model.h:119-124 get(): zero outside the grid */
+static inline float get_w(const float *rgba, int X, int Y, int Z, int x, int y,
+                          int z) {
+    if (x < 0 || x >= X || y < 0 || y >= Y || z < 0 || z >= Z) return 0.f;
+    return rgba[4 * flatten(X, Y, x, y, z) + 3];
+}
+
+/* src/Model.h:126-132 */
+static inline int is_inner(const float *rgba, int X, int Y, int Z, int x,
+                           int y, int z) {
+    return get_w(rgba, X, Y, Z, x - 1, y, z) != 0 &&
+           get_w(rgba, X, Y, Z, x + 1, y, z) != 0 &&
+           get_w(rgba, X, Y, Z, x, y - 1, z) != 0 &&
+           get_w(rgba, X, Y, Z, x, y + 1, z) != 0 &&
+           get_w(rgba, X, Y, Z, x, y, z - 1) != 0 &&
+           get_w(rgba, X, Y, Z, x, y, z + 1) != 0;
+}
+
+/* (N1) src/ColorReconstruction.h:59  cv::norm(cameras[i] - word_coord) */
+float arvx_oracle_depth(const float campos[3], float s, int x, int y, int z) {
+    float w[4];
+    to_word(s, x, y, z, w);
+    float d0 = campos[0] - w[0];
+    float d1 = campos[1] - w[1];
+    float d2 = campos[2] - w[2];
+    float d3 = 1.f - w[3]; /* cameras[i] = (tx,ty,tz,1), :21 */
+    double v0 = d0, v1 = d1, v2 = d2, v3 = d3;
+    double acc = 0.0;
+    acc += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+    return (float)sqrt(acc); /* double -> float at addColor(), src/Model.h:142 */
+}
+
+/* src/ColorReconstruction.h:34-74 (voxel_pass_loops) +
+ * src/ColorReconstruction.cpp:26-42 (closest) / :52-66 (average). */
+void arvx_oracle_color(int X, int Y, int Z, float s, int V, const float *M,
+                       const float *campos, const uint8_t *images, int W,
+                       int H, long stride, int mode, float *rgba) {
+    for (int x = 0; x < X; ++x)
+        for (int y = 0; y < Y; ++y)
+            for (int z = 0; z < Z; ++z) {
+                long i = flatten(X, Y, x, y, z);
+                if (rgba[4 * i + 3] == 0.f || is_inner(rgba, X, Y, Z, x, y, z))
+                    continue; /* .h:46-49 */
+                int n = 0;
+                float sum[4] = {0.f, 0.f, 0.f, 1.f}; /* .cpp:59 */
+                float best[4] = {0.f, 0.f, 0.f, 0.f};
+                float best_depth = 0.f;
+                for (int v = 0; v < V; ++v) { /* .h:50-60 */
+                    int px, py;
+                    if (!arvx_oracle_project(M + 12 * v, s, x, y, z, W, H, &px,
+                                             &py))
+                        continue;
+                    const uint8_t *p = images + (long)v * H * stride +
+                                       (long)py * stride + (long)px * 3;
+                    float col[4] = {(float)p[2], (float)p[1], (float)p[0], 1.f};
+                    float depth = arvx_oracle_depth(campos + 3 * v, s, x, y, z);
+                    if (n == 0 || depth < best_depth) { /* .cpp:33-40, strict < */
+                        memcpy(best, col, 16);
+                        best_depth = depth;
+                    }
+                    for (int c = 0; c < 4; ++c) sum[c] = sum[c] + col[c];
+                    ++n;
+                }
+                if (n == 0) continue; /* .cpp:29-31 / :55-57 */
+                if (mode == 0) {
+                    memcpy(rgba + 4 * i, best, 16); /* .cpp:41 */
+                } else {
+                    float fn = (float)n; /* Eigen Vector4f / size_t -> float */
+                    rgba[4 * i + 0] = roundf(sum[0] / fn); /* .cpp:64-65 */
+                    rgba[4 * i + 1] = roundf(sum[1] / fn);
+                    rgba[4 * i + 2] = roundf(sum[2] / fn);
+                    rgba[4 * i + 3] = 1.f;
+                }
+            }
+}
+
+/* src/Postprocessing3d.cpp:4-100, kernelSize = 3, restated literally: a
+ * dilation pass into `temp`, then the erosion pass whose tests `w < thresh`
+ * (thresh = 0) can only fire for negative w. */
+void arvx_oracle_closure(int X, int Y, int Z, float *rgba) {
+    const float thresh = 0.f;
+    const int size = 1;
+    long N = (long)X * Y * Z;
+    float *temp = (float *)malloc((size_t)N * 16);
+    for (int x = 0; x < X; ++x)
+        for (int y = 0; y < Y; ++y)
+            for (int z = 0; z < Z; ++z) {
+                long i = flatten(X, Y, x, y, z);
+                if (rgba[4 * i + 3] > thresh) { /* :23-27 */
+                    memcpy(temp + 4 * i, rgba + 4 * i, 16);
+                    continue;
+                }
+                int count = 0;
+                float sum[4] = {0, 0, 0, 0};
+                for (int a = -size; a <= size; ++a) {
+                    int xn = x + a;
+                    if (xn < 0 || xn >= X) continue;
+                    for (int b = -size; b <= size; ++b) {
+                        int yn = y + b;
+                        if (yn < 0 || yn >= Y) continue;
+                        for (int c = -size; c <= size; ++c) {
+                            int zn = z + c;
+                            if (zn < 0 || zn >= Z) continue;
+                            const float *val = rgba + 4 * flatten(X, Y, xn, yn, zn);
+                            if (val[3] > thresh) { /* :42-45 */
+                                ++count;
+                                for (int k = 0; k < 4; ++k) sum[k] = sum[k] + val[k];
+                            }
+                        }
+                    }
+                }
+                if (count > 0) /* :49-51 Eigen `sum /= count` -> float(count) */
+                    for (int k = 0; k < 4; ++k) sum[k] = sum[k] / (float)count;
+                memcpy(temp + 4 * i, sum, 16);
+            }
+    for (int x = 0; x < X; ++x) /* :60-96 erosion */
+        for (int y = 0; y < Y; ++y)
+            for (int z = 0; z < Z; ++z) {
+                long i = flatten(X, Y, x, y, z);
+                if (rgba[4 * i + 3] < thresh) continue; /* :66-69 keeps value */
+                int failed = 0;
+                for (int a = -size; a <= size && !failed; ++a) {
+                    int xn = x + a;
+                    if (xn < 0 || xn >= X) continue;
+                    for (int b = -size; b <= size && !failed; ++b) {
+                        int yn = y + b;
+                        if (yn < 0 || yn >= Y) continue;
+                        for (int c = -size; c <= size && !failed; ++c) {
+                            int zn = z + c;
+                            if (zn < 0 || zn >= Z) continue;
+                            if (temp[4 * flatten(X, Y, xn, yn, zn) + 3] < thresh)
+                                failed = 1;
+                        }
+                    }
+                }
+                if (failed)
+                    memset(rgba + 4 * i, 0, 16);
+                else
+                    memcpy(rgba + 4 * i, temp + 4 * i, 16);
+            }
+    free(temp);
+}

@@ -1,0 +1,100 @@
+/*
+ * arvx_oracle.h -- CPU restatement of the AR_Voxel_Project carving hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under ar_voxel_project_amd/ or include/
+ * may include, link or load this file.  Allowed users: tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ *
+ * PARITY UNPINNED: the reference has no unit tests, golden vectors or
+ * fixtures at the level of this path, its only
+ * known-answer files (Data/box_dataset/generated_models/{1,2,3}.off) need
+ * OpenCV-aruco poses, and the reference itself cannot be built in this image
+ * (OpenCV + Eigen3 absent).  The arithmetic of the two third-party calls on
+ * the path (cv::gemm, cv::norm; opencv 4.6.x, unpinned in the reference's
+ * CMakeLists.txt:16) is restated from its published source, see arvx_oracle.c.
+ *
+ * State plane convention (one byte per voxel, index x + X*(y + Y*z), the
+ * reference's Model::flatten, src/Model.h:104-106):
+ *   bit0 = occupied  (reference: voxels[i].w != 0, src/Model.h:119-132)
+ *   bit1 = seen      (reference: seen[i],         src/Model.h:151)
+ */
+#ifndef ARVX_ORACLE_H
+#define ARVX_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARVX_ORACLE_OCC  1u
+#define ARVX_ORACLE_SEEN 2u
+
+/* M = intr(3x3 f32) * pose(3x4 f32): cv::gemm small-matrix fp32 path. */
+void arvx_oracle_compose(const float K[9], const float Rt[12], float M[12]);
+
+/* Model::toWord + worldToCamera + round + Rect::contains.
+ * Returns 1 and writes (*px,*py) when the voxel projects inside WxH. */
+int arvx_oracle_project(const float M[12], float s, int x, int y, int z,
+                        int W, int H, int *px, int *py);
+
+/* Raw projection, no rounding: out[0..2] = proj (f32), out[3]=u, out[4]=v. */
+void arvx_oracle_project_raw(const float M[12], float s, int x, int y, int z,
+                             float out[5]);
+
+/* One view of the dense carve on a u8 state plane. mask: H rows of
+ * `stride` bytes, C interleaved channels; carved iff all C bytes == 0. */
+void arvx_oracle_carve_view(int X, int Y, int Z, float s, const float M[12],
+                            const uint8_t *mask, int W, int H, int C,
+                            long stride, uint8_t *state);
+
+/* All views in order; masks = V images back to back (H*stride bytes each). */
+void arvx_oracle_carve(int X, int Y, int Z, float s, int V, const float *M,
+                       const uint8_t *masks, int W, int H, int C, long stride,
+                       uint8_t *state);
+
+/* Same result as arvx_oracle_carve, x-fastest traversal, OpenMP threads. */
+void arvx_oracle_carve_mt(int X, int Y, int Z, float s, int V, const float *M,
+                          const uint8_t *masks, int W, int H, int C,
+                          long stride, uint8_t *state, int threads);
+
+/* Reference-shaped dense carve used only as the timed CPU baseline:
+ * AoS RGBA float voxels, bit-packed seen, x->y->z loop order, M recomputed
+ * per voxel from K and Rt as the reference does.  zlo/zhi restrict the z
+ * range so a bounded slab can be timed (full grid: 0, Z); rgba and seen_bits
+ * hold planes zlo..zhi-1 only. */
+void arvx_oracle_carve_ref(int X, int Y, int Z, float s, int V,
+                           const float K[9], const float *Rt,
+                           const uint8_t *masks, int W, int H, int C,
+                           long stride, float *rgba, uint64_t *seen_bits,
+                           int zlo, int zhi);
+
+/* fastCarve: BFS from voxel (0,0,0). */
+void arvx_oracle_fast_carve(int X, int Y, int Z, float s, int V,
+                            const float *M, const uint8_t *masks, int W,
+                            int H, int C, long stride, uint8_t *state);
+
+/* Model plumbing on the reference's AoS layout (N x 4 floats). */
+void arvx_oracle_model_init(float *rgba, long N);
+void arvx_oracle_state_to_model(const uint8_t *state, float *rgba, long N);
+void arvx_oracle_model_to_state(const float *rgba, uint8_t *state, long N);
+void arvx_oracle_handle_unseen(const uint8_t *state, float *rgba, long N);
+
+/* Colour pass. mode 0 = closest, 1 = average.  images: V BGR u8 images back
+ * to back, H rows of `stride` bytes.  campos: V x 3 floats = the translation
+ * column of the world->camera matrix (reference quirk).
+ * rgba is the model's voxel array, updated in place. */
+void arvx_oracle_color(int X, int Y, int Z, float s, int V, const float *M,
+                       const float *campos, const uint8_t *images, int W,
+                       int H, long stride, int mode, float *rgba);
+
+/* Depth of one sample as the reference computes it (cv::norm of Vec4f). */
+float arvx_oracle_depth(const float campos[3], float s, int x, int y, int z);
+
+/* 3x3x3 closure (applyClosure with thresh=0: dilation with colour mean). */
+void arvx_oracle_closure(int X, int Y, int Z, float *rgba);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

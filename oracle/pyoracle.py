@@ -1,0 +1,162 @@
+"""ctypes access to oracle/libarvx_oracle.so -- the CPU restatement used as the
+CHECKER by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Never import this from ar_voxel_project_amd/."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libarvx_oracle.so")
+OCC, SEEN = 1, 2
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} missing: run `make -C oracle`")
+        L = C.CDLL(LIB_PATH)
+        L.arvx_oracle_project.restype = C.c_int
+        L.arvx_oracle_depth.restype = C.c_float
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, np.uint8)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def compose(K, Rt):
+    K = _f32(K).reshape(9)
+    Rt = _f32(Rt).reshape(-1, 12)
+    M = np.empty_like(Rt)
+    for i in range(Rt.shape[0]):
+        lib().arvx_oracle_compose(_p(K), _p(Rt[i]), _p(M[i]))
+    return M.reshape(-1, 3, 4)
+
+
+def project(M, s, x, y, z, W, H):
+    M = _f32(M).reshape(12)
+    px, py = C.c_int(), C.c_int()
+    ok = lib().arvx_oracle_project(_p(M), C.c_float(s), int(x), int(y), int(z), W, H,
+                                   C.byref(px), C.byref(py))
+    return (px.value, py.value) if ok else None
+
+
+def project_raw(M, s, x, y, z):
+    M = _f32(M).reshape(12)
+    out = np.empty(5, np.float32)
+    lib().arvx_oracle_project_raw(_p(M), C.c_float(s), int(x), int(y), int(z), _p(out))
+    return out
+
+
+def _masks4(masks):
+    m = _u8(masks)
+    if m.ndim == 3:
+        m = m[..., None]
+    return m
+
+
+def fresh_state(X, Y, Z):
+    return np.full((Z, Y, X), OCC, np.uint8)
+
+
+def carve(X, Y, Z, s, M, masks, state=None, threads=0):
+    """Dense carve over all views; returns the (Z,Y,X) state plane."""
+    M = _f32(M).reshape(-1, 12)
+    m = _masks4(masks)
+    V, H, W, Cn = m.shape
+    st = fresh_state(X, Y, Z) if state is None else _u8(state).copy().reshape(Z, Y, X)
+    args = [X, Y, Z, C.c_float(s), V, _p(M), _p(m), W, H, Cn, C.c_long(W * Cn), _p(st)]
+    if threads == 1:
+        lib().arvx_oracle_carve(*args)
+    else:
+        lib().arvx_oracle_carve_mt(*args, int(threads))
+    return st
+
+
+def carve_view(X, Y, Z, s, M, mask, state):
+    M = _f32(M).reshape(12)
+    m = _u8(mask)
+    if m.ndim == 2:
+        m = m[..., None]
+    H, W, Cn = m.shape
+    st = _u8(state).copy().reshape(Z, Y, X)
+    lib().arvx_oracle_carve_view(X, Y, Z, C.c_float(s), _p(M), _p(m), W, H, Cn,
+                                 C.c_long(W * Cn), _p(st))
+    return st
+
+
+def carve_ref(X, Y, Z, s, K, Rt, masks, zlo=0, zhi=None):
+    """Reference-shaped baseline (AoS floats, x->y->z). Returns (rgba, seen_bits)."""
+    K = _f32(K).reshape(9)
+    Rt = _f32(Rt).reshape(-1, 12)
+    m = _masks4(masks)
+    V, H, W, Cn = m.shape
+    zhi = Z if zhi is None else zhi
+    N = X * Y * (zhi - zlo)  # arrays hold the sampled planes only
+    rgba = np.empty((N, 4), np.float32)
+    lib().arvx_oracle_model_init(_p(rgba), C.c_long(N))
+    seen = np.zeros((N + 63) // 64, np.uint64)
+    lib().arvx_oracle_carve_ref(X, Y, Z, C.c_float(s), V, _p(K), _p(Rt), _p(m), W, H, Cn,
+                                C.c_long(W * Cn), _p(rgba), _p(seen), int(zlo), int(zhi))
+    return rgba, seen
+
+
+def fast_carve(X, Y, Z, s, M, masks, state=None):
+    M = _f32(M).reshape(-1, 12)
+    m = _masks4(masks)
+    V, H, W, Cn = m.shape
+    st = fresh_state(X, Y, Z) if state is None else _u8(state).copy().reshape(Z, Y, X)
+    lib().arvx_oracle_fast_carve(X, Y, Z, C.c_float(s), V, _p(M), _p(m), W, H, Cn,
+                                 C.c_long(W * Cn), _p(st))
+    return st
+
+
+def model_from_state(state):
+    st = _u8(state).reshape(-1)
+    rgba = np.empty((st.size, 4), np.float32)
+    lib().arvx_oracle_state_to_model(_p(st), _p(rgba), C.c_long(st.size))
+    return rgba
+
+
+def handle_unseen(state, rgba):
+    st = _u8(state).reshape(-1)
+    out = _f32(rgba).copy()
+    lib().arvx_oracle_handle_unseen(_p(st), _p(out), C.c_long(st.size))
+    return out
+
+
+def color(X, Y, Z, s, M, campos, images, mode, rgba):
+    M = _f32(M).reshape(-1, 12)
+    campos = _f32(campos).reshape(-1, 3)
+    img = _u8(images)
+    V, H, W, Cn = img.shape
+    assert Cn == 3
+    out = _f32(rgba).copy()
+    lib().arvx_oracle_color(X, Y, Z, C.c_float(s), V, _p(M), _p(campos), _p(img), W, H,
+                            C.c_long(W * 3), int(mode), _p(out))
+    return out
+
+
+def depth(campos, s, x, y, z):
+    cp = _f32(campos).reshape(3)
+    return float(lib().arvx_oracle_depth(_p(cp), C.c_float(s), int(x), int(y), int(z)))
+
+
+def closure(X, Y, Z, rgba):
+    out = _f32(rgba).copy()
+    lib().arvx_oracle_closure(X, Y, Z, _p(out))
+    return out

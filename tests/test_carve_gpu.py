@@ -1,0 +1,146 @@
+"""Parity of the HIP dense carve (through the C-ABI) with the CPU oracle.
+Bar: the state plane is bit-exact (occupancy AND seen), every voxel."""
+import numpy as np
+import pytest
+
+from tests import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gpu(arvx, X, Y, Z, s, M, masks, flags=0, state=None, z_range=None, views=None):
+    with arvx.Context(X, Y, Z, s, z_range=z_range) as ctx:
+        ctx.set_views(M, masks)
+        if state is not None:
+            ctx.upload_state(state)
+        if views is None:
+            ctx.carve(flags)
+        else:
+            ctx.carve_views(views[0], views[1], flags)
+        return ctx.download_state()
+
+
+def assert_same(got, want, what=""):
+    if not np.array_equal(got, want):
+        bad = np.argwhere(got != want)
+        z, y, x = bad[0]
+        raise AssertionError(
+            f"{what}: {len(bad)} of {got.size} voxels differ; first (x={x},y={y},z={z}) "
+            f"gpu={got[z, y, x]} oracle={want[z, y, x]}")
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("N,V", [(32, 6), (64, 8)])
+def test_sphere_parity(arvx, oracle, N, V, flags):
+    sc = scenes.small_sphere(N, V)
+    want = oracle.carve(N, N, N, sc.voxel_size, sc.M, sc.masks)
+    got = run_gpu(arvx, N, N, N, sc.voxel_size, sc.M, sc.masks, flags)
+    assert_same(got, want, f"sphere {N}^3 x {V} flags={flags}")
+    assert (want == 3).sum() > 0 and (want == 2).sum() > 0
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("dims", [(10, 10, 5), (50, 50, 25), (100, 100, 50), (33, 17, 9),
+                                  (64, 8, 8), (1, 1, 1), (130, 7, 19)])
+def test_ragged_grids(arvx, oracle, dims, flags):
+    """The reference's own benchmark sizes (src/main.cpp:306-440) and odd shapes."""
+    X, Y, Z = dims
+    sc = scenes.small_sphere(32, 5)
+    s = np.float32(0.512 / max(dims))
+    want = oracle.carve(X, Y, Z, s, sc.M, sc.masks)
+    got = run_gpu(arvx, X, Y, Z, s, sc.M, sc.masks, flags)
+    assert_same(got, want, f"grid {dims} flags={flags}")
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("C,block", [(1, 1), (3, 1), (1, 8), (3, 16)])
+def test_noise_masks_random_cameras(arvx, oracle, C, block, flags):
+    """Noise masks make every rounding decision visible; random cameras put
+    voxels behind the camera, on the image border and at tiny depth."""
+    N, V, W, H = 48, 7, 160, 120
+    s = np.float32(0.512 / N)
+    _, _, M = scenes.random_cameras(V, 0.512, seed=3 + C + block, W=W, H=H, inside=True)
+    masks = scenes.noise_masks(V, H, W, C=C, block=block, seed=C * 10 + block)
+    want = oracle.carve(N, N, N, s, M, masks)
+    got = run_gpu(arvx, N, N, N, s, M, masks, flags)
+    assert_same(got, want, f"noise C={C} block={block} flags={flags}")
+
+
+def test_cull_matches_no_cull_large(arvx):
+    """Size-independent property at a size the oracle would take minutes for:
+    the culled kernel and the brute-force kernel agree voxel for voxel."""
+    sc = scenes.syn.sphere_scene(256, 12)
+    a = run_gpu(arvx, 256, 256, 256, sc.voxel_size, sc.M, sc.masks, 0)
+    b = run_gpu(arvx, 256, 256, 256, sc.voxel_size, sc.M, sc.masks, 1)
+    assert_same(a, b, "cull vs no-cull 256^3")
+    occ = (a & 1).mean()
+    assert 0.1 < occ < 0.4  # visual hull of the 0.35E sphere
+    assert not np.any(a == 0)  # carved implies seen
+
+
+def test_precarved_state_and_view_ranges(arvx, oracle):
+    """carve ANDs into whatever the model holds (voxels set to w=0 by the caller,
+    unseen) and a view-by-view run equals the all-views run."""
+    N, V = 40, 6
+    sc = scenes.small_sphere(N, V)
+    rng = np.random.default_rng(5)
+    st0 = rng.choice(np.array([0, 1, 2, 3], np.uint8), size=(N, N, N))
+    want = oracle.carve(N, N, N, sc.voxel_size, sc.M, sc.masks, state=st0)
+    got = run_gpu(arvx, N, N, N, sc.voxel_size, sc.M, sc.masks, 0, state=st0)
+    assert_same(got, want, "pre-carved state")
+    with arvx.Context(N, N, N, sc.voxel_size) as ctx:
+        ctx.set_views(sc.M, sc.masks)
+        ctx.upload_state(st0)
+        cur = st0
+        for i in range(V):
+            ctx.carve_views(i, 1)
+            cur = oracle.carve_view(N, N, N, sc.voxel_size, sc.M[i], sc.masks[i], cur)
+            assert_same(ctx.download_state(), cur, f"after view {i}")
+    assert_same(cur, want, "view-by-view == all views")
+
+
+def test_z_slabs_concatenate(arvx, oracle):
+    N, V = 48, 6
+    sc = scenes.small_sphere(N, V)
+    want = oracle.carve(N, N, N, sc.voxel_size, sc.M, sc.masks)
+    parts = [run_gpu(arvx, N, N, N, sc.voxel_size, sc.M, sc.masks, 0, z_range=r)
+             for r in [(0, 13), (13, 14), (14, 40), (40, 48)]]
+    assert_same(np.concatenate(parts, axis=0), want, "z slabs")
+
+
+def test_many_views_chunks(arvx, oracle):
+    """More than 64 views: the per-lane view classification runs in chunks."""
+    N, V = 24, 70
+    sc = scenes.small_sphere(N, V, W=96, H=72)
+    want = oracle.carve(N, N, N, sc.voxel_size, sc.M, sc.masks)
+    for flags in (0, 1):
+        got = run_gpu(arvx, N, N, N, sc.voxel_size, sc.M, sc.masks, flags)
+        assert_same(got, want, f"70 views flags={flags}")
+
+
+def test_all_background_and_all_foreground(arvx, oracle):
+    N, V, W, H = 32, 3, 96, 72
+    sc = scenes.small_sphere(N, V, W=W, H=H)
+    for fill in (0, 255):
+        masks = np.full((V, H, W), fill, np.uint8)
+        want = oracle.carve(N, N, N, sc.voxel_size, sc.M, masks)
+        got = run_gpu(arvx, N, N, N, sc.voxel_size, sc.M, masks)
+        assert_same(got, want, f"fill={fill}")
+
+
+def test_stats_and_errors(arvx):
+    sc = scenes.small_sphere(64, 8)
+    with arvx.Context(64, 64, 64, sc.voxel_size) as ctx:
+        with pytest.raises(arvx.ArvxError):
+            ctx.carve()  # no views yet
+        ctx.set_views(sc.M, sc.masks)
+        ctx.carve(arvx.CARVE_STATS)
+        st = ctx.stats()
+        assert st["subtiles"] == 4 * 8 * 8
+        assert 0 < st["subtiles_carved"] < st["subtiles"]
+        with pytest.raises(arvx.ArvxError):
+            ctx.carve_views(5, 10)
+    with pytest.raises(arvx.ArvxError):
+        arvx.Context(0, 4, 4, 0.1)
+    with pytest.raises(arvx.ArvxError):
+        arvx.Context(4, 4, 4, -1.0)
