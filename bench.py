@@ -134,7 +134,10 @@ def main():
         nvox_global = X * Y * Z
         flags = capi.CARVE_NO_CULL if args.no_cull else 0
         ctx = capi.Context(X, Y, Z, sc.voxel_size, device=local_rank, z_range=(zlo, zhi))
-        stream = torch.cuda.current_stream()
+        # a real (non-null) HIP stream shared by torch and the library, so that the
+        # torch.cuda.Event pairs below bracket exactly the carve kernel launch
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
         ctx.set_stream(stream.cuda_stream)
         d_masks = torch.from_numpy(sc.masks).to(dev)  # resident before timing
         ctx.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)

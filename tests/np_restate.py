@@ -1,0 +1,143 @@
+"""Second, independent restatement of the path's arithmetic in vectorised numpy
+(IEEE float32/float64 element ops), used to cross-check the C oracle.
+Follows the same reference lines as oracle/arvx_oracle.c."""
+import numpy as np
+
+F32, F64 = np.float32, np.float64
+
+
+def to_word(s, x, y, z):
+    """Model::toWord, reference src/Model.h:134-140."""
+    s = F32(s)
+    wx = (np.asarray(y).astype(F32) * s).astype(F32)  # note the x/y swap
+    wy = (np.asarray(x).astype(F32) * s).astype(F32)
+    wz = ((-np.asarray(z)).astype(F32) * s).astype(F32)
+    return wx, wy, wz
+
+
+def project_raw(M, s, x, y, z):
+    """proj = M * world via the cv::gemm generic path: exact f64 products, summed
+    ((p0+p1)+p2)+p3, rounded to f32; then the two f32 divides."""
+    M = np.asarray(M, F32).reshape(3, 4).astype(F64)
+    w0, w1, w2 = (a.astype(F64) for a in to_word(s, x, y, z))
+    a = []
+    for r in range(3):
+        acc = ((M[r, 0] * w0 + M[r, 1] * w1) + M[r, 2] * w2) + M[r, 3] * 1.0
+        a.append(acc.astype(F32))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u = (a[0] / a[2]).astype(F32)
+        v = (a[1] / a[2]).astype(F32)
+    return a, u, v
+
+
+def round_half_away(t):
+    """std::round for float32 inputs, computed exactly in float64."""
+    t = np.asarray(t, F64)
+    return np.where(np.isfinite(t), np.copysign(np.floor(np.abs(t) + 0.5), t), np.nan)
+
+
+def project(M, s, x, y, z, W, H):
+    """-> (inside bool array, px, py)."""
+    _, u, v = project_raw(M, s, x, y, z)
+    ru, rv = round_half_away(u), round_half_away(v)
+    inside = (ru >= 0) & (ru < W) & (rv >= 0) & (rv < H)  # NaN compares false
+    px = np.where(inside, ru, 0).astype(np.int64)
+    py = np.where(inside, rv, 0).astype(np.int64)
+    return inside, px, py
+
+
+def is_background(mask, px, py):
+    m = np.asarray(mask)
+    if m.ndim == 2:
+        return m[py, px] == 0
+    return (m[py, px, :] == 0).all(axis=-1)
+
+
+def carve(X, Y, Z, s, Ms, masks, state=None):
+    """Dense carve, all views, on a (Z,Y,X) state plane (bit0 occ, bit1 seen)."""
+    z, y, x = np.meshgrid(np.arange(Z), np.arange(Y), np.arange(X), indexing="ij")
+    st = np.full((Z, Y, X), 1, np.uint8) if state is None else np.array(state, np.uint8)
+    Ms = np.asarray(Ms, F32).reshape(-1, 3, 4)
+    for i in range(Ms.shape[0]):
+        inside, px, py = project(Ms[i], s, x, y, z, masks[i].shape[1], masks[i].shape[0])
+        bg = is_background(masks[i], px, py) & inside
+        st = np.where(inside, st | 2, st)
+        st = np.where(bg, st & 0xFE, st).astype(np.uint8)
+    return st
+
+
+def depth(campos, s, x, y, z):
+    """cv::norm(cameras[i] - word_coord): f32 differences, f64 sum of squares."""
+    w0, w1, w2 = to_word(s, x, y, z)
+    c = np.asarray(campos, F32)
+    d0 = (c[0] - w0).astype(F32).astype(F64)
+    d1 = (c[1] - w1).astype(F32).astype(F64)
+    d2 = (c[2] - w2).astype(F32).astype(F64)
+    d3 = F64(0.0)
+    acc = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3
+    return np.sqrt(acc).astype(F32)
+
+
+def surface_mask(occ):
+    """occupied and not isInner (reference src/Model.h:126-132; outside = empty)."""
+    p = np.pad(occ, 1, constant_values=False)
+    inner = (p[1:-1, 1:-1, :-2] & p[1:-1, 1:-1, 2:] & p[1:-1, :-2, 1:-1] & p[1:-1, 2:, 1:-1] &
+             p[:-2, 1:-1, 1:-1] & p[2:, 1:-1, 1:-1])
+    return occ & ~inner
+
+
+def color(X, Y, Z, s, Ms, campos, images, mode, rgba):
+    """Colour vote (reference src/ColorReconstruction.h:34-74, .cpp:22-70)."""
+    rgba = np.array(rgba, F32).reshape(Z, Y, X, 4)
+    occ = rgba[..., 3] != 0
+    surf = surface_mask(occ)
+    zs, ys, xs = np.nonzero(surf)
+    Ms = np.asarray(Ms, F32).reshape(-1, 3, 4)
+    n = np.zeros(len(zs), np.int64)
+    ssum = np.zeros((len(zs), 3), F32)
+    best = np.zeros((len(zs), 3), F32)
+    bestd = np.full(len(zs), np.inf, F32)
+    for i in range(Ms.shape[0]):
+        H, W = images[i].shape[:2]
+        inside, px, py = project(Ms[i], s, xs, ys, zs, W, H)
+        bgr = images[i][py, px].astype(F32)
+        rgb = bgr[:, ::-1]
+        d = depth(campos[i], s, xs, ys, zs)
+        take = inside & ((n == 0) | (d < bestd))
+        best[take] = rgb[take]
+        bestd[take] = d[take]
+        ssum[inside] = (ssum[inside] + rgb[inside]).astype(F32)
+        n += inside
+    has = n > 0
+    out = rgba.copy()
+    if mode == 0:
+        col = best
+    else:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            col = round_half_away((ssum / n[:, None].astype(F32)).astype(F32)).astype(F32)
+    sel = (zs[has], ys[has], xs[has])
+    out[sel + (slice(0, 3),)] = col[has]
+    out[sel + (3,)] = 1.0
+    return out.reshape(-1, 4)
+
+
+def closure(X, Y, Z, rgba):
+    """applyClosure(kernel 3) == one 3x3x3 dilation with colour mean."""
+    a = np.array(rgba, F32).reshape(Z, Y, X, 4)
+    occ = a[..., 3] > 0
+    p = np.pad(np.where(occ[..., None], a, 0).astype(F32), ((1, 1), (1, 1), (1, 1), (0, 0)))
+    c = np.pad(occ.astype(np.int32), 1)
+    ssum = np.zeros_like(a)
+    cnt = np.zeros((Z, Y, X), np.int32)
+    # reference order: x offset outermost, then y, then z (sums of small ints: exact)
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                sl = (slice(1 + dz, 1 + dz + Z), slice(1 + dy, 1 + dy + Y),
+                      slice(1 + dx, 1 + dx + X))
+                ssum = (ssum + p[sl]).astype(F32)
+                cnt += c[sl]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        mean = (ssum / cnt[..., None].astype(F32)).astype(F32)
+    out = np.where(occ[..., None], a, np.where(cnt[..., None] > 0, mean, F32(0)))
+    return out.reshape(-1, 4).astype(F32)
