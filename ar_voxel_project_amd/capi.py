@@ -29,9 +29,10 @@ SYMBOLS = [
     "arvx_ctx_set_stream", "arvx_ctx_synchronize", "arvx_ctx_voxels",
     "arvx_compose_projection", "arvx_set_views", "arvx_set_views_device",
     "arvx_set_images", "arvx_state_reset", "arvx_state_upload",
-    "arvx_state_download", "arvx_state_device_ptr", "arvx_state_bind",
+    "arvx_state_download", "arvx_state_device_ptr", "arvx_state_upload_halo",
     "arvx_pack_occupancy", "arvx_carve", "arvx_carve_views", "arvx_fast_carve",
     "arvx_color", "arvx_surface_count", "arvx_surface_download",
+    "arvx_surface_depth_download",
     "arvx_export_model", "arvx_get_stats",
 ]
 
@@ -88,7 +89,7 @@ def load_library() -> C.CDLL:
     lib.arvx_state_upload.argtypes = [p, u8p]
     lib.arvx_state_download.argtypes = [p, u8p]
     lib.arvx_state_device_ptr.argtypes = [p, C.POINTER(p), C.POINTER(C.c_size_t)]
-    lib.arvx_state_bind.argtypes = [p, p]
+    lib.arvx_state_upload_halo.argtypes = [p, u8p, u8p]
     lib.arvx_pack_occupancy.argtypes = [p, p]
     lib.arvx_carve.argtypes = [p, C.c_uint]
     lib.arvx_carve_views.argtypes = [p, C.c_int, C.c_int, C.c_uint]
@@ -96,6 +97,7 @@ def load_library() -> C.CDLL:
     lib.arvx_color.argtypes = [p, C.c_int]
     lib.arvx_surface_count.argtypes = [p, C.POINTER(C.c_int64)]
     lib.arvx_surface_download.argtypes = [p, C.POINTER(C.c_int64), f32p]
+    lib.arvx_surface_depth_download.argtypes = [p, f32p]
     lib.arvx_export_model.argtypes = [p, f32p, C.c_int]
     lib.arvx_get_stats.argtypes = [p, C.POINTER(Stats)]
     for name in SYMBOLS:
@@ -220,8 +222,15 @@ class Context:
         _check(self._lib.arvx_state_device_ptr(self._h, C.byref(ptr), C.byref(n)))
         return int(ptr.value)
 
-    def bind_state(self, dev_ptr: int) -> None:
-        _check(self._lib.arvx_state_bind(self._h, C.c_void_p(dev_ptr)))
+    def upload_halo(self, below=None, above=None) -> None:
+        def ptr(a):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
+            assert a.size == self.X * self.Y
+            self._keep.append(a)
+            return a.ctypes.data_as(C.POINTER(C.c_uint8))
+        _check(self._lib.arvx_state_upload_halo(self._h, ptr(below), ptr(above)))
 
     def pack_occupancy(self, dev_words_ptr: int) -> None:
         _check(self._lib.arvx_pack_occupancy(self._h, C.c_void_p(dev_words_ptr)))
@@ -254,6 +263,14 @@ class Context:
             _check(self._lib.arvx_surface_download(
                 self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)), _fp(rgb)))
         return idx, rgb
+
+    def surface_depth(self) -> np.ndarray:
+        n = C.c_int64()
+        _check(self._lib.arvx_surface_count(self._h, C.byref(n)))
+        d = np.empty(n.value, np.float32)
+        if n.value:
+            _check(self._lib.arvx_surface_depth_download(self._h, _fp(d)))
+        return d
 
     def export_model(self, apply_unseen: bool = False) -> np.ndarray:
         out = np.empty((self.nvox, 4), np.float32)

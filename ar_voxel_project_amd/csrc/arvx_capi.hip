@@ -15,6 +15,8 @@
 
 #include "arvx_ctx.h"
 #include "carve_kernels.h"
+#include "color_kernels.h"
+#include <algorithm>
 
 namespace {
 
@@ -97,21 +99,23 @@ int arvx_ctx_create_slab(arvx_ctx **out, int device, int X, int Y, int Z, float 
     c->z0 = z_begin;
     c->z1 = z_end;
     c->s = voxel_size;
+    c->ze0 = z_begin > 0 ? z_begin - 1 : 0;
+    c->ze1 = z_end < Z ? z_end + 1 : Z;
     c->nvox = (size_t)X * Y * (size_t)(z_end - z_begin);
+    c->nvox_ext = (size_t)X * Y * (size_t)(c->ze1 - c->ze0);
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
         return arvx::fail_hip(e, "hipStreamCreate", __FILE__, __LINE__);
     }
     c->stream = c->own_stream;
-    e = hipMalloc(&c->d_state_own, c->nvox);
+    e = hipMalloc(&c->d_state, c->nvox_ext);
     if (e == hipSuccess) e = hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long));
     if (e != hipSuccess) {
         arvx_ctx_destroy(c);
         return arvx::fail_hip(e, "hipMalloc(state)", __FILE__, __LINE__);
     }
-    c->d_state = c->d_state_own;
-    e = hipMemsetAsync(c->d_state, 0x01, c->nvox, c->stream);
+    e = hipMemsetAsync(c->d_state, 0x01, c->nvox_ext, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->d_stats, 0, 64, c->stream);
     if (e != hipSuccess) {
         arvx_ctx_destroy(c);
@@ -131,7 +135,7 @@ int arvx_ctx_destroy(arvx_ctx *ctx) {
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     ctx->free_views();
     ctx->free_color();
-    if (ctx->d_state_own) (void)hipFree(ctx->d_state_own);
+    if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -265,14 +269,30 @@ int arvx_set_views_device(arvx_ctx *ctx, int V, const float *M, const float *cam
 
 int arvx_state_reset(arvx_ctx *ctx) {
     ARVX_CHECK_CTX(ctx);
-    ARVX_HIP(hipMemsetAsync(ctx->d_state, 0x01, ctx->nvox, ctx->stream));
+    ctx->color_ready = false;
+    ARVX_HIP(hipMemsetAsync(ctx->d_state, 0x01, ctx->nvox_ext, ctx->stream));
     return ARVX_OK;
 }
 
 int arvx_state_upload(arvx_ctx *ctx, const uint8_t *state) {
     ARVX_CHECK_CTX(ctx);
     if (!state) return fail(ARVX_ERR_INVALID, "null state");
-    ARVX_HIP(hipMemcpyAsync(ctx->d_state, state, ctx->nvox, hipMemcpyHostToDevice, ctx->stream));
+    ctx->color_ready = false;
+    ARVX_HIP(hipMemcpyAsync(ctx->owned(), state, ctx->nvox, hipMemcpyHostToDevice, ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    return ARVX_OK;
+}
+
+int arvx_state_upload_halo(arvx_ctx *ctx, const uint8_t *plane_below, const uint8_t *plane_above) {
+    ARVX_CHECK_CTX(ctx);
+    const size_t plane = (size_t)ctx->X * ctx->Y;
+    ctx->color_ready = false;
+    if (plane_below && ctx->ze0 < ctx->z0)
+        ARVX_HIP(hipMemcpyAsync(ctx->d_state, plane_below, plane, hipMemcpyHostToDevice,
+                                ctx->stream));
+    if (plane_above && ctx->ze1 > ctx->z1)
+        ARVX_HIP(hipMemcpyAsync(ctx->owned() + ctx->nvox, plane_above, plane,
+                                hipMemcpyHostToDevice, ctx->stream));
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
     return ARVX_OK;
 }
@@ -280,22 +300,15 @@ int arvx_state_upload(arvx_ctx *ctx, const uint8_t *state) {
 int arvx_state_download(arvx_ctx *ctx, uint8_t *state) {
     ARVX_CHECK_CTX(ctx);
     if (!state) return fail(ARVX_ERR_INVALID, "null state");
-    ARVX_HIP(hipMemcpyAsync(state, ctx->d_state, ctx->nvox, hipMemcpyDeviceToHost, ctx->stream));
+    ARVX_HIP(hipMemcpyAsync(state, ctx->owned(), ctx->nvox, hipMemcpyDeviceToHost, ctx->stream));
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
     return ARVX_OK;
 }
 
 int arvx_state_device_ptr(arvx_ctx *ctx, void **ptr, size_t *bytes) {
     if (!ctx || !ptr) return fail(ARVX_ERR_INVALID, "null argument");
-    *ptr = ctx->d_state;
+    *ptr = ctx->owned();
     if (bytes) *bytes = ctx->nvox;
-    return ARVX_OK;
-}
-
-int arvx_state_bind(arvx_ctx *ctx, void *dev_state) {
-    ARVX_CHECK_CTX(ctx);
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->d_state = dev_state ? (uint8_t *)dev_state : ctx->d_state_own;
     return ARVX_OK;
 }
 
@@ -305,7 +318,7 @@ int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
     const size_t nround = (ctx->nvox + 255) / 256;
     const unsigned grid = (unsigned)(nround < 8192 ? (nround ? nround : 1) : 8192);
     hipLaunchKernelGGL(arvx::pack_occupancy_kernel, dim3(grid), dim3(256), 0, ctx->stream,
-                       ctx->d_state, ctx->nvox, (uint32_t *)dev_words);
+                       ctx->owned(), ctx->nvox, (uint32_t *)dev_words);
     ARVX_HIP(hipGetLastError());
     return ARVX_OK;
 }
@@ -327,8 +340,9 @@ int arvx_carve_views(arvx_ctx *ctx, int first, int count, unsigned flags) {
     p.stats = ctx->d_stats;
     p.X = ctx->X;
     p.Y = ctx->Y;
-    p.Z = ctx->z1 - ctx->z0;
-    p.zoff = ctx->z0;
+    p.Z = ctx->ze1 - ctx->ze0;  // owned planes plus halo (recomputed, never exchanged)
+    p.zoff = ctx->ze0;
+    ctx->color_ready = false;
     p.s = ctx->s;
     p.W = ctx->W;
     p.H = ctx->H;
@@ -374,21 +388,201 @@ int arvx_get_stats(arvx_ctx *ctx, arvx_stats *out) {
     return ARVX_OK;
 }
 
+// ---- colour pass -----------------------------------------------------------------
+
+int arvx_set_images(arvx_ctx *ctx, const uint8_t *const *images, size_t stride) {
+    ARVX_CHECK_CTX(ctx);
+    if (!ctx->views_ready) return fail(ARVX_ERR_STATE, "arvx_set_views must come first");
+    if (!images) return fail(ARVX_ERR_INVALID, "null images");
+    const size_t rowb = (size_t)ctx->W * 3;
+    if (stride < rowb) return fail(ARVX_ERR_INVALID, "stride %zu < W*3", stride);
+    for (int i = 0; i < ctx->V; ++i)
+        if (!images[i]) return fail(ARVX_ERR_INVALID, "null image %d", i);
+    const size_t img = rowb * ctx->H;
+    if (!ctx->d_images) ARVX_HIP(hipMalloc(&ctx->d_images, img * ctx->V));
+    for (int i = 0; i < ctx->V; ++i)
+        ARVX_HIP(hipMemcpy2DAsync(ctx->d_images + img * i, rowb, images[i], stride, rowb, ctx->H,
+                                  hipMemcpyHostToDevice, ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->images_ready = true;
+    ctx->color_ready = false;
+    return ARVX_OK;
+}
+
+int arvx_color(arvx_ctx *ctx, int mode) {
+    ARVX_CHECK_CTX(ctx);
+    if (!ctx->views_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
+    if (!ctx->images_ready) return fail(ARVX_ERR_STATE, "arvx_set_images has not been called");
+    if (!ctx->has_campos) return fail(ARVX_ERR_STATE, "arvx_set_views was given no campos");
+    if (mode != ARVX_COLOR_CLOSEST && mode != ARVX_COLOR_AVERAGE)
+        return fail(ARVX_ERR_INVALID, "colour mode %d", mode);
+    ctx->free_surface();
+    arvx::SurfaceParams sp;
+    sp.state_ext = ctx->d_state;
+    sp.X = ctx->X;
+    sp.Y = ctx->Y;
+    sp.Zown = ctx->z1 - ctx->z0;
+    sp.halo_lo = ctx->z0 - ctx->ze0;
+    sp.Zext = ctx->ze1 - ctx->ze0;
+    sp.nown = ctx->nvox;
+    const int nblk = (int)((ctx->nvox + arvx::kSurfChunk - 1) / arvx::kSurfChunk);
+    const size_t need = (size_t)nblk * sizeof(int) + (size_t)(nblk + 1) * sizeof(long long) + 64;
+    if (ctx->scratch_bytes < need) {
+        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        ARVX_HIP(hipMalloc(&ctx->d_scratch, need));
+        ctx->scratch_bytes = need;
+    }
+    long long *d_off = (long long *)ctx->d_scratch;
+    int *d_cnt = (int *)(d_off + nblk + 1);
+    hipLaunchKernelGGL(arvx::surface_count_kernel, dim3(nblk), dim3(256), 0, ctx->stream, sp,
+                       d_cnt);
+    hipLaunchKernelGGL(arvx::surface_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, d_cnt, nblk,
+                       d_off);
+    long long total = 0;
+    ARVX_HIP(hipMemcpyAsync(&total, d_off + nblk, sizeof total, hipMemcpyDeviceToHost,
+                            ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->surf_count = total;
+    if (total > 0) {
+        ARVX_HIP(hipMalloc(&ctx->d_surf_index, (size_t)total * sizeof(int)));
+        ARVX_HIP(hipMalloc(&ctx->d_surf_rgb, (size_t)total * 3 * sizeof(float)));
+        ARVX_HIP(hipMalloc(&ctx->d_surf_depth, (size_t)total * sizeof(float)));
+        ARVX_HIP(hipMalloc(&ctx->d_surf_has, (size_t)total));
+        hipLaunchKernelGGL(arvx::surface_write_kernel, dim3(nblk), dim3(256), 0, ctx->stream, sp,
+                           d_off, ctx->d_surf_index);
+        arvx::VoteParams vp;
+        vp.index = ctx->d_surf_index;
+        vp.n = total;
+        vp.X = ctx->X;
+        vp.Y = ctx->Y;
+        vp.zglob0 = ctx->z0;
+        vp.s = ctx->s;
+        vp.V = ctx->V;
+        vp.W = ctx->W;
+        vp.H = ctx->H;
+        vp.M = ctx->d_M;
+        vp.campos = ctx->d_campos;
+        vp.images = ctx->d_images;
+        vp.mode = mode;
+        vp.rgb = ctx->d_surf_rgb;
+        vp.depth = ctx->d_surf_depth;
+        vp.has = ctx->d_surf_has;
+        hipLaunchKernelGGL(arvx::color_vote_kernel, dim3((unsigned)((total + 255) / 256)),
+                           dim3(256), 0, ctx->stream, vp);
+        ARVX_HIP(hipGetLastError());
+        ctx->h_surf_index.resize((size_t)total);
+        ctx->h_surf_has.resize((size_t)total);
+        ARVX_HIP(hipMemcpyAsync(ctx->h_surf_index.data(), ctx->d_surf_index,
+                                (size_t)total * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        ARVX_HIP(hipMemcpyAsync(ctx->h_surf_has.data(), ctx->d_surf_has, (size_t)total,
+                                hipMemcpyDeviceToHost, ctx->stream));
+        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    unsigned long long sv = (unsigned long long)total;
+    ARVX_HIP(hipMemcpyAsync(ctx->d_stats + 4, &sv, sizeof sv, hipMemcpyHostToDevice, ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->color_ready = true;
+    return ARVX_OK;
+}
+
+int arvx_surface_count(arvx_ctx *ctx, int64_t *count) {
+    if (!ctx || !count) return fail(ARVX_ERR_INVALID, "null argument");
+    if (!ctx->color_ready) return fail(ARVX_ERR_STATE, "no colour result (call arvx_color)");
+    int64_t n = 0;
+    for (uint8_t h : ctx->h_surf_has) n += h;
+    *count = n;
+    return ARVX_OK;
+}
+
+static int surface_fetch(Ctx *ctx, std::vector<float> &rgb, std::vector<float> &depth) {
+    rgb.resize((size_t)ctx->surf_count * 3);
+    depth.resize((size_t)ctx->surf_count);
+    if (ctx->surf_count) {
+        ARVX_HIP(hipMemcpyAsync(rgb.data(), ctx->d_surf_rgb, rgb.size() * sizeof(float),
+                                hipMemcpyDeviceToHost, ctx->stream));
+        ARVX_HIP(hipMemcpyAsync(depth.data(), ctx->d_surf_depth, depth.size() * sizeof(float),
+                                hipMemcpyDeviceToHost, ctx->stream));
+        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return ARVX_OK;
+}
+
+int arvx_surface_download(arvx_ctx *ctx, int64_t *index, float *rgb) {
+    ARVX_CHECK_CTX(ctx);
+    if (!index || !rgb) return fail(ARVX_ERR_INVALID, "null argument");
+    if (!ctx->color_ready) return fail(ARVX_ERR_STATE, "no colour result (call arvx_color)");
+    std::vector<float> hrgb, hdepth;
+    int rc = surface_fetch(ctx, hrgb, hdepth);
+    if (rc) return rc;
+    size_t k = 0;
+    for (size_t e = 0; e < ctx->h_surf_has.size(); ++e) {
+        if (!ctx->h_surf_has[e]) continue;
+        index[k] = ctx->h_surf_index[e];
+        rgb[3 * k] = hrgb[3 * e];
+        rgb[3 * k + 1] = hrgb[3 * e + 1];
+        rgb[3 * k + 2] = hrgb[3 * e + 2];
+        ++k;
+    }
+    return ARVX_OK;
+}
+
+int arvx_surface_depth_download(arvx_ctx *ctx, float *depth) {
+    ARVX_CHECK_CTX(ctx);
+    if (!depth) return fail(ARVX_ERR_INVALID, "null argument");
+    if (!ctx->color_ready) return fail(ARVX_ERR_STATE, "no colour result (call arvx_color)");
+    std::vector<float> hrgb, hdepth;
+    int rc = surface_fetch(ctx, hrgb, hdepth);
+    if (rc) return rc;
+    size_t k = 0;
+    for (size_t e = 0; e < ctx->h_surf_has.size(); ++e)
+        if (ctx->h_surf_has[e]) depth[k++] = hdepth[e];
+    return ARVX_OK;
+}
+
+// Model::voxels of the owned voxels, built on the device in chunks and copied out.
+int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen) {
+    ARVX_CHECK_CTX(ctx);
+    if (!rgba) return fail(ARVX_ERR_INVALID, "null rgba");
+    const size_t chunk = (size_t)1 << 24;  // voxels per chunk: 256 MiB of float4
+    const size_t nchunk = std::min(chunk, ctx->nvox);
+    float4 *d_out = nullptr;
+    ARVX_HIP(hipMalloc(&d_out, nchunk * sizeof(float4)));
+    int rc = ARVX_OK;
+    for (size_t i0 = 0; i0 < ctx->nvox && rc == ARVX_OK; i0 += chunk) {
+        const size_t n = std::min(chunk, ctx->nvox - i0);
+        const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 16384);
+        hipLaunchKernelGGL(arvx::export_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream,
+                           ctx->owned(), i0, n, d_out, apply_unseen);
+        if (ctx->color_ready && ctx->surf_count > 0) {
+            const auto &idx = ctx->h_surf_index;
+            const long long first =
+                std::lower_bound(idx.begin(), idx.end(), (int)i0) - idx.begin();
+            const long long last = (i0 + n > (size_t)INT32_MAX)
+                                       ? (long long)idx.size()
+                                       : std::lower_bound(idx.begin(), idx.end(), (int)(i0 + n)) -
+                                             idx.begin();
+            if (last > first)
+                hipLaunchKernelGGL(arvx::export_scatter_kernel,
+                                   dim3((unsigned)((last - first + 255) / 256)), dim3(256), 0,
+                                   ctx->stream, ctx->d_surf_index, ctx->d_surf_rgb,
+                                   ctx->d_surf_has, first, last, ctx->owned(), i0, d_out,
+                                   apply_unseen);
+        }
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(rgba + 4 * i0, d_out, n * sizeof(float4), hipMemcpyDeviceToHost,
+                               ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = arvx::fail_hip(e, "export chunk", __FILE__, __LINE__);
+    }
+    (void)hipFree(d_out);
+    return rc;
+}
+
 // ---- not yet built -------------------------------------------------------------
 
-int arvx_set_images(arvx_ctx *, const uint8_t *const *, size_t) {
-    return fail(ARVX_ERR_STATE, "arvx_set_images: not implemented yet");
-}
 int arvx_fast_carve(arvx_ctx *) { return fail(ARVX_ERR_STATE, "arvx_fast_carve: not implemented yet"); }
-int arvx_color(arvx_ctx *, int) { return fail(ARVX_ERR_STATE, "arvx_color: not implemented yet"); }
-int arvx_surface_count(arvx_ctx *, int64_t *) {
-    return fail(ARVX_ERR_STATE, "arvx_surface_count: not implemented yet");
-}
-int arvx_surface_download(arvx_ctx *, int64_t *, float *) {
-    return fail(ARVX_ERR_STATE, "arvx_surface_download: not implemented yet");
-}
-int arvx_export_model(arvx_ctx *, float *, int) {
-    return fail(ARVX_ERR_STATE, "arvx_export_model: not implemented yet");
-}
 
 }  // extern "C"

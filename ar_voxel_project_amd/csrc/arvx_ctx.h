@@ -21,15 +21,17 @@ int fail_msg(int code, const char *msg);
 struct Ctx {
     int device = 0;
     int X = 0, Y = 0, Z = 0;  // full grid
-    int z0 = 0, z1 = 0;       // slab held here
+    int z0 = 0, z1 = 0;       // slab owned here
+    int ze0 = 0, ze1 = 0;     // slab plus one halo plane each side (clipped to the grid)
     float s = 0.f;
-    size_t nvox = 0;  // slab voxels
+    size_t nvox = 0;      // owned voxels
+    size_t nvox_ext = 0;  // voxels in the state buffer (owned + halo)
 
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
 
-    uint8_t *d_state_own = nullptr;
-    uint8_t *d_state = nullptr;  // own or bound
+    uint8_t *d_state = nullptr;  // planes ze0..ze1-1
+    uint8_t *owned() const { return d_state + (size_t)(z0 - ze0) * X * Y; }
     unsigned long long *d_stats = nullptr;
     void *d_scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -50,9 +52,11 @@ struct Ctx {
     bool images_ready = false;
     int *d_surf_index = nullptr;      // compacted flat indices (slab-local)
     float *d_surf_rgb = nullptr;      // 3 floats per surface voxel
+    float *d_surf_depth = nullptr;    // minimum sample depth per surface voxel
     uint8_t *d_surf_has = nullptr;    // 1 if the voxel received >= 1 sample
     int64_t surf_count = 0;           // occupied non-inner voxels found
-    int64_t surf_capacity = 0;
+    std::vector<int> h_surf_index;    // host copy (ascending)
+    std::vector<uint8_t> h_surf_has;
     bool color_ready = false;
 
     void free_views() {
@@ -65,17 +69,24 @@ struct Ctx {
         d_sat = nullptr;
         views_ready = false;
     }
-    void free_color() {
-        if (d_images) (void)hipFree(d_images);
+    void free_surface() {
         if (d_surf_index) (void)hipFree(d_surf_index);
         if (d_surf_rgb) (void)hipFree(d_surf_rgb);
+        if (d_surf_depth) (void)hipFree(d_surf_depth);
         if (d_surf_has) (void)hipFree(d_surf_has);
-        d_images = nullptr;
         d_surf_index = nullptr;
-        d_surf_rgb = nullptr;
+        d_surf_rgb = d_surf_depth = nullptr;
         d_surf_has = nullptr;
-        images_ready = color_ready = false;
-        surf_count = surf_capacity = 0;
+        color_ready = false;
+        surf_count = 0;
+        h_surf_index.clear();
+        h_surf_has.clear();
+    }
+    void free_color() {
+        free_surface();
+        if (d_images) (void)hipFree(d_images);
+        d_images = nullptr;
+        images_ready = false;
     }
 };
 

@@ -1,0 +1,223 @@
+// color_kernels.h -- per-voxel colour vote and model export for gfx950.
+//
+// Replaces the reference's colour pass: the `voxel_pass` loops of
+// src/ColorReconstruction.h:34-74 plus the bodies of reconstructClosestColor
+// (src/ColorReconstruction.cpp:26-42) and reconstructAvgColor (:52-66), and
+// Model::handleUnseen (src/Model.cpp:36-47) at export time.
+//
+// The reference walks all N voxels and votes only on occupied voxels that are
+// not "inner" (all six neighbours occupied, src/Model.h:126-132).  Here the
+// surface is first compacted into an index list in ascending flat-index order
+// (two passes over the u8 state plane, block-ordered so no sort is needed), then
+// one thread per surface voxel gathers its samples from the BGR images.
+#pragma once
+
+#include "arvx_device.h"
+
+namespace arvx {
+
+constexpr int kSurfChunk = 65536;  // voxels scanned by one workgroup
+
+struct SurfaceParams {
+    const uint8_t *state_ext;  // extended slab (with halo planes)
+    int X, Y;
+    int Zown;     // owned planes
+    int halo_lo;  // planes in front of the owned range inside state_ext (0/1)
+    int Zext;     // planes in state_ext
+    size_t nown;  // owned voxels
+};
+
+// occupied and not inner; neighbours outside the GRID count as empty
+// (Model::get returns zero there, reference src/Model.h:119-122); neighbours
+// outside the slab but inside the grid are read from the halo planes.
+__device__ __forceinline__ bool is_surface(const SurfaceParams &p, size_t i) {
+    const int x = (int)(i % p.X);
+    const size_t t = i / p.X;
+    const int y = (int)(t % p.Y);
+    const int ze = (int)(t / p.Y) + p.halo_lo;  // plane index inside state_ext
+    const size_t row = (size_t)p.X, plane = (size_t)p.X * p.Y;
+    const uint8_t *c = p.state_ext + (size_t)ze * plane + (size_t)y * row + x;
+    if (!(c[0] & 1u)) return false;
+    bool inner = true;
+    inner = inner && (x > 0) && (c[-1] & 1u);
+    inner = inner && (x + 1 < p.X) && (c[1] & 1u);
+    inner = inner && (y > 0) && (c[-(ptrdiff_t)row] & 1u);
+    inner = inner && (y + 1 < p.Y) && (c[row] & 1u);
+    inner = inner && (ze > 0) && (c[-(ptrdiff_t)plane] & 1u);
+    inner = inner && (ze + 1 < p.Zext) && (c[plane] & 1u);
+    return !inner;
+}
+
+__global__ __launch_bounds__(256) void surface_count_kernel(const SurfaceParams p,
+                                                            int *__restrict__ counts) {
+    __shared__ int wsum[4];
+    const size_t base = (size_t)blockIdx.x * kSurfChunk;
+    int mine = 0;
+    for (int it = 0; it < kSurfChunk / 256; ++it) {
+        const size_t i = base + (size_t)it * 256 + threadIdx.x;
+        const bool f = (i < p.nown) && is_surface(p, i);
+        mine += __popcll(__ballot(f));  // same value in every lane of the wave
+    }
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of `counts` (n entries) by ONE workgroup; offsets[n] = total
+__global__ __launch_bounds__(256) void surface_scan_kernel(const int *__restrict__ counts, int n,
+                                                           long long *__restrict__ offsets) {
+    __shared__ long long wtot[4];
+    __shared__ long long carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b0 = 0; b0 < n; b0 += 256) {
+        const int i = b0 + threadIdx.x;
+        const long long v = (i < n) ? counts[i] : 0;
+        long long sc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long t = __shfl_up(sc, d);
+            if (lane >= d) sc += t;
+        }
+        if (lane == 63) wtot[wave] = sc;
+        __syncthreads();
+        long long pre = carry_s;
+        for (int w = 0; w < wave; ++w) pre += wtot[w];
+        if (i < n) offsets[i] = pre + sc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[n] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void surface_write_kernel(const SurfaceParams p,
+                                                            const long long *__restrict__ offsets,
+                                                            int *__restrict__ index) {
+    __shared__ int wcnt[4];
+    const size_t base = (size_t)blockIdx.x * kSurfChunk;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long run = offsets[blockIdx.x];
+    for (int it = 0; it < kSurfChunk / 256; ++it) {
+        const size_t i = base + (size_t)it * 256 + threadIdx.x;
+        const bool f = (i < p.nown) && is_surface(p, i);
+        const unsigned long long b = __ballot(f);
+        if (lane == 0) wcnt[wave] = __popcll(b);
+        __syncthreads();
+        long long pre = run;
+        for (int w = 0; w < wave; ++w) pre += wcnt[w];
+        if (f) index[pre + __popcll(b & ((1ull << lane) - 1ull))] = (int)i;
+        run += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+}
+
+struct VoteParams {
+    const int *index;  // surface voxels, slab-local flat index over owned planes
+    long long n;
+    int X, Y;
+    int zglob0;  // global z of owned plane 0
+    float s;
+    int V, W, H;
+    const float *M;       // V x 12
+    const float *campos;  // V x 3
+    const uint8_t *images;  // V x H x W x 3 BGR
+    int mode;
+    float *rgb;    // n x 3
+    float *depth;  // n   (minimum sample depth)
+    uint8_t *has;  // n   (1 if >= 1 sample)
+};
+
+__global__ __launch_bounds__(256) void color_vote_kernel(const VoteParams p) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.n) return;
+    const int i = p.index[t];
+    const int x = i % p.X;
+    const int y = (i / p.X) % p.Y;
+    const int z = p.zglob0 + i / (p.X * p.Y);
+    // Model::toWord, reference src/Model.h:134-140
+    const float w0 = (float)y * p.s, w1 = (float)x * p.s, w2 = (float)(-z) * p.s;
+    const double d0w = (double)w0, d1w = (double)w1, d2w = (double)w2;
+    unsigned sr = 0, sg = 0, sb = 0, n = 0;
+    float best = 0.f, br = 0.f, bgc = 0.f, bb = 0.f;
+    for (int v = 0; v < p.V; ++v) {
+        const float *__restrict__ Mv = p.M + 12 * v;
+        float a[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double p0 = (double)Mv[4 * r] * d0w;
+            const double p1 = (double)Mv[4 * r + 1] * d1w;
+            const double p2 = (double)Mv[4 * r + 2] * d2w;
+            const double p3 = (double)Mv[4 * r + 3];
+            a[r] = row_sum(p0 + p1, p2, p3);
+        }
+        int pix;
+        if (!pixel_of(a[0], a[1], a[2], p.W, p.H, pix)) continue;  // ColorReconstruction.h:54-57
+        const uint8_t *q = p.images + ((size_t)v * p.W * p.H + pix) * 3;
+        const unsigned b = q[0], g = q[1], r = q[2];  // Vec3b is BGR; colour = (R,G,B,1), :59
+        // cv::norm(cameras[i] - word_coord): fp32 differences, fp64 sum of squares, :59
+        const float *c = p.campos + 3 * v;
+        const double e0 = (double)(c[0] - w0), e1 = (double)(c[1] - w1), e2 = (double)(c[2] - w2);
+        const double e3 = (double)(1.f - 1.f);
+        const double acc = ((e0 * e0 + e1 * e1) + e2 * e2) + e3 * e3;
+        const float depth = (float)sqrt(acc);
+        if (n == 0 || depth < best) {  // strict <: the first view wins ties, .cpp:33-40
+            best = depth;
+            br = (float)r;
+            bgc = (float)g;
+            bb = (float)b;
+        }
+        sr += r;
+        sg += g;
+        sb += b;
+        ++n;
+    }
+    p.has[t] = n ? 1 : 0;
+    p.depth[t] = best;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (n) {
+        if (p.mode == 0) {
+            o0 = br;
+            o1 = bgc;
+            o2 = bb;
+        } else {
+            const float fn = (float)n;  // sums <= 255*V are exact in fp32
+            o0 = roundf((float)sr / fn);  // .cpp:64-65
+            o1 = roundf((float)sg / fn);
+            o2 = roundf((float)sb / fn);
+        }
+    }
+    p.rgb[3 * t] = o0;
+    p.rgb[3 * t + 1] = o1;
+    p.rgb[3 * t + 2] = o2;
+}
+
+// Model::voxels for owned voxels [i0, i0+n): MODEL_COLOR where occupied, zero
+// where carved (reference src/Model.cpp:9-14, src/VoxelCarving.cpp:52) and,
+// with apply_unseen, UNSEEN_COLOR where never seen (src/Model.cpp:36-47).
+__global__ __launch_bounds__(256) void export_fill_kernel(const uint8_t *__restrict__ state_own,
+                                                          size_t i0, size_t n,
+                                                          float4 *__restrict__ out,
+                                                          int apply_unseen) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
+        const uint8_t st = state_own[i0 + k];
+        float4 v = (st & 1u) ? make_float4(50.f, 168.f, 141.f, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (apply_unseen && !(st & 2u)) v = make_float4(204.f, 0.f, 0.f, 1.f);
+        out[k] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void export_scatter_kernel(
+    const int *__restrict__ index, const float *__restrict__ rgb, const uint8_t *__restrict__ has,
+    long long first, long long last, const uint8_t *__restrict__ state_own, size_t i0,
+    float4 *__restrict__ out, int apply_unseen) {
+    const long long e = first + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= last || !has[e]) return;
+    const size_t i = (size_t)index[e];
+    if (apply_unseen && !(state_own[i] & 2u)) return;  // handleUnseen runs after colouring
+    out[i - i0] = make_float4(rgb[3 * e], rgb[3 * e + 1], rgb[3 * e + 2], 1.f);
+}
+
+}  // namespace arvx

@@ -120,10 +120,17 @@ int arvx_set_images(arvx_ctx *ctx, const uint8_t *const *images, size_t stride);
 int arvx_state_reset(arvx_ctx *ctx);
 int arvx_state_upload(arvx_ctx *ctx, const uint8_t *state);
 int arvx_state_download(arvx_ctx *ctx, uint8_t *state);
-/* Device address of the state plane (slab), for zero-copy consumers. */
+/* Device address of the owned part of the state plane, for zero-copy consumers. */
 int arvx_state_device_ptr(arvx_ctx *ctx, void **ptr, size_t *bytes);
-/* Use caller-owned device memory (>= slab voxels bytes) as the state plane. */
-int arvx_state_bind(arvx_ctx *ctx, void *dev_state);
+/* Slab contexts keep one halo plane on each side that lies inside the grid
+ * (z_begin-1 and z_end), because the colour pass needs the six neighbours of
+ * every voxel (reference Model::isInner, src/Model.h:126-132).  arvx_carve
+ * recomputes the halo planes itself (carving is a pure function of the voxel
+ * position), arvx_state_reset makes them fresh, arvx_state_upload leaves them
+ * untouched.  A caller that uploads a pre-carved model into a slab passes the
+ * neighbouring planes here (X*Y bytes each; NULL = leave as is). */
+int arvx_state_upload_halo(arvx_ctx *ctx, const uint8_t *plane_below,
+                           const uint8_t *plane_above);
 /* Pack bit0 (occupied) of the slab into 32-bit words, voxel i -> bit i%32 of
  * word i/32, written to device memory dev_words (>= ceil(n/32) words). */
 int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words);
@@ -147,6 +154,9 @@ int arvx_color(arvx_ctx *ctx, int mode);
  * and RGB values (3 floats each, integral), ascending index order. */
 int arvx_surface_count(arvx_ctx *ctx, int64_t *count);
 int arvx_surface_download(arvx_ctx *ctx, int64_t *index, float *rgb);
+/* Smallest sample depth of each coloured voxel (same order), as the reference
+ * computes it: (float)cv::norm(cameras[i] - world), src/ColorReconstruction.h:59. */
+int arvx_surface_depth_download(arvx_ctx *ctx, float *depth);
 /* Model::voxels as the reference would hold it after carve [+ colour]
  * [+ handleUnseen]: n*4 floats (RGBA), n = slab voxels. */
 int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen);
