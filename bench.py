@@ -38,24 +38,6 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def grid_for(world: int, base: int):
-    """Grid (X, Y, Z) holding ~world x base^3 voxels, cubic, multiple of 8 per axis."""
-    if world == 1:
-        return base, base, base
-    n = int(round(base * world ** (1.0 / 3.0) / 8.0)) * 8
-    return n, n, n
-
-
-def slab_of(Z: int, world: int, rank: int):
-    """Contiguous Z slab of rank: planes split as evenly as 8-plane tiles allow."""
-    tiles = (Z + 7) // 8
-    lo = (tiles * rank) // world * 8
-    hi = min(Z, (tiles * (rank + 1)) // world * 8)
-    if rank == world - 1:
-        hi = Z
-    return lo, hi
-
-
 def cpu_baseline(sc, X, Y, Z, budget_s=12.0):
     """The CPU oracle timed on this host, on a bounded sample of the same workload.
     Primary figure: the reference-shaped port (AoS float voxels, x->y->z loops, M
@@ -114,23 +96,31 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    # ARVX_BENCH_ONE_GPU=1 rehearses the N>1 code path on a one-GPU box (all ranks
+    # on cuda:0, gloo instead of RCCL); never set by the driver.
+    rehearsal = os.environ.get("ARVX_BENCH_ONE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from ar_voxel_project_amd import capi, synthetic
+    from ar_voxel_project_amd import capi, sharding, synthetic
 
     def barrier():
         if world > 1:
             dist.barrier()
 
     def run_config(base, V, steps, warmup, collective):
-        X, Y, Z = grid_for(world, base)
+        X, Y, Z = sharding.grid_for(world, base)
         sc = synthetic.sphere_scene(max(X, Y, Z), V)
         sc.X, sc.Y, sc.Z = X, Y, Z
-        zlo, zhi = slab_of(Z, world, rank)
+        zlo, zhi = sharding.slab_of(Z, world, rank)
         nvox_global = X * Y * Z
         flags = capi.CARVE_NO_CULL if args.no_cull else 0
         ctx = capi.Context(X, Y, Z, sc.voxel_size, device=local_rank, z_range=(zlo, zhi))
@@ -141,42 +131,44 @@ def main():
         ctx.set_stream(stream.cuda_stream)
         d_masks = torch.from_numpy(sc.masks).to(dev)  # resident before timing
         ctx.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
-        nwords_global = (nvox_global + 31) // 32
-        occ_bits = None
+        ex = None
         if world > 1 and collective != "none":
-            occ_bits = torch.zeros(nwords_global, dtype=torch.int32, device=dev)
-            off_words = (X * Y * zlo) // 32  # X*Y*8 planes granularity -> multiple of 32
-            my_words = (X * Y * (zhi - zlo) + 31) // 32
+            ex = sharding.OccupancyExchange(X, Y, Z, world, rank, dev, mode=collective, buffers=2)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
               for _ in range(steps)]
+        nstep = [0]
 
         def step(i=None):
+            # one job: fresh model -> carve all views -> (N>1) merge the occupancy of
+            # all slabs.  The collective of job k runs on RCCL's stream while job
+            # k+1 carves (two packed buffers); the final wait is inside the timing.
             ctx.reset()
             if i is not None:
                 ev[i][0].record(stream)
             ctx.carve(flags)
             if i is not None:
                 ev[i][1].record(stream)
-            if occ_bits is not None:
-                if collective == "allreduce":
-                    occ_bits.zero_()
-                    ctx.pack_occupancy(occ_bits.data_ptr() + 4 * off_words)
-                    dist.all_reduce(occ_bits, op=dist.ReduceOp.MAX)
-                else:
-                    ctx.pack_occupancy(occ_bits.data_ptr() + 4 * off_words)
-                    parts = [occ_bits[(X * Y * slab_of(Z, world, r)[0]) // 32:
-                                      (X * Y * slab_of(Z, world, r)[1] + 31) // 32]
-                             for r in range(world)]
-                    dist.all_gather(parts, parts[rank])
+            if ex is not None:
+                b = nstep[0] % 2
+                ex.prepare(b)
+                ctx.pack_occupancy(ex.my_slice(b).data_ptr())
+                ex.launch(b, async_op=True)
+            nstep[0] += 1
+
+        def drain():
+            if ex is not None:
+                ex.wait_all()
+            torch.cuda.synchronize()
 
         for _ in range(warmup):
             step()
+        drain()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
             step(i)
-        torch.cuda.synchronize()
+        drain()
         barrier()
         dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -188,6 +180,11 @@ def main():
         if rank == 0:
             st = ctx.download_state()
             occ = float((st & 1).mean())
+            if ex is not None:  # the merged plane must hold this rank's slab bits
+                mine = np.packbits((st.reshape(-1) & 1).astype(np.uint8), bitorder="little")
+                got = ex.my_slice((nstep[0] - 1) % 2).cpu().numpy().view(np.uint8)
+                if not np.array_equal(got[:len(mine)], mine):
+                    raise SystemExit("merged occupancy does not contain rank 0's slab")
         ctx.close()
         del d_masks
         return dict(X=X, Y=Y, Z=Z, V=V, dt=dt, kern_ms=kern_ms, sc=sc, occ=occ,

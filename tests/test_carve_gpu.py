@@ -144,3 +144,25 @@ def test_stats_and_errors(arvx):
         arvx.Context(0, 4, 4, 0.1)
     with pytest.raises(arvx.ArvxError):
         arvx.Context(4, 4, 4, -1.0)
+
+
+def test_pack_occupancy_layout(arvx, oracle):
+    """voxel i -> bit i%32 of word i//32, slab-local: what the RCCL exchange ships."""
+    import torch
+    X, Y, Z, V = 24, 8, 12, 4
+    sc = scenes.small_sphere(32, V, W=96, H=72)
+    s = np.float32(0.512 / 24)
+    want = oracle.carve(X, Y, Z, s, sc.M, sc.masks)
+    for zr in [(0, 12), (4, 8)]:
+        with arvx.Context(X, Y, Z, s, z_range=zr) as ctx:
+            ctx.set_views(sc.M, sc.masks)
+            ctx.carve()
+            n = X * Y * (zr[1] - zr[0])
+            words = torch.full(((n + 31) // 32 + 2,), -1, dtype=torch.int32, device="cuda")
+            ctx.pack_occupancy(words.data_ptr())
+            ctx.synchronize()
+            got = words.cpu().numpy()
+        occ = (want[zr[0]:zr[1]].reshape(-1) & 1).astype(np.uint8)
+        ref = np.packbits(occ, bitorder="little").view(np.int32)
+        assert np.array_equal(got[:len(ref)], ref)
+        assert np.all(got[len(ref):] == -1), "wrote past the slab's words"
