@@ -27,6 +27,14 @@ def build_oracle() -> str:
     return os.path.join(ROOT, "oracle", "libarvx_oracle.so")
 
 
+def build_host_tests() -> str:
+    """g++ -> tests/cpp/test_host: the C++ host layer (include/arvx/*.hpp) over libarvx.so"""
+    build_library()
+    _make("tests/cpp")
+    return os.path.join(ROOT, "tests", "cpp", "test_host")
+
+
 if __name__ == "__main__":
     print(build_library())
     print(build_oracle())
+    print(build_host_tests())

@@ -16,6 +16,7 @@
 #include "arvx_ctx.h"
 #include "carve_kernels.h"
 #include "color_kernels.h"
+#include "fast_carve_kernels.h"
 #include <algorithm>
 
 namespace {
@@ -325,15 +326,10 @@ int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
 
 // ---- carve -------------------------------------------------------------------
 
-int arvx_carve_views(arvx_ctx *ctx, int first, int count, unsigned flags) {
-    ARVX_CHECK_CTX(ctx);
-    if (!ctx->views_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
-    if (first < 0 || count < 0 || first + count > ctx->V)
-        return fail(ARVX_ERR_INVALID, "view range [%d,%d) outside [0,%d)", first, first + count,
-                    ctx->V);
-    if (count == 0) return ARVX_OK;
+// Launches the fused carve over planes [ze0, ze1) of `state` (owned + halo).
+static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned flags) {
     arvx::CarveParams p;
-    p.state = ctx->d_state;
+    p.state = state;
     p.M = ctx->d_M;
     p.bg = ctx->d_bg;
     p.sat = ctx->d_sat;
@@ -342,7 +338,6 @@ int arvx_carve_views(arvx_ctx *ctx, int first, int count, unsigned flags) {
     p.Y = ctx->Y;
     p.Z = ctx->ze1 - ctx->ze0;  // owned planes plus halo (recomputed, never exchanged)
     p.zoff = ctx->ze0;
-    ctx->color_ready = false;
     p.s = ctx->s;
     p.W = ctx->W;
     p.H = ctx->H;
@@ -366,6 +361,17 @@ int arvx_carve_views(arvx_ctx *ctx, int first, int count, unsigned flags) {
                            ctx->stream, p);
     ARVX_HIP(hipGetLastError());
     return ARVX_OK;
+}
+
+int arvx_carve_views(arvx_ctx *ctx, int first, int count, unsigned flags) {
+    ARVX_CHECK_CTX(ctx);
+    if (!ctx->views_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
+    if (first < 0 || count < 0 || first + count > ctx->V)
+        return fail(ARVX_ERR_INVALID, "view range [%d,%d) outside [0,%d)", first, first + count,
+                    ctx->V);
+    if (count == 0) return ARVX_OK;
+    ctx->color_ready = false;
+    return launch_carve(ctx, ctx->d_state, first, count, flags);
 }
 
 int arvx_carve(arvx_ctx *ctx, unsigned flags) {
@@ -581,8 +587,76 @@ int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen) {
     return rc;
 }
 
-// ---- not yet built -------------------------------------------------------------
+// ---- greedy carve -------------------------------------------------------------------
 
-int arvx_fast_carve(arvx_ctx *) { return fail(ARVX_ERR_STATE, "arvx_fast_carve: not implemented yet"); }
+int arvx_fast_carve(arvx_ctx *ctx) {
+    ARVX_CHECK_CTX(ctx);
+    if (!ctx->views_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
+    if (ctx->z0 != 0 || ctx->z1 != ctx->Z)
+        return fail(ARVX_ERR_STATE,
+                    "arvx_fast_carve needs the whole grid in one context (connectivity is global)");
+    ctx->color_ready = false;
+    arvx::FloodParams fp;
+    fp.X = ctx->X;
+    fp.Y = ctx->Y;
+    fp.Z = ctx->Z;
+    fp.XW = (ctx->X + 63) / 64;
+    const size_t nwords = (size_t)fp.XW * fp.Y * fp.Z;
+    uint8_t *d_tmp = nullptr;
+    unsigned long long *d_bits = nullptr;
+    int *d_changed = nullptr;
+    int rc = ARVX_OK;
+    hipError_t e = hipMalloc(&d_tmp, ctx->nvox);
+    if (e == hipSuccess) e = hipMalloc(&d_bits, 2 * nwords * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&d_changed, sizeof(int));
+    if (e != hipSuccess) rc = arvx::fail_hip(e, "hipMalloc(fast carve)", __FILE__, __LINE__);
+    if (rc == ARVX_OK) {
+        fp.open = d_bits;
+        fp.reach = d_bits + nwords;
+        fp.changed = d_changed;
+        // carvable = what the dense carve clears on a fresh plane
+        e = hipMemsetAsync(d_tmp, 0x01, ctx->nvox, ctx->stream);
+        if (e != hipSuccess) rc = arvx::fail_hip(e, "hipMemsetAsync", __FILE__, __LINE__);
+    }
+    if (rc == ARVX_OK) rc = launch_carve(ctx, d_tmp, 0, ctx->V, 0);
+    if (rc == ARVX_OK) {
+        const unsigned gpack = (unsigned)((nwords + 3) / 4);
+        hipLaunchKernelGGL(arvx::flood_pack_open_kernel, dim3(gpack), dim3(256), 0, ctx->stream,
+                           d_tmp, ctx->d_state, fp);
+        const unsigned gflood =
+            (unsigned)((size_t)fp.XW * ((fp.Y + 15) / 16) * ((fp.Z + 15) / 16));
+        // every launch that is not the last grows at least one word; the flag is
+        // checked every 8 launches
+        const long max_batches = 16 + (long)gflood * 16;
+        for (long batch = 0; batch < max_batches && rc == ARVX_OK; ++batch) {
+            int changed = 0;
+            e = hipMemsetAsync(d_changed, 0, sizeof(int), ctx->stream);
+            for (int k = 0; k < 8 && e == hipSuccess; ++k) {
+                hipLaunchKernelGGL(arvx::flood_step_kernel, dim3(gflood), dim3(256), 0,
+                                   ctx->stream, fp);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(&changed, d_changed, sizeof(int), hipMemcpyDeviceToHost,
+                                   ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = arvx::fail_hip(e, "flood fill", __FILE__, __LINE__);
+            if (!changed) break;
+            if (batch + 1 == max_batches)
+                rc = fail(ARVX_ERR_HIP, "flood fill did not converge");
+        }
+    }
+    if (rc == ARVX_OK) {
+        hipLaunchKernelGGL(arvx::flood_apply_kernel, dim3((unsigned)((ctx->nvox + 255) / 256)),
+                           dim3(256), 0, ctx->stream, ctx->d_state, fp);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = arvx::fail_hip(e, "flood apply", __FILE__, __LINE__);
+    }
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (d_bits) (void)hipFree(d_bits);
+    if (d_changed) (void)hipFree(d_changed);
+    return rc;
+}
 
 }  // extern "C"

@@ -1,0 +1,203 @@
+// voxel_carving.hpp -- the reference's carving / colouring entry points over the
+// GPU library (header only, C++17, links libarvx.so).
+//
+//   carve(...)                    reference src/VoxelCarving.h:19,  .cpp:60-72
+//   fastCarve(...)                reference src/VoxelCarving.h:31,  .cpp:74-167
+//   reconstructClosestColor(...)  reference src/ColorReconstruction.h:131, .cpp:22-46
+//   reconstructAvgColor(...)      reference src/ColorReconstruction.h:142, .cpp:48-70
+//
+// Same names, argument order and effect on `model`.  The reference's signatures
+// take cv::Mat camera matrix / distortion / images / masks and do three things
+// per view before its voxel loop: ChArUco pose estimation, pose inversion and
+// cv::undistort (src/VoxelCarving.cpp:25-36).  Those are third-party OpenCV
+// calls and stay with the caller; a `View` carries their results.  With OpenCV
+// present, include/arvx/opencv_dropin.hpp adds overloads with the reference's
+// exact cv::Mat signatures that do that pre-processing and forward here.
+#ifndef ARVX_VOXEL_CARVING_HPP
+#define ARVX_VOXEL_CARVING_HPP
+
+#include <functional>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "arvx/arvx.h"
+#include "arvx/model.hpp"
+
+namespace arvx {
+
+struct Image {  // undistorted u8 image: what cv::undistort returned in the reference
+    const uint8_t *data = nullptr;
+    int width = 0, height = 0, channels = 0;
+    size_t stride = 0;  // bytes per row
+};
+
+struct View {
+    float pose[12];  // world->camera, top 3x4 of estimatePoseFromImage(...).inv()
+    Image image;     // BGR, used by the colour pass only
+    Image mask;      // background where all channel bytes are 0
+    // optional: the product intr * pose computed by the caller (e.g. by cv::gemm,
+    // to be bit-identical with the reference's OpenCV build); otherwise it is
+    // composed by arvx_compose_projection (fp32, unfused, left to right)
+    bool has_M = false;
+    float M[12] = {0};
+};
+
+struct Intrinsics {
+    float K[9];  // cameraMatrix converted to CV_32F (src/VoxelCarving.cpp:29-30)
+};
+
+class Error : public std::runtime_error {
+   public:
+    Error(int code, const std::string &what) : std::runtime_error(what), code(code) {}
+    int code;
+};
+
+// called after each view when intermediateMeshes is set (the reference writes
+// out/intermediate/image_<i>_mesh.off there, src/VoxelCarving.cpp:65-68)
+using IntermediateHook = std::function<void(int view, Model &model)>;
+
+namespace detail {
+
+inline void check(int rc, const char *what) {
+    if (rc != ARVX_OK) {
+        std::string msg = std::string(what) + ": " + arvx_last_error();
+        std::cerr << "LOG(ERR) - GPU: " << msg << std::endl;
+        throw Error(rc, msg);
+    }
+}
+
+// one context for the duration of a call: views + the model's state on the GPU
+class Session {
+   public:
+    Session(const Intrinsics &intr, Model &model, const std::vector<View> &views, int device = 0)
+        : model_(model) {
+        if (views.empty()) throw Error(ARVX_ERR_INVALID, "no views");
+        check(arvx_ctx_create(&ctx_, device, model.getX(), model.getY(), model.getZ(),
+                              model.getSize()),
+              "arvx_ctx_create");
+        const int V = (int)views.size();
+        std::vector<float> M((size_t)V * 12), cam((size_t)V * 3);
+        std::vector<const uint8_t *> masks(V);
+        for (int i = 0; i < V; ++i) {
+            if (views[i].has_M)
+                for (int k = 0; k < 12; ++k) M[12 * (size_t)i + k] = views[i].M[k];
+            else
+                check(arvx_compose_projection(intr.K, views[i].pose, &M[12 * (size_t)i]),
+                      "arvx_compose_projection");
+            // cameras[i] = (pose(0,3), pose(1,3), pose(2,3), 1), src/ColorReconstruction.h:21
+            cam[3 * (size_t)i] = views[i].pose[3];
+            cam[3 * (size_t)i + 1] = views[i].pose[7];
+            cam[3 * (size_t)i + 2] = views[i].pose[11];
+            masks[i] = views[i].mask.data;
+            if (views[i].mask.width != views[0].mask.width ||
+                views[i].mask.height != views[0].mask.height ||
+                views[i].mask.channels != views[0].mask.channels ||
+                views[i].mask.stride != views[0].mask.stride)
+                fail("all masks must share one size and layout");
+        }
+        const Image &m0 = views[0].mask;
+        check(arvx_set_views(ctx_, V, M.data(), cam.data(), masks.data(), m0.width, m0.height,
+                             m0.channels, m0.stride),
+              "arvx_set_views");
+        const std::vector<uint8_t> st = model.device_state();
+        check(arvx_state_upload(ctx_, st.data()), "arvx_state_upload");
+    }
+    ~Session() { arvx_ctx_destroy(ctx_); }
+    Session(const Session &) = delete;
+    Session &operator=(const Session &) = delete;
+
+    arvx_ctx *ctx() { return ctx_; }
+
+    void set_images(const std::vector<View> &views) {
+        std::vector<const uint8_t *> imgs(views.size());
+        for (size_t i = 0; i < views.size(); ++i) {
+            const Image &im = views[i].image;
+            if (!im.data || im.channels != 3 || im.width != views[0].mask.width ||
+                im.height != views[0].mask.height || im.stride != views[0].image.stride)
+                fail("colour images must be BGR u8 with the masks' size");
+            imgs[i] = im.data;
+        }
+        check(arvx_set_images(ctx_, imgs.data(), views[0].image.stride), "arvx_set_images");
+    }
+
+    void pull_state() {
+        std::vector<uint8_t> st(model_.voxels());
+        check(arvx_state_download(ctx_, st.data()), "arvx_state_download");
+        model_.absorb_state(st.data());
+    }
+
+    void color(int mode) {
+        check(arvx_color(ctx_, mode), "arvx_color");
+        int64_t n = 0;
+        check(arvx_surface_count(ctx_, &n), "arvx_surface_count");
+        std::vector<int64_t> idx((size_t)n);
+        std::vector<float> rgb((size_t)n * 3);
+        if (n) check(arvx_surface_download(ctx_, idx.data(), rgb.data()), "arvx_surface_download");
+        for (int64_t k = 0; k < n; ++k)  // model.set(x,y,z,(R,G,B,1)), ColorReconstruction.cpp:41/65
+            model_.set_flat((int)idx[k], Vec4f(rgb[3 * k], rgb[3 * k + 1], rgb[3 * k + 2], 1.f));
+    }
+
+   private:
+    [[noreturn]] static void fail(const char *msg) {
+        std::cerr << "LOG(ERR) - GPU: " << msg << std::endl;
+        throw Error(ARVX_ERR_INVALID, msg);
+    }
+    Model &model_;
+    arvx_ctx *ctx_ = nullptr;
+};
+
+}  // namespace detail
+
+// reference carve(): every view carves the model; `model` may already be carved.
+inline void carve(const Intrinsics &intr, Model &model, const std::vector<View> &views,
+                  bool intermediateMeshes = false, const IntermediateHook &hook = nullptr) {
+    std::cout << "LOG - VC: starting carving process (version 1)." << std::endl;
+    detail::Session s(intr, model, views);
+    if (!intermediateMeshes) {
+        detail::check(arvx_carve(s.ctx(), 0), "arvx_carve");
+        s.pull_state();
+    } else {
+        for (int i = 0; i < (int)views.size(); ++i) {  // one view at a time, :63-69
+            detail::check(arvx_carve_views(s.ctx(), i, 1, 0), "arvx_carve_views");
+            s.pull_state();
+            std::cout << "LOG - VC: completed carving of a single image." << std::endl;
+            if (hook) {
+                std::cout << "LOG - VC: generating intermediate mesh for image " << i << std::endl;
+                hook(i, model);
+            }
+        }
+    }
+    std::cout << "LOG - VC: carving complete." << std::endl;
+}
+
+// reference fastCarve(): greedy flood from voxel (0,0,0).
+inline void fastCarve(const Intrinsics &intr, Model &model, const std::vector<View> &views) {
+    std::cout << "LOG - VC: starting carving process (version 2)." << std::endl;
+    detail::Session s(intr, model, views);
+    detail::check(arvx_fast_carve(s.ctx()), "arvx_fast_carve");
+    s.pull_state();
+    std::cout << "LOG - VC: carving complete." << std::endl;
+}
+
+inline void reconstructClosestColor(const Intrinsics &intr, Model &model,
+                                    const std::vector<View> &views) {
+    std::cout << "LOG - CR: starting color reconstruction (closest color)." << std::endl;
+    detail::Session s(intr, model, views);
+    s.set_images(views);
+    s.color(ARVX_COLOR_CLOSEST);
+    std::cout << "LOG - CR: color reconstruction finished." << std::endl;
+}
+
+inline void reconstructAvgColor(const Intrinsics &intr, Model &model,
+                                const std::vector<View> &views) {
+    std::cout << "LOG - CR: starting color reconstruction (average color)." << std::endl;
+    detail::Session s(intr, model, views);
+    s.set_images(views);
+    s.color(ARVX_COLOR_AVERAGE);
+    std::cout << "LOG - CR: color reconstruction finished." << std::endl;
+}
+
+}  // namespace arvx
+#endif

@@ -1,0 +1,138 @@
+// test_host.cpp -- exercises the C++ host layer (include/arvx/model.hpp,
+// voxel_carving.hpp).  `test_host model` needs no GPU; `test_host carve <scene>
+// <out> <mode>` runs the reference-shaped entry points on a scene dumped by the
+// Python test and writes the resulting Model::voxels for comparison with the
+// oracle.
+#include <cassert>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <vector>
+
+#include "arvx/voxel_carving.hpp"
+
+using arvx::Model;
+using arvx::Vec3i;
+using arvx::Vec4f;
+
+#define EXPECT(c)                                                       \
+    do {                                                                \
+        if (!(c)) {                                                     \
+            std::fprintf(stderr, "FAIL %s:%d %s\n", __FILE__, __LINE__, #c); \
+            return 1;                                                   \
+        }                                                               \
+    } while (0)
+
+static int test_model() {
+    Model m(4, 3, 2, 0.5f);
+    EXPECT(m.getX() == 4 && m.getY() == 3 && m.getZ() == 2 && m.getSize() == 0.5f);
+    EXPECT(m.get(0, 0, 0) == Vec4f(50, 168, 141, 1));   // MODEL_COLOR
+    EXPECT(m.get(-1, 0, 0) == Vec4f(0, 0, 0, 0));        // outside -> zero
+    EXPECT(m.get(4, 0, 0) == Vec4f(0, 0, 0, 0));
+    EXPECT(!m.isInner(1, 1, 0));                         // z-1 is outside the grid
+    Model big(3, 3, 3, 1.f);
+    EXPECT(big.isInner(1, 1, 1));
+    big.set(1, 1, 2, Vec4f(0, 0, 0, 0));
+    EXPECT(!big.isInner(1, 1, 1));
+    EXPECT(big.get(1, 1, 2).w() == 0);
+    // toWord swaps x/y and negates z
+    Vec4f w = m.toWord(3, 2, 1);
+    EXPECT(w(0) == 1.0f && w(1) == 1.5f && w(2) == -0.5f && w(3) == 1.0f);
+    EXPECT(m.toWord(Vec3i(3, 2, 1)) == w);
+    // colours, lists, seen
+    m.set(1, 1, 1, Vec4f(10, 20, 30, 1));
+    EXPECT(m.get(1, 1, 1) == Vec4f(10, 20, 30, 1));
+    m.addColor(1, 1, 1, Vec4f(1, 2, 3, 1), 0.25f);
+    m.addColor(1, 1, 1, Vec4f(4, 5, 6, 1), 0.5f);
+    EXPECT(m.getColors(1, 1, 1).size() == 2 && m.getColors(1, 1, 1)[1].depth == 0.5f);
+    EXPECT(m.getColors(0, 0, 0).empty());
+    EXPECT(!m.visited(Vec3i(2, 2, 1)));
+    m.visit(Vec3i(2, 2, 1));
+    m.see(1, 1, 1);
+    EXPECT(m.visited(Vec3i(2, 2, 1)) && m.visited(Vec3i(1, 1, 1)));
+    m.set(0, 0, 0, Vec4f(0, 0, 0, 0));
+    m.handleUnseen();
+    EXPECT(m.get(0, 0, 0) == Vec4f(204, 0, 0, 1));      // unseen, even if carved
+    EXPECT(m.get(1, 1, 1) == Vec4f(10, 20, 30, 1));     // seen keeps its colour
+    EXPECT(m.get(2, 2, 1) == Vec4f(50, 168, 141, 1));
+    EXPECT(m.get(3, 2, 1) == Vec4f(204, 0, 0, 1));
+    std::string s = Model(1, 1, 1, 1.f).to_string();
+    EXPECT(s == "z = 0:\n(50, 168, 141, 1)\n\n");
+    std::puts("model ok");
+    return 0;
+}
+
+// scene file: int32 X,Y,Z,V,W,H,C ; float s ; float K[9] ; V*(float pose[12]) ;
+//             V*H*W*C mask bytes ; V*H*W*3 image bytes ; X*Y*Z initial state bytes
+static int run_carve(const char *scene, const char *out, const char *mode) {
+    std::ifstream f(scene, std::ios::binary);
+    int32_t hd[7];
+    f.read((char *)hd, sizeof hd);
+    const int X = hd[0], Y = hd[1], Z = hd[2], V = hd[3], W = hd[4], H = hd[5], C = hd[6];
+    float s;
+    f.read((char *)&s, 4);
+    arvx::Intrinsics intr;
+    f.read((char *)intr.K, 36);
+    std::vector<arvx::View> views(V);
+    for (auto &v : views) f.read((char *)v.pose, 48);
+    std::vector<uint8_t> masks((size_t)V * H * W * C), images((size_t)V * H * W * 3);
+    f.read((char *)masks.data(), masks.size());
+    f.read((char *)images.data(), images.size());
+    std::vector<uint8_t> st0((size_t)X * Y * Z);
+    f.read((char *)st0.data(), st0.size());
+    if (!f) { std::fprintf(stderr, "short scene file\n"); return 2; }
+    for (int i = 0; i < V; ++i) {
+        views[i].mask = {masks.data() + (size_t)i * H * W * C, W, H, C, (size_t)W * C};
+        views[i].image = {images.data() + (size_t)i * H * W * 3, W, H, 3, (size_t)W * 3};
+    }
+    Model model(X, Y, Z, s);
+    for (int z = 0; z < Z; ++z)
+        for (int y = 0; y < Y; ++y)
+            for (int x = 0; x < X; ++x) {
+                const uint8_t b = st0[(size_t)x + (size_t)X * (y + (size_t)Y * z)];
+                if (!(b & 1)) model.set(x, y, z, Vec4f(0, 0, 0, 0));
+                if (b & 2) model.see(x, y, z);
+            }
+    int hooks = 0;
+    try {
+        if (!std::strcmp(mode, "carve")) arvx::carve(intr, model, views);
+        else if (!std::strcmp(mode, "carve_steps"))
+            arvx::carve(intr, model, views, true, [&](int, Model &) { ++hooks; });
+        else if (!std::strcmp(mode, "fast")) arvx::fastCarve(intr, model, views);
+        else if (!std::strcmp(mode, "closest")) {
+            arvx::carve(intr, model, views);
+            arvx::reconstructClosestColor(intr, model, views);
+        } else if (!std::strcmp(mode, "average_unseen")) {
+            arvx::carve(intr, model, views);
+            arvx::reconstructAvgColor(intr, model, views);
+            model.handleUnseen();
+        } else { std::fprintf(stderr, "unknown mode %s\n", mode); return 2; }
+    } catch (const arvx::Error &e) {
+        std::fprintf(stderr, "arvx::Error %d: %s\n", e.code, e.what());
+        return 3;
+    }
+    if (!std::strcmp(mode, "carve_steps") && hooks != V) return 4;
+    std::ofstream o(out, std::ios::binary);
+    for (int z = 0; z < Z; ++z)
+        for (int y = 0; y < Y; ++y)
+            for (int x = 0; x < X; ++x) {
+                Vec4f v = model.get(x, y, z);
+                o.write((const char *)v.v, 16);
+            }
+    // then the seen bits, one byte each
+    for (int z = 0; z < Z; ++z)
+        for (int y = 0; y < Y; ++y)
+            for (int x = 0; x < X; ++x) {
+                char b = model.visited(Vec3i(x, y, z)) ? 1 : 0;
+                o.write(&b, 1);
+            }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc >= 2 && !std::strcmp(argv[1], "model")) return test_model();
+    if (argc == 5 && !std::strcmp(argv[1], "carve")) return run_carve(argv[2], argv[3], argv[4]);
+    std::fprintf(stderr, "usage: test_host model | test_host carve <scene> <out> <mode>\n");
+    return 2;
+}

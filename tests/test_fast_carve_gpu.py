@@ -1,0 +1,82 @@
+"""Greedy carve (reference fastCarve, src/VoxelCarving.cpp:74-167) on the GPU vs
+the oracle's literal queue-based restatement: state plane bit-exact."""
+import numpy as np
+import pytest
+
+from tests import golden_io, scenes
+from tests.test_carve_gpu import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_fast(arvx, X, Y, Z, s, M, masks, state=None):
+    with arvx.Context(X, Y, Z, s) as ctx:
+        ctx.set_views(M, masks)
+        if state is not None:
+            ctx.upload_state(state)
+        ctx.fast_carve()
+        return ctx.download_state()
+
+
+@pytest.mark.parametrize("dims,V", [((32, 32, 32), 6), ((100, 100, 50), 5), ((70, 9, 33), 4),
+                                    ((130, 20, 20), 4), ((1, 1, 1), 3), ((10, 10, 5), 5)])
+def test_fast_carve_sphere(arvx, oracle, dims, V):
+    X, Y, Z = dims
+    sc = scenes.small_sphere(32, V)
+    s = np.float32(0.512 / max(dims))
+    want = oracle.fast_carve(X, Y, Z, s, sc.M, sc.masks)
+    got = gpu_fast(arvx, X, Y, Z, s, sc.M, sc.masks)
+    assert_same(got, want, f"fast carve {dims}")
+
+
+@pytest.mark.parametrize("block,p_bg", [(1, 0.6), (4, 0.5), (8, 0.45), (16, 0.7)])
+def test_fast_carve_mazes(arvx, oracle, block, p_bg):
+    """Noise masks carve maze-like regions: long winding fronts across many tiles."""
+    N, V, W, H = 72, 3, 160, 120
+    s = np.float32(0.512 / N)
+    _, _, M = scenes.random_cameras(V, 0.512, seed=block, W=W, H=H)
+    masks = scenes.noise_masks(V, H, W, block=block, p_bg=p_bg, seed=block + 1)
+    want = oracle.fast_carve(N, N, N, s, M, masks)
+    got = gpu_fast(arvx, N, N, N, s, M, masks)
+    assert_same(got, want, f"maze block={block}")
+
+
+def test_fast_carve_respects_previsited_walls(arvx, oracle):
+    """Voxels already seen are 'visited' to the reference's BFS and block it."""
+    N, V = 40, 5
+    sc = scenes.small_sphere(N, V)
+    st0 = np.full((N, N, N), 1, np.uint8)
+    st0[:, :, 20] |= 2  # a seen wall across x = 20
+    st0[5, 5, 20] = 1   # with one hole
+    want = oracle.fast_carve(N, N, N, sc.voxel_size, sc.M, sc.masks, state=st0)
+    got = gpu_fast(arvx, N, N, N, sc.voxel_size, sc.M, sc.masks, state=st0)
+    assert_same(got, want, "walls")
+    st1 = st0.copy()
+    st1[0, 0, 0] |= 2  # origin already visited: the queue dies at once
+    want = oracle.fast_carve(N, N, N, sc.voxel_size, sc.M, sc.masks, state=st1)
+    assert np.array_equal(want, st1)
+    assert_same(gpu_fast(arvx, N, N, N, sc.voxel_size, sc.M, sc.masks, state=st1), want, "dead")
+
+
+def test_fast_carve_origin_not_carvable(arvx, oracle):
+    N, V, W, H = 24, 3, 96, 72
+    sc = scenes.small_sphere(N, V, W=W, H=H)
+    masks = np.full((V, H, W), 255, np.uint8)  # everything foreground: only the seed is visited
+    want = oracle.fast_carve(N, N, N, sc.voxel_size, sc.M, masks)
+    assert (want & 2).sum() // 2 == 1
+    assert_same(gpu_fast(arvx, N, N, N, sc.voxel_size, sc.M, masks), want, "seed only")
+
+
+@pytest.mark.parametrize("name", golden_io.names())
+def test_fast_carve_golden(arvx, name):
+    g = golden_io.load(name)
+    got = gpu_fast(arvx, g["X"], g["Y"], g["Z"], g["s"], g["M"], g["masks"])
+    assert np.array_equal(got, g["fast_state"])
+
+
+def test_fast_carve_rejects_slabs(arvx):
+    sc = scenes.small_sphere(16, 3)
+    with arvx.Context(16, 16, 16, sc.voxel_size, z_range=(0, 8)) as ctx:
+        ctx.set_views(sc.M, sc.masks)
+        with pytest.raises(arvx.ArvxError):
+            ctx.fast_carve()
