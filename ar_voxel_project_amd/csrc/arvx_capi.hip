@@ -116,8 +116,8 @@ int arvx_ctx_create_slab(arvx_ctx **out, int device, int X, int Y, int Z, float 
         arvx_ctx_destroy(c);
         return arvx::fail_hip(e, "hipMalloc(state)", __FILE__, __LINE__);
     }
-    e = hipMemsetAsync(c->d_state, 0x01, c->nvox_ext, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->d_stats, 0, 64, c->stream);
+    c->fresh_pending = true;  // a fresh Model: filled on first read, see materialize()
+    e = hipMemsetAsync(c->d_stats, 0, 64, c->stream);
     if (e != hipSuccess) {
         arvx_ctx_destroy(c);
         return arvx::fail_hip(e, "hipMemsetAsync", __FILE__, __LINE__);
@@ -139,6 +139,7 @@ int arvx_ctx_destroy(arvx_ctx *ctx) {
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_coarse) (void)hipFree(ctx->d_coarse);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return ARVX_OK;
@@ -199,11 +200,14 @@ static int views_common(Ctx *ctx, int V, const float *M, const float *campos, in
 static int views_preprocess(Ctx *ctx, const uint8_t *d_masks, int C) {
     const int npix = ctx->W * ctx->H;
     dim3 g1((npix + 255) / 256, ctx->V);
+    ARVX_HIP(hipGetLastError());  // anything stale would be blamed on the launches below
     hipLaunchKernelGGL(arvx::mask_to_bits_kernel, g1, dim3(256), 0, ctx->stream, d_masks, C, npix,
                        ctx->d_bg, ctx->bgWords);
+    ARVX_HIP(hipGetLastError());
     dim3 g2(ctx->H, ctx->V);
     hipLaunchKernelGGL(arvx::sat_rows_kernel, g2, dim3(64), 0, ctx->stream, ctx->d_bg,
                        ctx->bgWords, ctx->W, ctx->H, ctx->d_sat, ctx->satStride);
+    ARVX_HIP(hipGetLastError());
     dim3 g3((ctx->W + 1 + 255) / 256, ctx->V);
     hipLaunchKernelGGL(arvx::sat_cols_kernel, g3, dim3(256), 0, ctx->stream, ctx->W, ctx->H,
                        ctx->d_sat, ctx->satStride);
@@ -268,15 +272,18 @@ int arvx_set_views_device(arvx_ctx *ctx, int V, const float *M, const float *cam
 
 // ---- state -------------------------------------------------------------------
 
+static int materialize(Ctx *ctx);
+
 int arvx_state_reset(arvx_ctx *ctx) {
     ARVX_CHECK_CTX(ctx);
     ctx->color_ready = false;
-    ARVX_HIP(hipMemsetAsync(ctx->d_state, 0x01, ctx->nvox_ext, ctx->stream));
+    ctx->fresh_pending = true;  // see materialize()
     return ARVX_OK;
 }
 
 int arvx_state_upload(arvx_ctx *ctx, const uint8_t *state) {
     ARVX_CHECK_CTX(ctx);
+    if (int mrc = materialize(ctx)) return mrc;
     if (!state) return fail(ARVX_ERR_INVALID, "null state");
     ctx->color_ready = false;
     ARVX_HIP(hipMemcpyAsync(ctx->owned(), state, ctx->nvox, hipMemcpyHostToDevice, ctx->stream));
@@ -286,6 +293,7 @@ int arvx_state_upload(arvx_ctx *ctx, const uint8_t *state) {
 
 int arvx_state_upload_halo(arvx_ctx *ctx, const uint8_t *plane_below, const uint8_t *plane_above) {
     ARVX_CHECK_CTX(ctx);
+    if (int mrc = materialize(ctx)) return mrc;
     const size_t plane = (size_t)ctx->X * ctx->Y;
     ctx->color_ready = false;
     if (plane_below && ctx->ze0 < ctx->z0)
@@ -300,6 +308,7 @@ int arvx_state_upload_halo(arvx_ctx *ctx, const uint8_t *plane_below, const uint
 
 int arvx_state_download(arvx_ctx *ctx, uint8_t *state) {
     ARVX_CHECK_CTX(ctx);
+    if (int mrc = materialize(ctx)) return mrc;
     if (!state) return fail(ARVX_ERR_INVALID, "null state");
     ARVX_HIP(hipMemcpyAsync(state, ctx->owned(), ctx->nvox, hipMemcpyDeviceToHost, ctx->stream));
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
@@ -308,6 +317,8 @@ int arvx_state_download(arvx_ctx *ctx, uint8_t *state) {
 
 int arvx_state_device_ptr(arvx_ctx *ctx, void **ptr, size_t *bytes) {
     if (!ctx || !ptr) return fail(ARVX_ERR_INVALID, "null argument");
+    ARVX_HIP(hipSetDevice(ctx->device));
+    if (int mrc = materialize(ctx)) return mrc;
     *ptr = ctx->owned();
     if (bytes) *bytes = ctx->nvox;
     return ARVX_OK;
@@ -315,6 +326,7 @@ int arvx_state_device_ptr(arvx_ctx *ctx, void **ptr, size_t *bytes) {
 
 int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
     ARVX_CHECK_CTX(ctx);
+    if (int mrc = materialize(ctx)) return mrc;
     if (!dev_words) return fail(ARVX_ERR_INVALID, "null dev_words");
     const size_t nround = (ctx->nvox + 255) / 256;
     const unsigned grid = (unsigned)(nround < 8192 ? (nround ? nround : 1) : 8192);
@@ -327,7 +339,9 @@ int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
 // ---- carve -------------------------------------------------------------------
 
 // Launches the fused carve over planes [ze0, ze1) of `state` (owned + halo).
-static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned flags) {
+// `fresh`: the plane is known to be all-occupied/unseen, so it is not read.
+static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned flags,
+                        bool fresh) {
     arvx::CarveParams p;
     p.state = state;
     p.M = ctx->d_M;
@@ -345,13 +359,37 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
     p.satStride = ctx->satStride;
     p.v0 = first;
     p.v1 = first + count;
-    p.flags = flags;
+    p.flags = (flags & 3u) | (fresh ? 4u : 0u);
     p.tilesX = (p.X + arvx::kTileX - 1) / arvx::kTileX;
     p.tilesY = (p.Y + arvx::kTileY - 1) / arvx::kTileY;
     p.tilesZ = (p.Z + arvx::kTileZ - 1) / arvx::kTileZ;
+    p.coarseX = (p.X + arvx::kCoarseX - 1) / arvx::kCoarseX;
+    p.coarseY = (p.Y + arvx::kCoarseY - 1) / arvx::kCoarseY;
+    p.coarseZ = (p.Z + arvx::kCoarseZ - 1) / arvx::kCoarseZ;
+    p.nchunks = (count + 63) / 64;
+    p.coarseMixed = p.coarseFg = nullptr;
+    p.coarseCarved = nullptr;
+    if (flags & ARVX_CARVE_STATS) ARVX_HIP(hipMemsetAsync(ctx->d_stats, 0, 32, ctx->stream));
+    if (!(flags & ARVX_CARVE_NO_CULL)) {
+        const size_t ncoarse = (size_t)p.coarseX * p.coarseY * p.coarseZ;
+        const size_t words = ncoarse * p.nchunks;
+        const size_t need = 2 * words * sizeof(unsigned long long) + ncoarse + 64;
+        if (ctx->coarse_bytes < need) {
+            if (ctx->d_coarse) (void)hipFree(ctx->d_coarse);
+            ctx->d_coarse = nullptr;
+            ctx->coarse_bytes = 0;
+            ARVX_HIP(hipMalloc(&ctx->d_coarse, need));
+            ctx->coarse_bytes = need;
+        }
+        p.coarseMixed = (unsigned long long *)ctx->d_coarse;
+        p.coarseFg = p.coarseMixed + words;
+        p.coarseCarved = (uint8_t *)(p.coarseFg + words);
+        hipLaunchKernelGGL(arvx::carve_coarse_kernel, dim3((unsigned)((ncoarse + 3) / 4)),
+                           dim3(256), 0, ctx->stream, p);
+        ARVX_HIP(hipGetLastError());
+    }
     const size_t ntiles = (size_t)p.tilesX * p.tilesY * p.tilesZ;
     const unsigned grid = (unsigned)(((ntiles + 7) / 8) * 8);
-    if (flags & ARVX_CARVE_STATS) ARVX_HIP(hipMemsetAsync(ctx->d_stats, 0, 32, ctx->stream));
     const bool aligned = (p.X % 4 == 0) && (((uintptr_t)p.state & 3u) == 0);
     if (aligned)
         hipLaunchKernelGGL(arvx::carve_fused_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream,
@@ -363,6 +401,16 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
     return ARVX_OK;
 }
 
+// arvx_state_reset is lazy: the plane is filled only if somebody reads it before
+// a carve (which writes every voxel) has replaced it.
+static int materialize(Ctx *ctx) {
+    if (ctx->fresh_pending) {
+        ARVX_HIP(hipMemsetAsync(ctx->d_state, 0x01, ctx->nvox_ext, ctx->stream));
+        ctx->fresh_pending = false;
+    }
+    return ARVX_OK;
+}
+
 int arvx_carve_views(arvx_ctx *ctx, int first, int count, unsigned flags) {
     ARVX_CHECK_CTX(ctx);
     if (!ctx->views_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
@@ -371,7 +419,9 @@ int arvx_carve_views(arvx_ctx *ctx, int first, int count, unsigned flags) {
                     ctx->V);
     if (count == 0) return ARVX_OK;
     ctx->color_ready = false;
-    return launch_carve(ctx, ctx->d_state, first, count, flags);
+    const bool fresh = ctx->fresh_pending;
+    ctx->fresh_pending = false;  // the kernel writes every voxel of the plane
+    return launch_carve(ctx, ctx->d_state, first, count, flags, fresh);
 }
 
 int arvx_carve(arvx_ctx *ctx, unsigned flags) {
@@ -417,6 +467,7 @@ int arvx_set_images(arvx_ctx *ctx, const uint8_t *const *images, size_t stride) 
 
 int arvx_color(arvx_ctx *ctx, int mode) {
     ARVX_CHECK_CTX(ctx);
+    if (int mrc = materialize(ctx)) return mrc;
     if (!ctx->views_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
     if (!ctx->images_ready) return fail(ARVX_ERR_STATE, "arvx_set_images has not been called");
     if (!ctx->has_campos) return fail(ARVX_ERR_STATE, "arvx_set_views was given no campos");
@@ -444,8 +495,10 @@ int arvx_color(arvx_ctx *ctx, int mode) {
     int *d_cnt = (int *)(d_off + nblk + 1);
     hipLaunchKernelGGL(arvx::surface_count_kernel, dim3(nblk), dim3(256), 0, ctx->stream, sp,
                        d_cnt);
+    ARVX_HIP(hipGetLastError());
     hipLaunchKernelGGL(arvx::surface_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, d_cnt, nblk,
                        d_off);
+    ARVX_HIP(hipGetLastError());
     long long total = 0;
     ARVX_HIP(hipMemcpyAsync(&total, d_off + nblk, sizeof total, hipMemcpyDeviceToHost,
                             ctx->stream));
@@ -458,6 +511,7 @@ int arvx_color(arvx_ctx *ctx, int mode) {
         ARVX_HIP(hipMalloc(&ctx->d_surf_has, (size_t)total));
         hipLaunchKernelGGL(arvx::surface_write_kernel, dim3(nblk), dim3(256), 0, ctx->stream, sp,
                            d_off, ctx->d_surf_index);
+        ARVX_HIP(hipGetLastError());
         arvx::VoteParams vp;
         vp.index = ctx->d_surf_index;
         vp.n = total;
@@ -550,6 +604,7 @@ int arvx_surface_depth_download(arvx_ctx *ctx, float *depth) {
 // Model::voxels of the owned voxels, built on the device in chunks and copied out.
 int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen) {
     ARVX_CHECK_CTX(ctx);
+    if (int mrc = materialize(ctx)) return mrc;
     if (!rgba) return fail(ARVX_ERR_INVALID, "null rgba");
     const size_t chunk = (size_t)1 << 24;  // voxels per chunk: 256 MiB of float4
     const size_t nchunk = std::min(chunk, ctx->nvox);
@@ -591,6 +646,7 @@ int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen) {
 
 int arvx_fast_carve(arvx_ctx *ctx) {
     ARVX_CHECK_CTX(ctx);
+    if (int mrc = materialize(ctx)) return mrc;
     if (!ctx->views_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
     if (ctx->z0 != 0 || ctx->z1 != ctx->Z)
         return fail(ARVX_ERR_STATE,
@@ -614,11 +670,9 @@ int arvx_fast_carve(arvx_ctx *ctx) {
         fp.open = d_bits;
         fp.reach = d_bits + nwords;
         fp.changed = d_changed;
-        // carvable = what the dense carve clears on a fresh plane
-        e = hipMemsetAsync(d_tmp, 0x01, ctx->nvox, ctx->stream);
-        if (e != hipSuccess) rc = arvx::fail_hip(e, "hipMemsetAsync", __FILE__, __LINE__);
+        // carvable = what the dense carve clears on a fresh plane (not read: `fresh`)
     }
-    if (rc == ARVX_OK) rc = launch_carve(ctx, d_tmp, 0, ctx->V, 0);
+    if (rc == ARVX_OK) rc = launch_carve(ctx, d_tmp, 0, ctx->V, 0, true);
     if (rc == ARVX_OK) {
         const unsigned gpack = (unsigned)((nwords + 3) / 4);
         hipLaunchKernelGGL(arvx::flood_pack_open_kernel, dim3(gpack), dim3(256), 0, ctx->stream,

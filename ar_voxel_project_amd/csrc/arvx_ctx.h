@@ -32,6 +32,9 @@ struct Ctx {
 
     uint8_t *d_state = nullptr;  // planes ze0..ze1-1
     uint8_t *owned() const { return d_state + (size_t)(z0 - ze0) * X * Y; }
+    bool fresh_pending = false;  // arvx_state_reset is lazy (arvx_capi.hip: materialize)
+    void *d_coarse = nullptr;    // coarse pre-pass masks of the carve kernel
+    size_t coarse_bytes = 0;
     unsigned long long *d_stats = nullptr;
     void *d_scratch = nullptr;
     size_t scratch_bytes = 0;

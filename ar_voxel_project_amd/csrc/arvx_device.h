@@ -17,6 +17,7 @@ namespace arvx {
 
 constexpr int kTileX = 64, kTileY = 8, kTileZ = 8;  // voxels per workgroup
 constexpr int kSubX = 16;                           // x extent of one wave's sub-tile
+constexpr int kCoarseX = 64, kCoarseY = 32, kCoarseZ = 32;  // pre-pass tile (64 sub-tiles)
 constexpr uint32_t kDone4 = 0x02020202u;            // 4 voxels carved+seen
 constexpr int kMaxImageDim = 16384;
 
@@ -34,8 +35,13 @@ struct CarveParams {
     int W, H;
     int bgWords, satStride;
     int v0, v1;             // view range [v0, v1)
-    unsigned flags;
+    unsigned flags;         // bit0 no cull, bit1 stats, bit2 state is fresh (skip the load)
     int tilesX, tilesY, tilesZ;
+    // coarse pre-pass results
+    int coarseX, coarseY, coarseZ, nchunks;
+    unsigned long long *coarseMixed;  // [ncoarse][nchunks] views to re-classify per sub-tile
+    unsigned long long *coarseFg;     // [ncoarse][nchunks] views that see only foreground
+    uint8_t *coarseCarved;            // [ncoarse] some view carves the whole coarse tile
 };
 
 // Rounded pixel of one projected voxel.  a0,a1,a2 are the fp32 row results.

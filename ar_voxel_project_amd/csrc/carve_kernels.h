@@ -13,9 +13,10 @@
 // so the four waves of a workgroup together touch whole 64-byte runs.
 //
 // Per sub-tile, before any voxel is projected, lane i classifies view i: the
-// eight corners of the sub-tile's world box are projected in fp64, a rigorous
-// error margin is added, and the resulting pixel rectangle is looked up in
-// the view's summed-area table of foreground pixels:
+// eight corners of the sub-tile's world box are projected, a rigorous error
+// margin is added, and the resulting pixel rectangle is looked up in the view's
+// summed-area table of foreground pixels (a pre-pass does the same for coarse
+// 64x32x32 tiles first, so most sub-tiles inherit their answer):
 //   rectangle outside the image            -> no voxel is seen by this view
 //   inside, no foreground pixel            -> every voxel is carved: sub-tile done
 //   inside, only foreground pixels         -> every voxel is seen, none carved
@@ -30,65 +31,88 @@
 
 namespace arvx {
 
-// Conservative classification of the voxel box [x0,x1]x[y0,y1]x[z0,z1]
-// (inclusive, z global) against one view.  Rigour: every voxel's w = fl32(i*s)
-// lies between the corner values (rounding is monotone), the row values a_r are
-// affine in w, and u = a_0/a_2 is linear-fractional, so over a box on which
-// a_2 keeps its sign the extremes of u,v sit at the eight corners.  The
-// computed a_r differ from the real ones by <= 2^-24*E_r (+fp64 dust), E_r the
-// sum of |terms|; 2^-22*E_r is used.  The fp32 divide adds 2^-24*|u|; the
-// corner quotients are taken in fp32 (3 ulp); 2^-20*|u| + 2^-12 covers both.
-__device__ inline int classify_box(const float *__restrict__ M, float s, int x0, int x1,
-                                   int y0, int y1, int z0, int z1, int W, int H,
+// World-space box of a block of voxels: the fl32 products Model::toWord forms at
+// its two faces per axis (x/y swapped, z negated; reference src/Model.h:134-140).
+struct BoxW {
+    float wy0, wy1, wx0, wx1, wz0, wz1;
+};
+
+__device__ __forceinline__ BoxW make_box(float s, int x0, int x1, int y0, int y1, int z0, int z1) {
+    BoxW b;
+    b.wy0 = (float)y0 * s;
+    b.wy1 = (float)y1 * s;
+    b.wx0 = (float)x0 * s;
+    b.wx1 = (float)x1 * s;
+    b.wz0 = (float)(-z0) * s;
+    b.wz1 = (float)(-z1) * s;
+    return b;
+}
+
+// Conservative classification of a voxel box against one view, all in fp32.
+//
+// Rigour.  Every voxel's w = fl32(i*s) lies between the corner values (rounding
+// is monotone); the rows a_r are affine in w and u = a_0/a_2, v = a_1/a_2 are
+// linear-fractional, so over a box on which a_2 keeps its sign the real-valued
+// extremes of u,v sit at the eight corners.  Error budget per row, in units of
+// E_r = sum_k |M[r][k]|*max|w_k| and u = 2^-24:
+//   * the value the exact path computes (fp64 sum rounded to fp32) differs from
+//     the real a_r by <= 1u*E_r (+ fp64 dust);
+//   * a corner evaluated here as base + deltas (3 fma, <= 3 mul of a rounded
+//     difference, <= 3 add) differs from the real corner value by < 16u*E_r;
+//   total < 17u*E_r; eps_r = 2^-19*E_r = 32u*E_r is used.
+// The quotient: |u_computed - u_real| <= (eps_0 + |u| eps_2)/(|a_2| - eps_2)
+// plus the roundings of the exact path's divide (1u|u|), of rcp+mul here (<3u|u|)
+// and of the bound arithmetic below (<2u|u|): 2^-20|u| = 16u|u| and an absolute
+// 2^-12 cover them.  roundf(t) lies in [t-0.5, t+0.5].
+__device__ inline int classify_box(const float *__restrict__ M, const BoxW b, int W, int H,
                                    const int *__restrict__ sat) {
-    const double wy[2] = {(double)((float)y0 * s), (double)((float)y1 * s)};
-    const double wx[2] = {(double)((float)x0 * s), (double)((float)x1 * s)};
-    const double wz[2] = {(double)((float)(-z0) * s), (double)((float)(-z1) * s)};
-    const double ay = fmax(fabs(wy[0]), fabs(wy[1]));
-    const double ax = fmax(fabs(wx[0]), fabs(wx[1]));
-    const double az = fmax(fabs(wz[0]), fabs(wz[1]));
-    double m[12];
+    const float dy = b.wy1 - b.wy0, dx = b.wx1 - b.wx0, dz = b.wz1 - b.wz0;
+    const float ay = fmaxf(fabsf(b.wy0), fabsf(b.wy1));
+    const float ax = fmaxf(fabsf(b.wx0), fabsf(b.wx1));
+    const float az = fmaxf(fabsf(b.wz0), fabsf(b.wz1));
+    float a[3][8], E[3];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) m[i] = (double)M[i];
-    double E[3];
+    for (int r = 0; r < 3; ++r) {
+        const float m0 = M[4 * r], m1 = M[4 * r + 1], m2 = M[4 * r + 2], m3 = M[4 * r + 3];
+        E[r] = fabsf(m0) * ay + fabsf(m1) * ax + fabsf(m2) * az + fabsf(m3);
+        const float base = fmaf(m0, b.wy0, fmaf(m1, b.wx0, fmaf(m2, b.wz0, m3)));
+        const float ey = m0 * dy, ex = m1 * dx, ez = m2 * dz;
+        a[r][0] = base;
+        a[r][1] = base + ey;
+        a[r][2] = base + ex;
+        a[r][3] = a[r][1] + ex;
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-        E[r] = fabs(m[4 * r]) * ay + fabs(m[4 * r + 1]) * ax + fabs(m[4 * r + 2]) * az +
-               fabs(m[4 * r + 3]);
+        for (int c = 0; c < 4; ++c) a[r][4 + c] = a[r][c] + ez;
+    }
     float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
-    double cmin = INFINITY, cmax = -INFINITY;
+    float cmin = INFINITY, cmax = -INFINITY;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const double y = wy[c & 1], x = wx[(c >> 1) & 1], z = wz[c >> 2];
-        const double a0 = fma(m[0], y, fma(m[1], x, fma(m[2], z, m[3])));
-        const double a1 = fma(m[4], y, fma(m[5], x, fma(m[6], z, m[7])));
-        const double a2 = fma(m[8], y, fma(m[9], x, fma(m[10], z, m[11])));
-        cmin = fmin(cmin, a2);
-        cmax = fmax(cmax, a2);
-        const float fu = (float)a0 / (float)a2;
-        const float fv = (float)a1 / (float)a2;
+        cmin = fminf(cmin, a[2][c]);
+        cmax = fmaxf(cmax, a[2][c]);
+        const float rc = __builtin_amdgcn_rcpf(a[2][c]);
+        const float fu = a[0][c] * rc, fv = a[1][c] * rc;
         umin = fminf(umin, fu);
         umax = fmaxf(umax, fu);
         vmin = fminf(vmin, fv);
         vmax = fmaxf(vmax, fv);
     }
-    const double k22 = 2.384185791015625e-07;  // 2^-22
-    const double k20 = 9.5367431640625e-07;    // 2^-20
-    const double k12 = 2.44140625e-04;         // 2^-12
-    const double eps2 = E[2] * k22;
-    const double cabs = (cmin > 0.0) ? cmin : ((cmax < 0.0) ? -cmax : 0.0);
-    if (!(cabs > 8.0 * eps2 + 1e-30)) return kClsMixed;  // denominator may vanish
-    const double cden = cabs - eps2;
-    const double Ua = fmax(fabs((double)umin), fabs((double)umax));
-    const double Va = fmax(fabs((double)vmin), fabs((double)vmax));
-    if (!(Ua < 1.0e6 && Va < 1.0e6)) return kClsMixed;  // also NaN
-    const double mu = (E[0] * k22 + Ua * eps2) / cden + Ua * k20 + k12;
-    const double mv = (E[1] * k22 + Va * eps2) / cden + Va * k20 + k12;
-    // roundf(t) lies in [t-0.5, t+0.5]
-    const int pxlo = (int)ceil((double)umin - mu - 0.5);
-    const int pxhi = (int)floor((double)umax + mu + 0.5);
-    const int pylo = (int)ceil((double)vmin - mv - 0.5);
-    const int pyhi = (int)floor((double)vmax + mv + 0.5);
+    const float k19 = 1.9073486328125e-06f;  // 2^-19
+    const float k20 = 9.5367431640625e-07f;  // 2^-20
+    const float k12 = 2.44140625e-04f;       // 2^-12
+    const float eps0 = E[0] * k19, eps1 = E[1] * k19, eps2 = E[2] * k19;
+    const float cabs = (cmin > 0.f) ? cmin : ((cmax < 0.f) ? -cmax : 0.f);
+    if (!(cabs > 8.f * eps2 + 1e-30f)) return kClsMixed;  // the denominator may vanish
+    const float Ua = fmaxf(fabsf(umin), fabsf(umax));
+    const float Va = fmaxf(fabsf(vmin), fabsf(vmax));
+    if (!(Ua < 1.0e6f && Va < 1.0e6f)) return kClsMixed;  // also NaN
+    const float rden = 1.0001f / (cabs - eps2);
+    const float mu = (eps0 + Ua * eps2) * rden + Ua * k20 + k12;
+    const float mv = (eps1 + Va * eps2) * rden + Va * k20 + k12;
+    const int pxlo = (int)ceilf(umin - mu - 0.5f);
+    const int pxhi = (int)floorf(umax + mu + 0.5f);
+    const int pylo = (int)ceilf(vmin - mv - 0.5f);
+    const int pyhi = (int)floorf(vmax + mv + 0.5f);
     if (pxhi < 0 || pxlo >= W || pyhi < 0 || pylo >= H) return kClsOut;
     if (pxlo < 0 || pxhi >= W || pylo < 0 || pyhi >= H) return kClsMixed;
     const int S = W + 1;
@@ -97,6 +121,42 @@ __device__ inline int classify_box(const float *__restrict__ M, float s, int x0,
     if (cnt == 0) return kClsCarved;
     const int area = (pxhi - pxlo + 1) * (pyhi - pylo + 1);
     return (cnt == area) ? kClsFg : kClsMixed;
+}
+
+// Pre-pass over coarse tiles of 64 x 32 x 32 voxels (64 sub-tiles each): one wave
+// per coarse tile, lane i = view i.  A view that sees the whole coarse box as
+// background decides all 64 sub-tiles at once; views that are "outside" or "all
+// foreground" for the coarse box are that for every sub-tile too, so the main
+// kernel re-classifies only the views left in the coarse "mixed" mask.
+__global__ __launch_bounds__(256) void carve_coarse_kernel(const CarveParams p) {
+    const int ct = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int ncoarse = p.coarseX * p.coarseY * p.coarseZ;
+    if (ct >= ncoarse) return;
+    const int cx = ct % p.coarseX;
+    const int cy = (ct / p.coarseX) % p.coarseY;
+    const int cz = ct / (p.coarseX * p.coarseY);
+    const int x0 = cx * kCoarseX, y0 = cy * kCoarseY, z0 = cz * kCoarseZ;
+    const BoxW box = make_box(p.s, x0, min(x0 + kCoarseX - 1, p.X - 1), y0,
+                              min(y0 + kCoarseY - 1, p.Y - 1), p.zoff + z0,
+                              p.zoff + min(z0 + kCoarseZ - 1, p.Z - 1));
+    bool any_carved = false;
+    int chunk = 0;
+    for (int vc = p.v0; vc < p.v1; vc += 64, ++chunk) {
+        const int myv = vc + lane;
+        int cls = kClsOut;
+        if (myv < p.v1)
+            cls = classify_box(p.M + 12 * myv, box, p.W, p.H, p.sat + (size_t)myv * p.satStride);
+        const unsigned long long carved = __ballot(cls == kClsCarved);
+        const unsigned long long mixed = __ballot(cls == kClsMixed);
+        const unsigned long long fg = __ballot(cls == kClsFg);
+        any_carved = any_carved || carved;
+        if (lane == 0) {
+            p.coarseMixed[(size_t)ct * p.nchunks + chunk] = mixed;
+            p.coarseFg[(size_t)ct * p.nchunks + chunk] = fg;
+        }
+    }
+    if (lane == 0) p.coarseCarved[ct] = any_carved ? 1 : 0;
 }
 
 template <bool kAligned4>
@@ -138,16 +198,33 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(const CarveParams p) {
     bool loaded = false, all_carved = false, all_done = false;
     const size_t row = (size_t)p.X;
     const size_t plane = (size_t)p.X * p.Y;
+    const bool cull = !(p.flags & 1u);
+    const int ct = cull ? tx + p.coarseX * ((ty >> 2) + p.coarseY * (tz >> 2)) : 0;
+    if (cull && p.coarseCarved[ct]) {  // wave-uniform (scalar load)
+        all_carved = true;
+        if ((p.flags & 2u) && lane == 0) {
+            atomicAdd(&p.stats[0], 1ull);
+            atomicAdd(&p.stats[1], 1ull);
+        }
+    }
+    const BoxW box = make_box(p.s, sx0, sx1, sy0, sy1, p.zoff + sz0, p.zoff + sz1);
 
-    for (int vc = p.v0; vc < p.v1 && !all_done; vc += 64) {
+    int chunk = 0;
+    for (int vc = p.v0; vc < p.v1 && !all_done && !all_carved; vc += 64, ++chunk) {
         const int myv = vc + lane;
         int cls = kClsOut;
         if (myv < p.v1) {
-            cls = (p.flags & 1u)
-                      ? kClsMixed
-                      : classify_box(p.M + 12 * myv, p.s, sx0, sx1, sy0, sy1, p.zoff + sz0,
-                                     p.zoff + sz1, p.W, p.H,
-                                     p.sat + (size_t)myv * p.satStride);
+            if (!cull) {
+                cls = kClsMixed;
+            } else {
+                const unsigned long long cm = p.coarseMixed[(size_t)ct * p.nchunks + chunk];
+                const unsigned long long cf = p.coarseFg[(size_t)ct * p.nchunks + chunk];
+                if ((cf >> lane) & 1ull)
+                    cls = kClsFg;  // inherited: the coarse rectangle contains this one
+                else if ((cm >> lane) & 1ull)
+                    cls = classify_box(p.M + 12 * myv, box, p.W, p.H,
+                                       p.sat + (size_t)myv * p.satStride);
+            }
         }
         const unsigned long long carved = __ballot(cls == kClsCarved);
         unsigned long long mixed = __ballot(cls == kClsMixed);
@@ -171,7 +248,13 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(const CarveParams p) {
                 const int z = zb + k;
                 if (lane_ok && z < p.Z) {
                     const uint8_t *src = p.state + (size_t)z * plane + (size_t)y * row + x;
-                    if (kAligned4) {
+                    if (p.flags & 4u) {  // fresh model: all occupied, none seen; no load
+                        uint32_t w = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            w |= (uint32_t)((x + j < p.X) ? 1u : 2u) << (8 * j);
+                        st[k] = w;
+                    } else if (kAligned4) {
                         st[k] = *reinterpret_cast<const uint32_t *>(src);
                     } else {
                         uint32_t w = 0;

@@ -166,3 +166,51 @@ def test_pack_occupancy_layout(arvx, oracle):
         ref = np.packbits(occ, bitorder="little").view(np.int32)
         assert np.array_equal(got[:len(ref)], ref)
         assert np.all(got[len(ref):] == -1), "wrote past the slab's words"
+
+
+@pytest.mark.parametrize("seed,block,inside", [(1, 8, False), (2, 32, True), (3, 64, False),
+                                               (4, 16, True), (5, 128, True)])
+def test_cull_matches_no_cull_block_noise(arvx, seed, block, inside):
+    """Blocky random masks give large all-background / all-foreground rectangles next
+    to edges everywhere: the rectangle classification (coarse pre-pass, inheritance,
+    fp32 margins) is exercised on every outcome, with cameras inside and outside the
+    grid.  The brute-force kernel (NO_CULL) is the reference; it is itself checked
+    against the oracle at small sizes."""
+    N, V, W, H = 192, 9, 640, 480
+    s = np.float32(0.512 / N)
+    _, _, M = scenes.random_cameras(V, 0.512, seed=seed, W=W, H=H, inside=inside)
+    masks = scenes.noise_masks(V, H, W, block=block, p_bg=0.55, seed=seed + 100)
+    a = run_gpu(arvx, N, N, N, s, M, masks, 0)
+    b = run_gpu(arvx, N, N, N, s, M, masks, 1)
+    assert_same(a, b, f"cull vs no-cull, block noise seed={seed}")
+    # slabs and view sub-ranges go through the same coarse tables
+    c = np.concatenate([run_gpu(arvx, N, N, N, s, M, masks, 0, z_range=r)
+                        for r in [(0, 70), (70, 71), (71, 192)]], axis=0)
+    assert_same(c, b, "slabs")
+    with arvx.Context(N, N, N, s) as ctx:
+        ctx.set_views(M, masks)
+        ctx.carve_views(0, 4)
+        ctx.carve_views(4, 5)
+        assert_same(ctx.download_state(), b, "two view ranges")
+
+
+def test_lazy_reset_and_reuse(arvx, oracle):
+    """reset() is lazy (the carve writes every voxel); every reader must still see a
+    fresh plane, and a context can be carved, reset and carved again."""
+    N, V = 32, 5
+    sc = scenes.small_sphere(N, V)
+    want = oracle.carve(N, N, N, sc.voxel_size, sc.M, sc.masks)
+    with arvx.Context(N, N, N, sc.voxel_size) as ctx:
+        assert np.all(ctx.download_state() == 1)  # fresh at creation
+        ctx.set_views(sc.M, sc.masks)
+        ctx.carve()
+        assert_same(ctx.download_state(), want, "first carve")
+        ctx.reset()
+        assert np.all(ctx.download_state() == 1)
+        ctx.reset()
+        ctx.carve(arvx.CARVE_NO_CULL)
+        assert_same(ctx.download_state(), want, "after reset, no-cull")
+        ctx.reset()
+        ctx.carve_views(0, 2)
+        ctx.carve_views(2, 3)
+        assert_same(ctx.download_state(), want, "after reset, two ranges")
