@@ -66,6 +66,13 @@ def load_library() -> C.CDLL:
         raise FileNotFoundError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or make -C ar_voxel_project_amd/csrc); there is no CPU fallback")
+    # torch (device memory / streams / torch.distributed in bench and tests) ships its
+    # own HIP runtime; it must be loaded BEFORE libarvx.so pulls in /opt/rocm's, or a
+    # later `import torch` finds "No HIP GPUs".  libarvx itself does not use torch.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     p = C.c_void_p
     f32p = C.POINTER(C.c_float)

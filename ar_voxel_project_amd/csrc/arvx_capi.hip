@@ -388,8 +388,9 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
                            dim3(256), 0, ctx->stream, p);
         ARVX_HIP(hipGetLastError());
     }
-    const size_t ntiles = (size_t)p.tilesX * p.tilesY * p.tilesZ;
-    const unsigned grid = (unsigned)(((ntiles + 7) / 8) * 8);
+    // rows of tiles (along x) are dealt to the XCDs cyclically: see the kernel
+    const size_t rows8 = ((size_t)p.tilesY * p.tilesZ + 7) / 8 * 8;
+    const unsigned grid = (unsigned)(rows8 * p.tilesX);
     const bool aligned = (p.X % 4 == 0) && (((uintptr_t)p.state & 3u) == 0);
     if (aligned)
         hipLaunchKernelGGL(arvx::carve_fused_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream,
