@@ -25,12 +25,12 @@ COLOR_AVERAGE = 1
 # every symbol include/arvx/arvx.h declares
 SYMBOLS = [
     "arvx_version", "arvx_last_error", "arvx_device_count",
-    "arvx_ctx_create", "arvx_ctx_create_slab", "arvx_ctx_destroy",
+    "arvx_ctx_create", "arvx_ctx_create_slab", "arvx_ctx_create_striped", "arvx_ctx_destroy",
     "arvx_ctx_set_stream", "arvx_ctx_synchronize", "arvx_ctx_voxels",
     "arvx_compose_projection", "arvx_set_views", "arvx_set_views_device",
     "arvx_set_images", "arvx_state_reset", "arvx_state_upload",
     "arvx_state_download", "arvx_state_device_ptr", "arvx_state_upload_halo",
-    "arvx_pack_occupancy", "arvx_carve", "arvx_carve_views", "arvx_fast_carve",
+    "arvx_pack_occupancy", "arvx_pack_occupancy_global", "arvx_carve", "arvx_carve_views", "arvx_fast_carve",
     "arvx_color", "arvx_surface_count", "arvx_surface_download",
     "arvx_surface_depth_download",
     "arvx_export_model", "arvx_get_stats",
@@ -83,6 +83,8 @@ def load_library() -> C.CDLL:
     lib.arvx_ctx_create.argtypes = [C.POINTER(p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
     lib.arvx_ctx_create_slab.argtypes = [C.POINTER(p), C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_float, C.c_int, C.c_int]
+    lib.arvx_ctx_create_striped.argtypes = [C.POINTER(p), C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_float, C.c_int, C.c_int]
     lib.arvx_ctx_destroy.argtypes = [p]
     lib.arvx_ctx_set_stream.argtypes = [p, p]
     lib.arvx_ctx_synchronize.argtypes = [p]
@@ -98,6 +100,7 @@ def load_library() -> C.CDLL:
     lib.arvx_state_device_ptr.argtypes = [p, C.POINTER(p), C.POINTER(C.c_size_t)]
     lib.arvx_state_upload_halo.argtypes = [p, u8p, u8p]
     lib.arvx_pack_occupancy.argtypes = [p, p]
+    lib.arvx_pack_occupancy_global.argtypes = [p, p]
     lib.arvx_carve.argtypes = [p, C.c_uint]
     lib.arvx_carve_views.argtypes = [p, C.c_int, C.c_int, C.c_uint]
     lib.arvx_fast_carve.argtypes = [p]
@@ -137,21 +140,39 @@ def compose_projection(K, Rt) -> np.ndarray:
     return M.reshape(3, 4)
 
 
+def stripe_planes(Z: int, world: int, rank: int) -> np.ndarray:
+    """Global z of the planes a striped context holds, in local order."""
+    groups = np.arange(rank, Z // 8, world)
+    return (groups[:, None] * 8 + np.arange(8)[None, :]).reshape(-1)
+
+
 class Context:
     """One voxel grid (or Z slab) on one GPU: thin wrapper of arvx_ctx."""
 
     def __init__(self, X: int, Y: int, Z: int, voxel_size: float, device: int = 0,
-                 z_range: Optional[Sequence[int]] = None):
+                 z_range: Optional[Sequence[int]] = None,
+                 stripes: Optional[Sequence[int]] = None):
+        """z_range=(z0,z1): contiguous slab.  stripes=(world, rank): 8-plane groups
+        rank, rank+world, ... (load-balanced multi-GPU split)."""
         self._lib = load_library()
         self._h = C.c_void_p()
         self.X, self.Y, self.Z = int(X), int(Y), int(Z)
         self.voxel_size = float(np.float32(voxel_size))
-        z0, z1 = (0, Z) if z_range is None else (int(z_range[0]), int(z_range[1]))
-        self.z_range = (z0, z1)
-        _check(self._lib.arvx_ctx_create_slab(C.byref(self._h), device, X, Y, Z,
-                                              C.c_float(voxel_size), z0, z1))
-        self.shape = (z1 - z0, Y, X)  # numpy view of the state plane: [z][y][x]
-        self.nvox = (z1 - z0) * Y * X
+        if stripes is not None:
+            world, rank = int(stripes[0]), int(stripes[1])
+            _check(self._lib.arvx_ctx_create_striped(C.byref(self._h), device, X, Y, Z,
+                                                     C.c_float(voxel_size), world, rank))
+            self.planes = stripe_planes(Z, world, rank)
+            self.z_range = None
+        else:
+            z0, z1 = (0, Z) if z_range is None else (int(z_range[0]), int(z_range[1]))
+            self.z_range = (z0, z1)
+            _check(self._lib.arvx_ctx_create_slab(C.byref(self._h), device, X, Y, Z,
+                                                  C.c_float(voxel_size), z0, z1))
+            self.planes = np.arange(z0, z1)
+        nz = len(self.planes)  # global z of every local plane
+        self.shape = (nz, Y, X)  # numpy view of the state plane: [z][y][x]
+        self.nvox = nz * Y * X
         self._keep = []
 
     def close(self) -> None:
@@ -241,6 +262,9 @@ class Context:
 
     def pack_occupancy(self, dev_words_ptr: int) -> None:
         _check(self._lib.arvx_pack_occupancy(self._h, C.c_void_p(dev_words_ptr)))
+
+    def pack_occupancy_global(self, dev_global_words_ptr: int) -> None:
+        _check(self._lib.arvx_pack_occupancy_global(self._h, C.c_void_p(dev_global_words_ptr)))
 
     def set_stream(self, stream_ptr: int) -> None:
         _check(self._lib.arvx_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))

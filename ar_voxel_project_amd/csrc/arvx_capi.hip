@@ -126,6 +126,28 @@ int arvx_ctx_create_slab(arvx_ctx **out, int device, int X, int Y, int Z, float 
     return ARVX_OK;
 }
 
+int arvx_ctx_create_striped(arvx_ctx **out, int device, int X, int Y, int Z, float voxel_size,
+                            int world, int rank) {
+    if (!out) return fail(ARVX_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world)
+        return fail(ARVX_ERR_INVALID, "rank %d of world %d", rank, world);
+    if (Z < 1 || Z % 8) return fail(ARVX_ERR_INVALID, "striped slabs need Z %% 8 == 0 (Z=%d)", Z);
+    const int groups = Z / 8;
+    const int mine = (groups - rank + world - 1) / world;  // groups rank, rank+world, ...
+    if (mine < 1) return fail(ARVX_ERR_INVALID, "rank %d owns no planes (Z=%d)", rank, Z);
+    // build it as a contiguous context of mine*8 planes, then switch the z mapping
+    int rc = arvx_ctx_create_slab(out, device, X, Y, Z, voxel_size, 0, mine * 8);
+    if (rc) return rc;
+    arvx_ctx *c = *out;
+    c->ze0 = 0;  // no halo planes: neighbours in z belong to other ranks
+    c->ze1 = mine * 8;
+    c->nvox_ext = c->nvox;
+    c->stripe_world = world;
+    c->stripe_rank = rank;
+    return ARVX_OK;
+}
+
 int arvx_ctx_create(arvx_ctx **out, int device, int X, int Y, int Z, float voxel_size) {
     return arvx_ctx_create_slab(out, device, X, Y, Z, voxel_size, 0, Z);
 }
@@ -295,6 +317,7 @@ int arvx_state_upload_halo(arvx_ctx *ctx, const uint8_t *plane_below, const uint
     ARVX_CHECK_CTX(ctx);
     if (int mrc = materialize(ctx)) return mrc;
     const size_t plane = (size_t)ctx->X * ctx->Y;
+    if (ctx->stripe_world > 1) return fail(ARVX_ERR_STATE, "striped slabs keep no halo planes");
     ctx->color_ready = false;
     if (plane_below && ctx->ze0 < ctx->z0)
         ARVX_HIP(hipMemcpyAsync(ctx->d_state, plane_below, plane, hipMemcpyHostToDevice,
@@ -336,6 +359,22 @@ int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
     return ARVX_OK;
 }
 
+int arvx_pack_occupancy_global(arvx_ctx *ctx, void *dev_global_words) {
+    ARVX_CHECK_CTX(ctx);
+    if (int mrc = materialize(ctx)) return mrc;
+    if (!dev_global_words) return fail(ARVX_ERR_INVALID, "null dev_global_words");
+    const size_t plane = (size_t)ctx->X * ctx->Y;
+    if (plane % 64) return fail(ARVX_ERR_INVALID, "X*Y must be a multiple of 64");
+    const size_t nround = ctx->nvox / 256 + 1;
+    const unsigned grid = (unsigned)(nround < 8192 ? nround : 8192);
+    hipLaunchKernelGGL(arvx::pack_occupancy_global_kernel, dim3(grid), dim3(256), 0, ctx->stream,
+                       ctx->owned(), plane, ctx->z1 - ctx->z0,
+                       ctx->stripe_world > 1 ? 0 : ctx->z0, ctx->stripe_world, ctx->stripe_rank,
+                       (uint32_t *)dev_global_words);
+    ARVX_HIP(hipGetLastError());
+    return ARVX_OK;
+}
+
 // ---- carve -------------------------------------------------------------------
 
 // Launches the fused carve over planes [ze0, ze1) of `state` (owned + halo).
@@ -352,6 +391,8 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
     p.Y = ctx->Y;
     p.Z = ctx->ze1 - ctx->ze0;  // owned planes plus halo (recomputed, never exchanged)
     p.zoff = ctx->ze0;
+    p.zstride = ctx->stripe_world;
+    p.zphase = ctx->stripe_rank;
     p.s = ctx->s;
     p.W = ctx->W;
     p.H = ctx->H;
@@ -363,9 +404,12 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
     p.tilesX = (p.X + arvx::kTileX - 1) / arvx::kTileX;
     p.tilesY = (p.Y + arvx::kTileY - 1) / arvx::kTileY;
     p.tilesZ = (p.Z + arvx::kTileZ - 1) / arvx::kTileZ;
+    // coarse tile 64x32x32; striped slabs: 64x64x8, so that it stays inside one stripe
+    p.cyShift = ctx->stripe_world > 1 ? 3 : 2;
+    p.czShift = ctx->stripe_world > 1 ? 0 : 2;
     p.coarseX = (p.X + arvx::kCoarseX - 1) / arvx::kCoarseX;
-    p.coarseY = (p.Y + arvx::kCoarseY - 1) / arvx::kCoarseY;
-    p.coarseZ = (p.Z + arvx::kCoarseZ - 1) / arvx::kCoarseZ;
+    p.coarseY = (p.Y + (8 << p.cyShift) - 1) / (8 << p.cyShift);
+    p.coarseZ = (p.Z + (8 << p.czShift) - 1) / (8 << p.czShift);
     p.nchunks = (count + 63) / 64;
     p.coarseMixed = p.coarseFg = nullptr;
     p.coarseCarved = nullptr;
@@ -474,6 +518,8 @@ int arvx_color(arvx_ctx *ctx, int mode) {
     if (!ctx->has_campos) return fail(ARVX_ERR_STATE, "arvx_set_views was given no campos");
     if (mode != ARVX_COLOR_CLOSEST && mode != ARVX_COLOR_AVERAGE)
         return fail(ARVX_ERR_INVALID, "colour mode %d", mode);
+    if (ctx->stripe_world > 1)
+        return fail(ARVX_ERR_STATE, "the colour pass needs contiguous slabs (neighbour planes)");
     ctx->free_surface();
     arvx::SurfaceParams sp;
     sp.state_ext = ctx->d_state;
@@ -649,7 +695,7 @@ int arvx_fast_carve(arvx_ctx *ctx) {
     ARVX_CHECK_CTX(ctx);
     if (int mrc = materialize(ctx)) return mrc;
     if (!ctx->views_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
-    if (ctx->z0 != 0 || ctx->z1 != ctx->Z)
+    if (ctx->z0 != 0 || ctx->z1 != ctx->Z || ctx->stripe_world > 1)
         return fail(ARVX_ERR_STATE,
                     "arvx_fast_carve needs the whole grid in one context (connectivity is global)");
     ctx->color_ready = false;

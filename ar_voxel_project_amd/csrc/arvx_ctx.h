@@ -23,6 +23,7 @@ struct Ctx {
     int X = 0, Y = 0, Z = 0;  // full grid
     int z0 = 0, z1 = 0;       // slab owned here
     int ze0 = 0, ze1 = 0;     // slab plus one halo plane each side (clipped to the grid)
+    int stripe_world = 1, stripe_rank = 0;  // striped slabs (arvx_ctx_create_striped)
     float s = 0.f;
     size_t nvox = 0;      // owned voxels
     size_t nvox_ext = 0;  // voxels in the state buffer (owned + halo)

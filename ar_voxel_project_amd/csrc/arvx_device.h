@@ -17,7 +17,7 @@ namespace arvx {
 
 constexpr int kTileX = 64, kTileY = 8, kTileZ = 8;  // voxels per workgroup
 constexpr int kSubX = 16;                           // x extent of one wave's sub-tile
-constexpr int kCoarseX = 64, kCoarseY = 32, kCoarseZ = 32;  // pre-pass tile (64 sub-tiles)
+constexpr int kCoarseX = 64;  // pre-pass tile: 64 x (8 << cyShift) x (8 << czShift) voxels
 constexpr uint32_t kDone4 = 0x02020202u;            // 4 voxels carved+seen
 constexpr int kMaxImageDim = 16384;
 
@@ -30,7 +30,9 @@ struct CarveParams {
     const int *sat;         // V x satStride, summed-area table of foreground pixels
     unsigned long long *stats;
     int X, Y, Z;            // slab extent in voxels (Z = planes held)
-    int zoff;               // global z of slab plane 0
+    int zoff;               // global z of slab plane 0 (contiguous slabs)
+    int zstride, zphase;    // striped slabs: local 8-plane group g is global group
+                            // g*zstride + zphase (contiguous: 1, 0)
     float s;                // voxel edge
     int W, H;
     int bgWords, satStride;
@@ -39,10 +41,16 @@ struct CarveParams {
     int tilesX, tilesY, tilesZ;
     // coarse pre-pass results
     int coarseX, coarseY, coarseZ, nchunks;
+    int cyShift, czShift;   // coarse tile = 64 x (8 << cyShift) x (8 << czShift)
     unsigned long long *coarseMixed;  // [ncoarse][nchunks] views to re-classify per sub-tile
     unsigned long long *coarseFg;     // [ncoarse][nchunks] views that see only foreground
     uint8_t *coarseCarved;            // [ncoarse] some view carves the whole coarse tile
 };
+
+// global z of local plane lz
+__device__ __forceinline__ int global_z(const CarveParams &p, int lz) {
+    return p.zoff + (((lz >> 3) * p.zstride + p.zphase) << 3) + (lz & 7);
+}
 
 // Rounded pixel of one projected voxel.  a0,a1,a2 are the fp32 row results.
 // Returns false (outside) for non-finite quotients as x86's cvttss2si does.

@@ -123,7 +123,8 @@ __device__ inline int classify_box(const float *__restrict__ M, const BoxW b, in
     return (cnt == area) ? kClsFg : kClsMixed;
 }
 
-// Pre-pass over coarse tiles of 64 x 32 x 32 voxels (64 sub-tiles each): one wave
+// Pre-pass over coarse tiles of 64 x 32 x 32 voxels (64 sub-tiles each; striped
+// slabs use 64 x 64 x 8 so that a coarse tile stays inside one stripe): one wave
 // per coarse tile, lane i = view i.  A view that sees the whole coarse box as
 // background decides all 64 sub-tiles at once; views that are "outside" or "all
 // foreground" for the coarse box are that for every sub-tile too, so the main
@@ -136,10 +137,12 @@ __global__ __launch_bounds__(256) void carve_coarse_kernel(const CarveParams p) 
     const int cx = ct % p.coarseX;
     const int cy = (ct / p.coarseX) % p.coarseY;
     const int cz = ct / (p.coarseX * p.coarseY);
-    const int x0 = cx * kCoarseX, y0 = cy * kCoarseY, z0 = cz * kCoarseZ;
+    const int cyN = 8 << p.cyShift, czN = 8 << p.czShift;
+    const int x0 = cx * kCoarseX, y0 = cy * cyN, z0 = cz * czN;
+    // (striped slabs: the box spans the foreign planes in between as well -- conservative)
     const BoxW box = make_box(p.s, x0, min(x0 + kCoarseX - 1, p.X - 1), y0,
-                              min(y0 + kCoarseY - 1, p.Y - 1), p.zoff + z0,
-                              p.zoff + min(z0 + kCoarseZ - 1, p.Z - 1));
+                              min(y0 + cyN - 1, p.Y - 1), global_z(p, z0),
+                              global_z(p, min(z0 + czN - 1, p.Z - 1)));
     bool any_carved = false;
     int chunk = 0;
     for (int vc = p.v0; vc < p.v1; vc += 64, ++chunk) {
@@ -194,14 +197,15 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(const CarveParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) dwx[j] = (double)((float)(x + j) * p.s);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dwz[k] = (double)((float)(-(p.zoff + zb + k)) * p.s);
+    for (int k = 0; k < 4; ++k) dwz[k] = (double)((float)(-global_z(p, zb + k)) * p.s);
 
     uint32_t st[4] = {kDone4, kDone4, kDone4, kDone4};
     bool loaded = false, all_carved = false, all_done = false;
     const size_t row = (size_t)p.X;
     const size_t plane = (size_t)p.X * p.Y;
     const bool cull = !(p.flags & 1u);
-    const int ct = cull ? tx + p.coarseX * ((ty >> 2) + p.coarseY * (tz >> 2)) : 0;
+    const int ct =
+        cull ? tx + p.coarseX * ((ty >> p.cyShift) + p.coarseY * (tz >> p.czShift)) : 0;
     if (cull && p.coarseCarved[ct]) {  // wave-uniform (scalar load)
         all_carved = true;
         if ((p.flags & 2u) && lane == 0) {
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(const CarveParams p) {
             atomicAdd(&p.stats[1], 1ull);
         }
     }
-    const BoxW box = make_box(p.s, sx0, sx1, sy0, sy1, p.zoff + sz0, p.zoff + sz1);
+    const BoxW box = make_box(p.s, sx0, sx1, sy0, sy1, global_z(p, sz0), global_z(p, sz1));
 
     int chunk = 0;
     for (int vc = p.v0; vc < p.v1 && !all_done && !all_carved; vc += 64, ++chunk) {
@@ -431,6 +435,28 @@ __global__ __launch_bounds__(256) void pack_occupancy_kernel(const uint8_t *__re
             const size_t nw = (n + 31) >> 5;
             if (w0 < nw) words[w0] = (uint32_t)b;
             if (w0 + 1 < nw) words[w0 + 1] = (uint32_t)(b >> 32);
+        }
+    }
+}
+
+// Same, written at each stripe's place in the GLOBAL word plane (striped or
+// contiguous slabs): local 8-plane group g lands at global group g*zstride+zphase.
+__global__ __launch_bounds__(256) void pack_occupancy_global_kernel(
+    const uint8_t *__restrict__ state, size_t plane, int Zloc, int zoff, int zstride, int zphase,
+    uint32_t *__restrict__ words) {
+    // plane (= X*Y) is a multiple of 32: every plane starts on a word
+    const size_t n = plane * (size_t)Zloc;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const bool occ = state[i] & 1u;  // n is a multiple of 64 when plane % 64 == 0
+        const unsigned long long b = __ballot(occ);
+        if ((threadIdx.x & 63) == 0) {
+            const int lz = (int)(i / plane);
+            const size_t in_plane = i % plane;
+            const int gz = zoff + (((lz >> 3) * zstride + zphase) << 3) + (lz & 7);
+            uint32_t *dst = words + ((size_t)gz * plane + in_plane) / 32;
+            dst[0] = (uint32_t)b;
+            dst[1] = (uint32_t)(b >> 32);
         }
     }
 }

@@ -14,6 +14,14 @@ every rank holds the whole grid's occupancy.  Two interchangeable forms:
   allgather  the slabs are equal-sized, so the full plane is simply the
              concatenation of the ranks' slab words
 
+Two ways to cut the grid:
+
+  slab     rank r owns the contiguous planes slab_of(Z, world, r)
+  striped  with the planes cut into groups of 8, rank r owns groups r, r+world, ...
+           Surface voxels (where the per-voxel work is) cluster in z, so contiguous
+           slabs leave the ranks that own empty space idle; stripes balance the load.
+           Only the allreduce form applies (a rank's words are scattered).
+
 Host logic only: runs on CPU tensors with gloo (tests) and on GPU tensors with
 nccl == RCCL (bench.py).
 """
@@ -44,6 +52,11 @@ def slab_of(Z: int, world: int, rank: int) -> Tuple[int, int]:
     return z0, z0 + q + (1 if rank < r else 0)
 
 
+def stripe_planes(Z: int, world: int, rank: int):
+    """Global z of the planes rank owns under the striped layout, in local order."""
+    return [g * 8 + k for g in range(rank, Z // 8, world) for k in range(8)]
+
+
 def words_of(nvox: int) -> int:
     return (nvox + 31) // 32
 
@@ -53,11 +66,17 @@ class OccupancyExchange:
     voxel i -> bit i % 32 of int32 word i // 32, x fastest)."""
 
     def __init__(self, X: int, Y: int, Z: int, world: int, rank: int, device,
-                 mode: str = "allreduce", buffers: int = 2):
-        assert mode in ("allreduce", "allgather")
+                 mode: str = "allreduce", buffers: int = 2, layout: str = "slab"):
+        assert mode in ("allreduce", "allgather") and layout in ("slab", "striped")
         self.X, self.Y, self.Z, self.world, self.rank, self.mode = X, Y, Z, world, rank, mode
+        self.layout = layout
         self.z0, self.z1 = slab_of(Z, world, rank)
         plane = X * Y
+        if layout == "striped":
+            if mode != "allreduce":
+                raise ValueError("striped slabs are merged by allreduce only")
+            if Z % 8 or plane % 64:
+                raise ValueError("striped slabs need Z % 8 == 0 and X*Y % 64 == 0")
         if (plane * self.z0) % 32 or (world > 1 and (plane * (self.z1 - self.z0)) % 32):
             raise ValueError("slab boundaries must fall on 32-voxel words of the packed plane")
         if mode == "allgather" and Z % world:
@@ -78,8 +97,11 @@ class OccupancyExchange:
         allreduce re-zero the words owned by other ranks."""
         self.wait(b)
         if self.mode == "allreduce" and self.world > 1:
-            self.full[b][:self.off_words].zero_()
-            self.full[b][self.off_words + self.my_words:].zero_()
+            if self.layout == "striped":
+                self.full[b].zero_()  # own stripes are rewritten by the pack that follows
+            else:
+                self.full[b][:self.off_words].zero_()
+                self.full[b][self.off_words + self.my_words:].zero_()
 
     def launch(self, b: int, async_op: bool = True) -> None:
         """Start the collective on buffer b (own slab words already written)."""

@@ -123,7 +123,12 @@ def main():
         zlo, zhi = sharding.slab_of(Z, world, rank)
         nvox_global = X * Y * Z
         flags = capi.CARVE_NO_CULL if args.no_cull else 0
-        ctx = capi.Context(X, Y, Z, sc.voxel_size, device=local_rank, z_range=(zlo, zhi))
+        # allreduce: striped (load-balanced) slabs; allgather needs contiguous ones
+        layout = "striped" if (world > 1 and collective != "allgather") else "slab"
+        if layout == "striped":
+            ctx = capi.Context(X, Y, Z, sc.voxel_size, device=local_rank, stripes=(world, rank))
+        else:
+            ctx = capi.Context(X, Y, Z, sc.voxel_size, device=local_rank, z_range=(zlo, zhi))
         # a real (non-null) HIP stream shared by torch and the library, so that the
         # torch.cuda.Event pairs below bracket exactly the carve kernel launch
         stream = torch.cuda.Stream(device=dev)
@@ -133,7 +138,8 @@ def main():
         ctx.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
         ex = None
         if world > 1 and collective != "none":
-            ex = sharding.OccupancyExchange(X, Y, Z, world, rank, dev, mode=collective, buffers=2)
+            ex = sharding.OccupancyExchange(X, Y, Z, world, rank, dev, mode=collective, buffers=2,
+                                            layout=layout)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
               for _ in range(steps)]
         nstep = [0]
@@ -151,7 +157,7 @@ def main():
             if ex is not None:
                 b = nstep[0] % 2
                 ex.prepare(b)
-                ctx.pack_occupancy(ex.my_slice(b).data_ptr())
+                ctx.pack_occupancy_global(ex.full[b].data_ptr())
                 ex.launch(b, async_op=True)
             nstep[0] += 1
 
@@ -180,15 +186,18 @@ def main():
         if rank == 0:
             st = ctx.download_state()
             occ = float((st & 1).mean())
-            if ex is not None:  # the merged plane must hold this rank's slab bits
-                mine = np.packbits((st.reshape(-1) & 1).astype(np.uint8), bitorder="little")
-                got = ex.my_slice((nstep[0] - 1) % 2).cpu().numpy().view(np.uint8)
-                if not np.array_equal(got[:len(mine)], mine):
-                    raise SystemExit("merged occupancy does not contain rank 0's slab")
+            if ex is not None:  # the merged plane must hold this rank's planes
+                got = ex.full[(nstep[0] - 1) % 2].cpu().numpy().view(np.uint8)
+                got = got.reshape(Z, X * Y // 8)[ctx.planes]
+                mine = np.packbits((st.reshape(len(ctx.planes), -1) & 1).astype(np.uint8),
+                                   axis=1, bitorder="little")
+                if not np.array_equal(got, mine):
+                    raise SystemExit("merged occupancy does not contain rank 0's planes")
         ctx.close()
         del d_masks
+        nplanes = len(ctx.planes) if hasattr(ctx, "planes") else zhi - zlo
         return dict(X=X, Y=Y, Z=Z, V=V, dt=dt, kern_ms=kern_ms, sc=sc, occ=occ,
-                    slab=(zlo, zhi), nvox=nvox_global)
+                    nplanes=nplanes, layout=layout, nvox=nvox_global)
 
     r = run_config(args.grid, args.views, args.steps, args.warmup, args.collective)
     vv = r["nvox"] * r["V"]
@@ -198,7 +207,7 @@ def main():
     # roofline of the carve kernel: SURVEY 8(d) algorithmic bytes, HBM-read side:
     # N*V (one state byte per voxel-view) + V*W*H (one mask byte per pixel), for the
     # voxels THIS rank's launch processes.
-    nv_rank = r["X"] * r["Y"] * (r["slab"][1] - r["slab"][0])
+    nv_rank = r["X"] * r["Y"] * r["nplanes"]
     alg_bytes = nv_rank * r["V"] + r["V"] * r["sc"].W * r["sc"].H
     achieved = alg_bytes / (r["kern_ms"] * 1e-3) / 1e9
     traffic = None
@@ -228,7 +237,7 @@ def main():
         "config": {"workload": f"synthetic sphere silhouettes, {r['X']}x{r['Y']}x{r['Z']} grid, "
                                f"{r['V']} views 640x480, dense carve (all views fused)",
                    "grid": [r["X"], r["Y"], r["Z"]], "views": r["V"],
-                   "parallelism": f"z-slab x{world}" if world > 1 else "single GPU",
+                   "parallelism": f"z-slab x{world} ({r['layout']})" if world > 1 else "single GPU",
                    "collective": args.collective if world > 1 else "none",
                    "cull": not args.no_cull},
         "carve_kernel_ms": r["kern_ms"], "occupied_fraction": r["occ"],

@@ -78,6 +78,13 @@ int arvx_ctx_create(arvx_ctx **out, int device, int X, int Y, int Z,
  * (one Z slab of a multi-GPU split). State buffers cover the slab only. */
 int arvx_ctx_create_slab(arvx_ctx **out, int device, int X, int Y, int Z,
                          float voxel_size, int z_begin, int z_end);
+/* Same grid, striped over `world` GPUs for load balance: with the planes cut
+ * into groups of 8, this context holds groups rank, rank+world, rank+2*world, ...
+ * back to back (Z must be a multiple of 8).  Carve, state up/download and
+ * arvx_pack_occupancy_global work on striped contexts; the colour pass and
+ * arvx_fast_carve need neighbouring planes and take contiguous slabs only. */
+int arvx_ctx_create_striped(arvx_ctx **out, int device, int X, int Y, int Z,
+                            float voxel_size, int world, int rank);
 int arvx_ctx_destroy(arvx_ctx *ctx);
 /* Launch on a caller-owned hipStream_t (borrowed); NULL = context's own. */
 int arvx_ctx_set_stream(arvx_ctx *ctx, void *hip_stream);
@@ -134,6 +141,10 @@ int arvx_state_upload_halo(arvx_ctx *ctx, const uint8_t *plane_below,
 /* Pack bit0 (occupied) of the slab into 32-bit words, voxel i -> bit i%32 of
  * word i/32, written to device memory dev_words (>= ceil(n/32) words). */
 int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words);
+/* Same bits, written at their place in the word plane of the WHOLE grid
+ * (ceil(X*Y*Z/32) words at dev_global_words): plane z starts at word z*X*Y/32.
+ * Works for contiguous and striped slabs; needs X*Y to be a multiple of 64. */
+int arvx_pack_occupancy_global(arvx_ctx *ctx, void *dev_global_words);
 
 /* ---- hot path --------------------------------------------------------- */
 

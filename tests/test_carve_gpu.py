@@ -159,6 +159,7 @@ def test_pack_occupancy_layout(arvx, oracle):
             ctx.carve()
             n = X * Y * (zr[1] - zr[0])
             words = torch.full(((n + 31) // 32 + 2,), -1, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()  # the fill runs on torch's stream, the pack on the context's
             ctx.pack_occupancy(words.data_ptr())
             ctx.synchronize()
             got = words.cpu().numpy()
@@ -214,3 +215,47 @@ def test_lazy_reset_and_reuse(arvx, oracle):
         ctx.carve_views(0, 2)
         ctx.carve_views(2, 3)
         assert_same(ctx.download_state(), want, "after reset, two ranges")
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_striped_slabs(arvx, oracle, world):
+    """Striped (load-balanced) split: rank r holds 8-plane groups r, r+world, ...; the
+    union over ranks is the full carve, and pack_occupancy_global puts every plane's
+    bits at its place in the whole grid's word plane."""
+    import torch
+    X, Y, Z, V = 48, 40, 64, 6
+    sc = scenes.small_sphere(64, V)
+    s = np.float32(0.512 / 64)
+    want = oracle.carve(X, Y, Z, s, sc.M, sc.masks)
+    total_words = X * Y * Z // 32
+    merged = torch.zeros(total_words, dtype=torch.int32, device="cuda")
+    got = np.zeros_like(want)
+    for rank in range(world):
+        with arvx.Context(X, Y, Z, s, stripes=(world, rank)) as ctx:
+            ctx.set_views(sc.M, sc.masks)
+            ctx.carve()
+            st = ctx.download_state()
+            assert st.shape[0] == len(ctx.planes)
+            got[ctx.planes] = st
+            words = torch.zeros(total_words, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()  # the fill runs on torch's stream, the pack on the context's
+            ctx.pack_occupancy_global(words.data_ptr())
+            ctx.synchronize()
+            merged += words  # what the SUM all-reduce does
+            with pytest.raises(arvx.ArvxError):
+                ctx.fast_carve()
+    assert_same(got, want, f"striped world={world}")
+    ref = np.packbits((want.reshape(-1) & 1).astype(np.uint8), bitorder="little").view(np.int32)
+    assert np.array_equal(merged.cpu().numpy(), ref)
+    # contiguous slabs through the same global pack
+    merged.zero_()
+    for zr in [(0, 24), (24, 64)]:
+        with arvx.Context(X, Y, Z, s, z_range=zr) as ctx:
+            ctx.set_views(sc.M, sc.masks)
+            ctx.carve()
+            words = torch.zeros(total_words, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()  # the fill runs on torch's stream, the pack on the context's
+            ctx.pack_occupancy_global(words.data_ptr())
+            ctx.synchronize()
+            merged += words
+    assert np.array_equal(merged.cpu().numpy(), ref)
