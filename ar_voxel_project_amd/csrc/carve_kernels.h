@@ -410,17 +410,6 @@ __global__ __launch_bounds__(256) void sat_cols_kernel(int W, int H, int *__rest
     }
 }
 
-__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *__restrict__ dst, size_t n4,
-                                                       uint32_t value, uint8_t *__restrict__ tail,
-                                                       int ntail) {
-    // n4 = number of 16-byte groups
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    uint4 v4 = make_uint4(value, value, value, value);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
-        reinterpret_cast<uint4 *>(dst)[i] = v4;
-    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = (uint8_t)value;
-}
-
 // occupancy bit-plane: voxel i -> bit i%32 of word i/32
 __global__ __launch_bounds__(256) void pack_occupancy_kernel(const uint8_t *__restrict__ state,
                                                              size_t n,

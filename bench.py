@@ -216,7 +216,7 @@ def main():
         try:
             tj = json.load(open(tpath))
             key = f"{r['X']}x{r['Y']}x{r['Z']}x{r['V']}" + ("_nocull" if args.no_cull else "")
-            traffic = tj.get(key)
+            traffic = tj.get(key, {}).get("bytes_per_launch") if world == 1 else None
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -259,3 +259,66 @@ def test_striped_slabs(arvx, oracle, world):
             ctx.synchronize()
             merged += words
     assert np.array_equal(merged.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("W,H,C,V", [(33, 17, 1, 3), (97, 61, 3, 1), (64, 64, 4, 64), (40, 30, 2, 65),
+                                     (1, 1, 1, 2)])
+def test_odd_image_sizes_and_view_counts(arvx, oracle, W, H, C, V):
+    N = 28
+    s = np.float32(0.512 / N)
+    _, _, M = scenes.random_cameras(V, 0.512, seed=W + V, W=W, H=H, inside=(V % 2 == 0))
+    masks = scenes.noise_masks(V, H, W, C=C, block=max(1, W // 8), seed=H)
+    want = oracle.carve(N, N, N, s, M, masks)
+    for flags in (0, 1):
+        assert_same(run_gpu(arvx, N, N, N, s, M, masks, flags), want,
+                    f"{W}x{H}x{C} V={V} flags={flags}")
+
+
+def test_camera_centre_on_a_voxel(arvx, oracle):
+    """proj2 == 0 exactly for the voxel the camera sits on: 0/0 and x/0 -> outside."""
+    N, W, H = 24, 96, 72
+    s = np.float32(0.5 / 16)  # power of two: the voxel position is exact
+    K = scenes.syn.K_DATASET.copy()
+    K[0] *= W / 640
+    K[1] *= H / 480
+    K32 = K.astype(np.float32)
+    Rts = []
+    for (vx, vy, vz) in [(5, 6, 7), (0, 0, 0), (23, 23, 23)]:
+        cam = np.array([vy * float(s), vx * float(s), -vz * float(s)])
+        Rts.append(scenes.syn.look_at_rt(cam, cam + np.array([0.3, 0.2, -0.5])))
+    Rt = np.array(Rts)
+    Rt[:, :, :3] = np.round(Rt[:, :, :3] * 64) / 64  # few mantissa bits: R*cam is exact
+    Rt[:, :, 3] = -np.einsum("vij,vj->vi", Rt[:, :, :3],
+                             np.array([[6 * s, 5 * s, -7 * s], [0, 0, 0], [23 * s, 23 * s, -23 * s]]))
+    Rt = Rt.astype(np.float32)
+    M = scenes.syn.compose_m(K32, Rt)
+    raw = oracle.project_raw(M[0], s, 5, 6, 7)
+    assert raw[2] == 0.0 and oracle.project(M[0], s, 5, 6, 7, W, H) is None
+    masks = scenes.noise_masks(3, H, W, block=3, seed=5)
+    want = oracle.carve(N, N, N, s, M, masks)
+    for flags in (0, 1):
+        assert_same(run_gpu(arvx, N, N, N, s, M, masks, flags), want, f"on-voxel camera {flags}")
+
+
+def test_row_stride_padding(arvx, oracle):
+    """Masks with padded rows (cv::Mat step > cols*channels) through arvx_set_views."""
+    import ctypes as C
+    N, V, W, H, Cn = 20, 3, 50, 30, 3
+    s = np.float32(0.512 / N)
+    _, _, M = scenes.random_cameras(V, 0.512, seed=1, W=W, H=H)
+    tight = scenes.noise_masks(V, H, W, C=Cn, block=4, seed=2)
+    stride = W * Cn + 13
+    padded = np.full((V, H, stride), 0xAB, np.uint8)  # garbage in the padding
+    padded[:, :, :W * Cn] = tight.reshape(V, H, W * Cn)
+    want = oracle.carve(N, N, N, s, M, tight)
+    lib = arvx.load_library()
+    with arvx.Context(N, N, N, s) as ctx:
+        ptrs = (C.c_void_p * V)(*[padded[i].ctypes.data for i in range(V)])
+        Mf = np.ascontiguousarray(M, np.float32).reshape(-1)
+        rc = lib.arvx_set_views(ctx._h, V, Mf.ctypes.data_as(C.POINTER(C.c_float)), None, ptrs,
+                                W, H, Cn, stride)
+        assert rc == 0, lib.arvx_last_error()
+        ctx.carve()
+        assert_same(ctx.download_state(), want, "padded rows")
+        assert lib.arvx_set_views(ctx._h, V, Mf.ctypes.data_as(C.POINTER(C.c_float)), None, ptrs,
+                                  W, H, Cn, W * Cn - 1) == 1  # stride too small
