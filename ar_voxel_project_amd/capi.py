@@ -33,6 +33,7 @@ SYMBOLS = [
     "arvx_pack_occupancy", "arvx_pack_occupancy_global", "arvx_carve", "arvx_carve_views", "arvx_fast_carve",
     "arvx_color", "arvx_surface_count", "arvx_surface_download",
     "arvx_surface_depth_download",
+    "arvx_colors_upload", "arvx_closure", "arvx_closure_count", "arvx_closure_download",
     "arvx_export_model", "arvx_get_stats",
 ]
 
@@ -108,6 +109,10 @@ def load_library() -> C.CDLL:
     lib.arvx_surface_count.argtypes = [p, C.POINTER(C.c_int64)]
     lib.arvx_surface_download.argtypes = [p, C.POINTER(C.c_int64), f32p]
     lib.arvx_surface_depth_download.argtypes = [p, f32p]
+    lib.arvx_colors_upload.argtypes = [p, C.c_int64, C.POINTER(C.c_int64), f32p]
+    lib.arvx_closure.argtypes = [p, C.c_int, C.c_int]
+    lib.arvx_closure_count.argtypes = [p, C.POINTER(C.c_int64)]
+    lib.arvx_closure_download.argtypes = [p, C.POINTER(C.c_int64), f32p]
     lib.arvx_export_model.argtypes = [p, f32p, C.c_int]
     lib.arvx_get_stats.argtypes = [p, C.POINTER(Stats)]
     for name in SYMBOLS:
@@ -302,6 +307,25 @@ class Context:
         if n.value:
             _check(self._lib.arvx_surface_depth_download(self._h, _fp(d)))
         return d
+
+    def upload_colors(self, index, rgb) -> None:
+        index = np.ascontiguousarray(index, dtype=np.int64)
+        rgb = _f32(rgb).reshape(-1, 3)
+        assert len(index) == len(rgb)
+        _check(self._lib.arvx_colors_upload(self._h, len(index),
+                                            index.ctypes.data_as(C.POINTER(C.c_int64)), _fp(rgb)))
+
+    def closure(self, kernel_size: int = 3, apply_unseen: bool = True):
+        """applyClosure; returns (flat indices of the filled voxels, their RGBA)."""
+        _check(self._lib.arvx_closure(self._h, kernel_size, int(apply_unseen)))
+        n = C.c_int64()
+        _check(self._lib.arvx_closure_count(self._h, C.byref(n)))
+        idx = np.empty(n.value, np.int64)
+        rgba = np.empty((n.value, 4), np.float32)
+        if n.value:
+            _check(self._lib.arvx_closure_download(
+                self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)), _fp(rgba)))
+        return idx, rgba
 
     def export_model(self, apply_unseen: bool = False) -> np.ndarray:
         out = np.empty((self.nvox, 4), np.float32)

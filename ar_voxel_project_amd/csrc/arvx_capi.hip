@@ -16,6 +16,7 @@
 #include "arvx_ctx.h"
 #include "carve_kernels.h"
 #include "color_kernels.h"
+#include "closure_kernels.h"
 #include "fast_carve_kernels.h"
 #include <algorithm>
 
@@ -299,6 +300,7 @@ static int materialize(Ctx *ctx);
 int arvx_state_reset(arvx_ctx *ctx) {
     ARVX_CHECK_CTX(ctx);
     ctx->color_ready = false;
+    ctx->closure_ready = false;
     ctx->fresh_pending = true;  // see materialize()
     return ARVX_OK;
 }
@@ -308,6 +310,7 @@ int arvx_state_upload(arvx_ctx *ctx, const uint8_t *state) {
     if (int mrc = materialize(ctx)) return mrc;
     if (!state) return fail(ARVX_ERR_INVALID, "null state");
     ctx->color_ready = false;
+    ctx->closure_ready = false;
     ARVX_HIP(hipMemcpyAsync(ctx->owned(), state, ctx->nvox, hipMemcpyHostToDevice, ctx->stream));
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
     return ARVX_OK;
@@ -319,6 +322,7 @@ int arvx_state_upload_halo(arvx_ctx *ctx, const uint8_t *plane_below, const uint
     const size_t plane = (size_t)ctx->X * ctx->Y;
     if (ctx->stripe_world > 1) return fail(ARVX_ERR_STATE, "striped slabs keep no halo planes");
     ctx->color_ready = false;
+    ctx->closure_ready = false;
     if (plane_below && ctx->ze0 < ctx->z0)
         ARVX_HIP(hipMemcpyAsync(ctx->d_state, plane_below, plane, hipMemcpyHostToDevice,
                                 ctx->stream));
@@ -464,6 +468,7 @@ int arvx_carve_views(arvx_ctx *ctx, int first, int count, unsigned flags) {
                     ctx->V);
     if (count == 0) return ARVX_OK;
     ctx->color_ready = false;
+    ctx->closure_ready = false;
     const bool fresh = ctx->fresh_pending;
     ctx->fresh_pending = false;  // the kernel writes every voxel of the plane
     return launch_carve(ctx, ctx->d_state, first, count, flags, fresh);
@@ -507,6 +512,7 @@ int arvx_set_images(arvx_ctx *ctx, const uint8_t *const *images, size_t stride) 
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
     ctx->images_ready = true;
     ctx->color_ready = false;
+    ctx->closure_ready = false;
     return ARVX_OK;
 }
 
@@ -653,6 +659,9 @@ int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen) {
     ARVX_CHECK_CTX(ctx);
     if (int mrc = materialize(ctx)) return mrc;
     if (!rgba) return fail(ARVX_ERR_INVALID, "null rgba");
+    if (ctx->closure_ready && (apply_unseen != 0) != (ctx->closure_unseen != 0))
+        return fail(ARVX_ERR_STATE, "arvx_closure was computed with apply_unseen=%d",
+                    ctx->closure_unseen);
     const size_t chunk = (size_t)1 << 24;  // voxels per chunk: 256 MiB of float4
     const size_t nchunk = std::min(chunk, ctx->nvox);
     float4 *d_out = nullptr;
@@ -678,6 +687,20 @@ int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen) {
                                    ctx->d_surf_has, first, last, ctx->owned(), i0, d_out,
                                    apply_unseen);
         }
+        if (ctx->closure_ready && ctx->clo_count > 0) {
+            const auto &idx = ctx->h_clo_index;
+            const long long first =
+                std::lower_bound(idx.begin(), idx.end(), (int)i0) - idx.begin();
+            const long long last = (i0 + n > (size_t)INT32_MAX)
+                                       ? (long long)idx.size()
+                                       : std::lower_bound(idx.begin(), idx.end(), (int)(i0 + n)) -
+                                             idx.begin();
+            if (last > first)
+                hipLaunchKernelGGL(arvx::export_overlay_kernel,
+                                   dim3((unsigned)((last - first + 255) / 256)), dim3(256), 0,
+                                   ctx->stream, ctx->d_clo_index, (const float4 *)ctx->d_clo_rgba,
+                                   first, last, i0, d_out);
+        }
         hipError_t e = hipGetLastError();
         if (e == hipSuccess)
             e = hipMemcpyAsync(rgba + 4 * i0, d_out, n * sizeof(float4), hipMemcpyDeviceToHost,
@@ -687,6 +710,120 @@ int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen) {
     }
     (void)hipFree(d_out);
     return rc;
+}
+
+// ---- closure -------------------------------------------------------------------------
+
+int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const float *rgb) {
+    ARVX_CHECK_CTX(ctx);
+    if (n < 0 || (n > 0 && (!index || !rgb))) return fail(ARVX_ERR_INVALID, "bad colour list");
+    ctx->free_surface();
+    std::vector<int> idx((size_t)n);
+    for (int64_t k = 0; k < n; ++k) {
+        if (index[k] < 0 || (size_t)index[k] >= ctx->nvox || (k && index[k] <= index[k - 1]))
+            return fail(ARVX_ERR_INVALID, "colour indices must be ascending and inside the grid");
+        idx[(size_t)k] = (int)index[k];
+    }
+    ctx->surf_count = n;
+    ctx->h_surf_index = idx;
+    ctx->h_surf_has.assign((size_t)n, 1);
+    if (n > 0) {
+        ARVX_HIP(hipMalloc(&ctx->d_surf_index, (size_t)n * sizeof(int)));
+        ARVX_HIP(hipMalloc(&ctx->d_surf_rgb, (size_t)n * 3 * sizeof(float)));
+        ARVX_HIP(hipMalloc(&ctx->d_surf_depth, (size_t)n * sizeof(float)));
+        ARVX_HIP(hipMalloc(&ctx->d_surf_has, (size_t)n));
+        ARVX_HIP(hipMemcpyAsync(ctx->d_surf_index, idx.data(), (size_t)n * sizeof(int),
+                                hipMemcpyHostToDevice, ctx->stream));
+        ARVX_HIP(hipMemcpyAsync(ctx->d_surf_rgb, rgb, (size_t)n * 3 * sizeof(float),
+                                hipMemcpyHostToDevice, ctx->stream));
+        ARVX_HIP(hipMemsetAsync(ctx->d_surf_depth, 0, (size_t)n * sizeof(float), ctx->stream));
+        ARVX_HIP(hipMemsetAsync(ctx->d_surf_has, 1, (size_t)n, ctx->stream));
+        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->color_ready = true;
+    return ARVX_OK;
+}
+
+int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
+    ARVX_CHECK_CTX(ctx);
+    if (int mrc = materialize(ctx)) return mrc;
+    if (kernel_size < 1 || kernel_size % 2 != 1 || kernel_size > 9)
+        return fail(ARVX_ERR_INVALID, "kernel size %d (odd, 1..9)", kernel_size);
+    if (ctx->z0 != 0 || ctx->z1 != ctx->Z || ctx->stripe_world > 1)
+        return fail(ARVX_ERR_STATE, "arvx_closure needs the whole grid in one context");
+    if (ctx->closure_ready)
+        return fail(ARVX_ERR_STATE, "closure already applied to this model state");
+    ctx->free_closure();
+    arvx::ClosureParams cp;
+    cp.state = ctx->d_state;
+    cp.X = ctx->X;
+    cp.Y = ctx->Y;
+    cp.Z = ctx->Z;
+    cp.radius = (kernel_size - 1) / 2;
+    cp.apply_unseen = apply_unseen ? 1 : 0;
+    cp.col_index = ctx->color_ready ? ctx->d_surf_index : nullptr;
+    cp.col_rgb = ctx->color_ready ? ctx->d_surf_rgb : nullptr;
+    cp.col_has = ctx->color_ready ? ctx->d_surf_has : nullptr;
+    cp.ncol = ctx->color_ready ? ctx->surf_count : 0;
+    const int nblk = (int)((ctx->nvox + arvx::kSurfChunk - 1) / arvx::kSurfChunk);
+    const size_t need = (size_t)nblk * sizeof(int) + (size_t)(nblk + 1) * sizeof(long long) + 64;
+    if (ctx->scratch_bytes < need) {
+        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        ARVX_HIP(hipMalloc(&ctx->d_scratch, need));
+        ctx->scratch_bytes = need;
+    }
+    long long *d_off = (long long *)ctx->d_scratch;
+    int *d_cnt = (int *)(d_off + nblk + 1);
+    hipLaunchKernelGGL(arvx::closure_count_kernel, dim3(nblk), dim3(256), 0, ctx->stream, cp,
+                       d_cnt);
+    ARVX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(arvx::surface_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, d_cnt, nblk,
+                       d_off);
+    ARVX_HIP(hipGetLastError());
+    long long total = 0;
+    ARVX_HIP(hipMemcpyAsync(&total, d_off + nblk, sizeof total, hipMemcpyDeviceToHost,
+                            ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->clo_count = total;
+    if (total > 0) {
+        ARVX_HIP(hipMalloc(&ctx->d_clo_index, (size_t)total * sizeof(int)));
+        ARVX_HIP(hipMalloc(&ctx->d_clo_rgba, (size_t)total * sizeof(float4)));
+        hipLaunchKernelGGL(arvx::closure_write_kernel, dim3(nblk), dim3(256), 0, ctx->stream, cp,
+                           d_off, ctx->d_clo_index, (float4 *)ctx->d_clo_rgba);
+        ARVX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(arvx::closure_mark_kernel, dim3((unsigned)((total + 255) / 256)),
+                           dim3(256), 0, ctx->stream, ctx->d_state, ctx->d_clo_index, total);
+        ARVX_HIP(hipGetLastError());
+        ctx->h_clo_index.resize((size_t)total);
+        ARVX_HIP(hipMemcpyAsync(ctx->h_clo_index.data(), ctx->d_clo_index,
+                                (size_t)total * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->closure_ready = true;
+    ctx->closure_unseen = cp.apply_unseen;
+    return ARVX_OK;
+}
+
+int arvx_closure_count(arvx_ctx *ctx, int64_t *count) {
+    if (!ctx || !count) return fail(ARVX_ERR_INVALID, "null argument");
+    if (!ctx->closure_ready) return fail(ARVX_ERR_STATE, "no closure result (call arvx_closure)");
+    *count = ctx->clo_count;
+    return ARVX_OK;
+}
+
+int arvx_closure_download(arvx_ctx *ctx, int64_t *index, float *rgba) {
+    ARVX_CHECK_CTX(ctx);
+    if (!index || !rgba) return fail(ARVX_ERR_INVALID, "null argument");
+    if (!ctx->closure_ready) return fail(ARVX_ERR_STATE, "no closure result (call arvx_closure)");
+    for (size_t k = 0; k < ctx->h_clo_index.size(); ++k) index[k] = ctx->h_clo_index[k];
+    if (ctx->clo_count) {
+        ARVX_HIP(hipMemcpyAsync(rgba, ctx->d_clo_rgba, (size_t)ctx->clo_count * sizeof(float4),
+                                hipMemcpyDeviceToHost, ctx->stream));
+        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return ARVX_OK;
 }
 
 // ---- greedy carve -------------------------------------------------------------------
@@ -699,6 +836,7 @@ int arvx_fast_carve(arvx_ctx *ctx) {
         return fail(ARVX_ERR_STATE,
                     "arvx_fast_carve needs the whole grid in one context (connectivity is global)");
     ctx->color_ready = false;
+    ctx->closure_ready = false;
     arvx::FloodParams fp;
     fp.X = ctx->X;
     fp.Y = ctx->Y;

@@ -63,6 +63,24 @@ struct Ctx {
     std::vector<uint8_t> h_surf_has;
     bool color_ready = false;
 
+    // closure (dilation) result: filled voxels, ascending index
+    int *d_clo_index = nullptr;
+    void *d_clo_rgba = nullptr;  // float4 per filled voxel
+    int64_t clo_count = 0;
+    bool closure_ready = false;
+    int closure_unseen = 0;
+    std::vector<int> h_clo_index;
+
+    void free_closure() {
+        if (d_clo_index) (void)hipFree(d_clo_index);
+        if (d_clo_rgba) (void)hipFree(d_clo_rgba);
+        d_clo_index = nullptr;
+        d_clo_rgba = nullptr;
+        clo_count = 0;
+        closure_ready = false;
+        h_clo_index.clear();
+    }
+
     void free_views() {
         if (d_M) (void)hipFree(d_M);
         if (d_campos) (void)hipFree(d_campos);
@@ -74,6 +92,7 @@ struct Ctx {
         views_ready = false;
     }
     void free_surface() {
+        free_closure();
         if (d_surf_index) (void)hipFree(d_surf_index);
         if (d_surf_rgb) (void)hipFree(d_surf_rgb);
         if (d_surf_depth) (void)hipFree(d_surf_depth);

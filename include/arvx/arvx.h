@@ -168,6 +168,25 @@ int arvx_surface_download(arvx_ctx *ctx, int64_t *index, float *rgb);
 /* Smallest sample depth of each coloured voxel (same order), as the reference
  * computes it: (float)cv::norm(cameras[i] - world), src/ColorReconstruction.h:59. */
 int arvx_surface_depth_download(arvx_ctx *ctx, float *depth);
+/* Replace the device-side sparse colours by a caller-supplied list (n voxels,
+ * ascending flat index, 3 floats RGB each, w = 1): lets a host Model that was
+ * coloured elsewhere go through arvx_closure / arvx_export_model. */
+int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const float *rgb);
+
+/* Morphological closure: reference applyClosure(model, kernel_size),
+ * src/Postprocessing3d.cpp:4-100 (called at src/main.cpp:297-299 after the
+ * colour pass and handleUnseen).  As in the reference the erosion half never
+ * removes anything (it tests w < 0), so this is one dilation with a
+ * kernel_size^3 box whose new voxels get the mean RGBA of their occupied
+ * neighbours.  apply_unseen != 0: the model is taken as it is after
+ * handleUnseen().  State bytes may carry bit2 (voxel painted UNSEEN_COLOR by
+ * a host Model).  Whole-grid contexts only.  The filled voxels become occupied;
+ * arvx_export_model(ctx, ., same apply_unseen) then returns the closed model. */
+int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen);
+int arvx_closure_count(arvx_ctx *ctx, int64_t *count);
+/* Filled voxels, ascending flat index, 4 floats RGBA each. */
+int arvx_closure_download(arvx_ctx *ctx, int64_t *index, float *rgba);
+
 /* Model::voxels as the reference would hold it after carve [+ colour]
  * [+ handleUnseen]: n*4 floats (RGBA), n = slab voxels. */
 int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen);

@@ -15,6 +15,7 @@
 #ifndef ARVX_MODEL_HPP
 #define ARVX_MODEL_HPP
 
+#include <algorithm>
 #include <cstdint>
 #include <fstream>
 #include <iostream>
@@ -170,6 +171,18 @@ class Model {
         set(x, y, z, v);
     }
     size_t colored_voxels() const { return colors_.size(); }
+    // explicit colours of occupied voxels, ascending flat index (for arvx_colors_upload)
+    std::vector<std::pair<int, Vec4f>> sorted_colors() const {
+        std::vector<std::pair<int, Vec4f>> v;
+        v.reserve(colors_.size());
+        for (const auto &kv : colors_)
+            if (kv.second.w() != 0) v.push_back(kv);
+        std::sort(v.begin(), v.end(),
+                  [](const std::pair<int, Vec4f> &a, const std::pair<int, Vec4f> &b) {
+                      return a.first < b.first;
+                  });
+        return v;
+    }
 
    private:
     const int size_x, size_y, size_z;

@@ -10,6 +10,7 @@
 #include <iostream>
 #include <vector>
 
+#include "arvx/postprocessing.hpp"
 #include "arvx/voxel_carving.hpp"
 
 using arvx::Model;
@@ -107,6 +108,12 @@ static int run_carve(const char *scene, const char *out, const char *mode) {
             arvx::carve(intr, model, views);
             arvx::reconstructAvgColor(intr, model, views);
             model.handleUnseen();
+        } else if (!std::strcmp(mode, "closure")) {  // src/main.cpp:262-299
+            arvx::carve(intr, model, views);
+            arvx::reconstructAvgColor(intr, model, views);
+            model.handleUnseen();
+            if (arvx::applyClosure(&model, 3) != 0) return 5;
+            if (arvx::applyClosure(&model, 4) != -1) return 6;  // even size: skipped
         } else { std::fprintf(stderr, "unknown mode %s\n", mode); return 2; }
     } catch (const arvx::Error &e) {
         std::fprintf(stderr, "arvx::Error %d: %s\n", e.code, e.what());

@@ -1,0 +1,85 @@
+"""Morphological closure (reference applyClosure, src/Postprocessing3d.cpp:4-100)
+on the GPU vs the oracle's literal restatement: the whole RGBA model, exactly."""
+import numpy as np
+import pytest
+
+from tests import golden_io, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def pipeline(arvx, X, Y, Z, s, M, campos, masks, images, mode, unseen, ksize=3):
+    with arvx.Context(X, Y, Z, s) as ctx:
+        ctx.set_views(M, masks, campos=campos)
+        ctx.set_images(images)
+        ctx.carve()
+        if mode is not None:
+            ctx.color(mode)
+        idx, rgba = ctx.closure(ksize, unseen)
+        out = ctx.export_model(unseen)
+        st = ctx.download_state()
+        with pytest.raises(arvx.ArvxError):
+            ctx.closure(ksize, unseen)  # already applied
+        with pytest.raises(arvx.ArvxError):
+            ctx.export_model(not unseen)  # inconsistent flag
+    return idx, rgba, out, st
+
+
+@pytest.mark.parametrize("mode,unseen", [(1, True), (0, True), (1, False), (None, True)])
+@pytest.mark.parametrize("dims", [(32, 32, 32), (50, 50, 25), (21, 13, 11)])
+def test_closure_parity(arvx, oracle, dims, mode, unseen):
+    X, Y, Z = dims
+    V = 5
+    sc = scenes.syn.sphere_scene(32, V, W=160, H=120, with_images=True)
+    s = np.float32(0.512 / max(dims))
+    st = oracle.carve(X, Y, Z, s, sc.M, sc.masks)
+    model = oracle.model_from_state(st)
+    if mode is not None:
+        model = oracle.color(X, Y, Z, s, sc.M, sc.campos, sc.images, mode, model)
+    if unseen:
+        model = oracle.handle_unseen(st, model)
+    want = oracle.closure(X, Y, Z, model)
+    idx, rgba, out, gst = pipeline(arvx, X, Y, Z, s, sc.M, sc.campos, sc.masks, sc.images, mode,
+                                   unseen)
+    assert np.array_equal(out, want)
+    filled = np.nonzero((want[:, 3] != 0) & (model[:, 3] == 0))[0]
+    assert np.array_equal(idx, filled) and len(idx) > 0
+    assert np.array_equal(rgba, want[idx])
+    occ_want = want[:, 3] != 0
+    occ_got = ((gst.reshape(-1) & 1) == 1) | (unseen & ((gst.reshape(-1) & 2) == 0))
+    assert np.array_equal(occ_got, occ_want)
+
+
+def test_closure_kernel_5_and_uploaded_colors(arvx, oracle):
+    """Bigger box, and a model whose colours come from the caller (arvx_colors_upload)."""
+    X, Y, Z = 18, 15, 12
+    rng = np.random.default_rng(4)
+    st0 = np.where(rng.random((Z, Y, X)) < 0.08, 3, 2).astype(np.uint8)
+    model = oracle.model_from_state(st0)
+    occ = np.nonzero(model[:, 3] != 0)[0]
+    pick = occ[rng.random(len(occ)) < 0.5]
+    model[pick, :3] = rng.integers(0, 256, size=(len(pick), 3)).astype(np.float32)
+    for k, radius_fn in ((5, None), (3, None), (1, None)):
+        want = model.copy()
+        if k == 3:
+            want = oracle.closure(X, Y, Z, model)
+        with arvx.Context(X, Y, Z, 0.01) as ctx:
+            ctx.upload_state(st0)
+            ctx.upload_colors(pick, model[pick, :3])
+            idx, rgba = ctx.closure(k, False)
+            out = ctx.export_model(False)
+        if k == 3:
+            assert np.array_equal(out, want)
+        elif k == 1:
+            assert len(idx) == 0 and np.array_equal(out, model)
+        else:
+            assert len(idx) > 0 and np.all(out[idx, 3] == 1.0)
+            assert np.array_equal(out[occ], model[occ])
+
+
+@pytest.mark.parametrize("name", golden_io.names())
+def test_closure_matches_golden(arvx, name):
+    g = golden_io.load(name)
+    _, _, out, _ = pipeline(arvx, g["X"], g["Y"], g["Z"], g["s"], g["M"], g["campos"], g["masks"],
+                            g["images"], 1, True)
+    assert np.array_equal(out, g["closed_rgba"])

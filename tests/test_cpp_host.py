@@ -49,7 +49,8 @@ def read_result(path, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["carve", "carve_steps", "closest", "average_unseen", "fast"])
+@pytest.mark.parametrize("mode", ["carve", "carve_steps", "closest", "average_unseen", "fast",
+                                  "closure"])
 def test_cpp_entry_points_match_oracle(host_bin, oracle, tmp_path, mode):
     X, Y, Z, V = 30, 20, 12, 5
     sc = scenes.syn.sphere_scene(32, V, W=96, H=72, with_images=True)
@@ -72,8 +73,11 @@ def test_cpp_entry_points_match_oracle(host_bin, oracle, tmp_path, mode):
     if mode == "closest":
         want = oracle.color(X, Y, Z, s, M, sc.campos, sc.images, 0, want)
         assert "LOG - CR: starting color reconstruction (closest color)." in r.stdout
-    if mode == "average_unseen":
+    if mode in ("average_unseen", "closure"):
         want = oracle.color(X, Y, Z, s, M, sc.campos, sc.images, 1, want)
         want = oracle.handle_unseen(st, want)
+    if mode == "closure":
+        want = oracle.closure(X, Y, Z, want)
+        assert "LOG - PP: starting dilution." in r.stdout
     assert np.array_equal(seen, (st.reshape(-1) & 2) == 2)
     assert np.array_equal(rgba, want)
