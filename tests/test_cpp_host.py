@@ -81,3 +81,36 @@ def test_cpp_entry_points_match_oracle(host_bin, oracle, tmp_path, mode):
         assert "LOG - PP: starting dilution." in r.stdout
     assert np.array_equal(seen, (st.reshape(-1) & 2) == 2)
     assert np.array_equal(rgba, want)
+
+
+@pytest.mark.gpu
+def test_bench6_table(host_bin, oracle, tmp_path):
+    """The reference's -c=6 benchmark sequence (src/main.cpp:306-440) through the C++
+    layer: eight runs, reference table layout, occupancy equal to the oracle's."""
+    exe = os.path.join(ROOT, "tools", "cpp", "arvx_bench6")
+    V, W, H = 8, 640, 480
+    sc = scenes.syn.box_scene((100, 100, 50), V, with_images=True)
+    # the reference's box sits in a 0.28 m cube (100 x 0.0028): scale the scene to it
+    scale = 0.28 / 0.512
+    Rt = sc.Rt.copy()
+    Rt[:, :, 3] *= np.float32(scale)
+    scene = str(tmp_path / "scene.bin")
+    write_scene(scene, 1, 1, 1, 1.0, sc.K, Rt, sc.masks, sc.images, np.ones(1, np.uint8))
+    r = subprocess.run([exe, scene], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout[-2000:]
+    assert "Benchmark (all times in milliseconds)" in r.stdout
+    rows = [ln for ln in r.stdout.splitlines() if "coloring\t|" in ln]
+    assert len(rows) == 8 and rows[3].startswith("Large, V1, avg. coloring") and "100x100x50" in rows[3]
+    occ = [int(ln.split()[1]) for ln in r.stdout.splitlines() if ln.startswith("occupied ")]
+    M = oracle.compose(sc.K, Rt)
+    for (dims, s, ver), got in zip([((10, 10, 5), 0.028, 1), ((50, 50, 25), 0.0056, 1),
+                                    ((50, 50, 25), 0.0056, 1), ((100, 100, 50), 0.0028, 1),
+                                    ((10, 10, 5), 0.028, 2), ((50, 50, 25), 0.0056, 2),
+                                    ((50, 50, 25), 0.0056, 2), ((100, 100, 50), 0.0028, 2)], occ):
+        X, Y, Z = dims
+        st = (oracle.carve if ver == 1 else oracle.fast_carve)(X, Y, Z, np.float32(s), M, sc.masks)
+        model = oracle.color(X, Y, Z, np.float32(s), M, Rt[:, :, 3], sc.images, 1,
+                             oracle.model_from_state(st))
+        closed = oracle.closure(X, Y, Z, oracle.handle_unseen(st, model))
+        assert got == int((closed[:, 3] != 0).sum()), (dims, ver)
+    print(r.stdout[r.stdout.index("Benchmark (all"):])
