@@ -178,6 +178,27 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(const CarveParams p) {
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
+    const bool cull = !(p.flags & 1u);
+    const int ct =
+        cull ? tx + p.coarseX * ((ty >> p.cyShift) + p.coarseY * (tz >> p.czShift)) : 0;
+    const bool coarse_carved = cull && p.coarseCarved[ct];  // workgroup-uniform (scalar load)
+    if (kAligned4 && coarse_carved && (p.X & 15) == 0 && (tx + 1) * kTileX <= p.X) {
+        // Pure fill of a 64x8x8 tile that the pre-pass decided: every voxel carved and
+        // seen.  One 16-byte store per thread, 4 lanes per 64-byte row, instead of the
+        // per-sub-tile layout's four dword stores per lane.
+        const int yy = ty * kTileY + ((threadIdx.x >> 2) & 7);
+        const int zz = tz * kTileZ + (threadIdx.x >> 5);
+        if (yy < p.Y && zz < p.Z) {
+            uint8_t *dst = p.state + ((size_t)zz * p.Y + yy) * p.X + tx * kTileX +
+                           16 * (threadIdx.x & 3);
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(kDone4, kDone4, kDone4, kDone4);
+        }
+        if ((p.flags & 2u) && lane == 0) {
+            atomicAdd(&p.stats[0], 1ull);
+            atomicAdd(&p.stats[1], 1ull);
+        }
+        return;
+    }
     const int sx0 = tx * kTileX + wave * kSubX;
     if (sx0 >= p.X) return;  // wave-uniform
     const int sy0 = ty * kTileY;
@@ -203,10 +224,7 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(const CarveParams p) {
     bool loaded = false, all_carved = false, all_done = false;
     const size_t row = (size_t)p.X;
     const size_t plane = (size_t)p.X * p.Y;
-    const bool cull = !(p.flags & 1u);
-    const int ct =
-        cull ? tx + p.coarseX * ((ty >> p.cyShift) + p.coarseY * (tz >> p.czShift)) : 0;
-    if (cull && p.coarseCarved[ct]) {  // wave-uniform (scalar load)
+    if (coarse_carved) {
         all_carved = true;
         if ((p.flags & 2u) && lane == 0) {
             atomicAdd(&p.stats[0], 1ull);

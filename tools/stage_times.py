@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Wall-clock of every stage of the path through the C-ABI, host buffers in and out
+(i.e. PCIe-inclusive): set_views, carve, state download, fast carve, colour vote,
+closure, export.  Usage: python tools/stage_times.py [grid ...]   (GPU required)"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from ar_voxel_project_amd import capi, synthetic  # noqa: E402
+
+
+def timed(fn, reps=3):
+    best = 1e9
+    out = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        best = min(best, time.perf_counter() - t0)
+    return best * 1e3, out
+
+
+def main():
+    grids = [int(a) for a in sys.argv[1:] if a.isdigit()] or [256, 512]
+    V = 36
+    for N in grids:
+        sc = synthetic.sphere_scene(N, V, with_images=True)
+        ctx = capi.Context(N, N, N, sc.voxel_size)
+        r = {"grid": N, "views": V}
+        r["set_views_ms"], _ = timed(lambda: (ctx.set_views(sc.M, sc.masks, campos=sc.campos),
+                                              ctx.synchronize()))
+        r["set_images_ms"], _ = timed(lambda: ctx.set_images(sc.images), 1)
+
+        def carve():
+            ctx.reset()
+            ctx.carve()
+            ctx.synchronize()
+        r["carve_ms"], _ = timed(carve, 5)
+        r["state_download_ms"], st = timed(ctx.download_state, 2)
+        r["occupied_fraction"] = float((st & 1).mean())
+
+        def fast():
+            ctx.reset()
+            ctx.fast_carve()
+        r["fast_carve_ms"], _ = timed(fast, 2)
+        carve()
+
+        def color():
+            ctx.color(capi.COLOR_AVERAGE)
+        r["color_avg_ms"], _ = timed(color, 3)
+        idx, _ = ctx.surface()
+        r["coloured_voxels"] = int(len(idx))
+        r["closure_ms"], (cidx, _) = timed(lambda: ctx.closure(3, True), 1)
+        r["closure_filled"] = int(len(cidx))
+        if N <= 512:
+            r["export_model_ms"], _ = timed(lambda: ctx.export_model(True), 1)
+        ctx.close()
+        print(json.dumps(r))
+
+
+if __name__ == "__main__":
+    main()
