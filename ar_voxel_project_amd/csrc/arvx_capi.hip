@@ -766,7 +766,12 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     cp.col_has = ctx->color_ready ? ctx->d_surf_has : nullptr;
     cp.ncol = ctx->color_ready ? ctx->surf_count : 0;
     const int nblk = (int)((ctx->nvox + arvx::kSurfChunk - 1) / arvx::kSurfChunk);
-    const size_t need = (size_t)nblk * sizeof(int) + (size_t)(nblk + 1) * sizeof(long long) + 64;
+    cp.tX = (cp.X + 7) / 8;
+    cp.tY = (cp.Y + 7) / 8;
+    cp.tZ = (cp.Z + 7) / 8;
+    const size_t ntile = (size_t)cp.tX * cp.tY * cp.tZ;
+    const size_t need = (size_t)nblk * sizeof(int) + (size_t)(nblk + 1) * sizeof(long long) + 64 +
+                        ntile;
     if (ctx->scratch_bytes < need) {
         if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
         ctx->d_scratch = nullptr;
@@ -776,6 +781,11 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     }
     long long *d_off = (long long *)ctx->d_scratch;
     int *d_cnt = (int *)(d_off + nblk + 1);
+    uint8_t *d_tiles = (uint8_t *)(d_cnt + nblk + 8);
+    cp.tile_any = d_tiles;
+    hipLaunchKernelGGL(arvx::closure_tiles_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0,
+                       ctx->stream, cp, d_tiles);
+    ARVX_HIP(hipGetLastError());
     hipLaunchKernelGGL(arvx::closure_count_kernel, dim3(nblk), dim3(256), 0, ctx->stream, cp,
                        d_cnt);
     ARVX_HIP(hipGetLastError());

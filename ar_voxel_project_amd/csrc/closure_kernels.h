@@ -27,6 +27,8 @@ struct ClosureParams {
     const float *col_rgb;
     const uint8_t *col_has;
     long long ncol;
+    const uint8_t *tile_any;  // per 8x8x8 tile: holds an occupied voxel (skip test)
+    int tX, tY, tZ;
 };
 
 // bit2 = painted with UNSEEN_COLOR by the host Model (include/arvx/model.hpp)
@@ -83,10 +85,43 @@ __device__ inline int cl_gather(const ClosureParams &p, size_t i, float4 &sum) {
     return count;
 }
 
+// can the box of radius r around voxel i contain an occupied voxel at all?
+// (most of the grid is far from the hull: this keeps the 27-neighbour scan off it)
+__device__ __forceinline__ bool cl_near_occupied(const ClosureParams &p, size_t i) {
+    const int x = (int)(i % p.X);
+    const size_t t = i / p.X;
+    const int y = (int)(t % p.Y), z = (int)(t / p.Y);
+    const int x0 = max(x - p.radius, 0) >> 3, x1 = min(x + p.radius, p.X - 1) >> 3;
+    const int y0 = max(y - p.radius, 0) >> 3, y1 = min(y + p.radius, p.Y - 1) >> 3;
+    const int z0 = max(z - p.radius, 0) >> 3, z1 = min(z + p.radius, p.Z - 1) >> 3;
+    for (int c = z0; c <= z1; ++c)
+        for (int b = y0; b <= y1; ++b)
+            for (int a = x0; a <= x1; ++a)
+                if (p.tile_any[a + p.tX * (b + p.tY * c)]) return true;
+    return false;
+}
+
 __device__ __forceinline__ bool cl_fills(const ClosureParams &p, size_t i, size_t n) {
-    if (i >= n || cl_occupied(p, p.state[i])) return false;
+    if (i >= n || cl_occupied(p, p.state[i]) || !cl_near_occupied(p, i)) return false;
     float4 dummy;
     return cl_gather<false>(p, i, dummy) > 0;
+}
+
+// one wave per 8x8x8 tile: lane = one x-row of 8 voxels
+__global__ __launch_bounds__(256) void closure_tiles_kernel(const ClosureParams p,
+                                                            uint8_t *__restrict__ tile_any) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= p.tX * p.tY * p.tZ) return;
+    const int lane = threadIdx.x & 63;
+    const int a = t % p.tX, b = (t / p.tX) % p.tY, c = t / (p.tX * p.tY);
+    const int y = b * 8 + (lane & 7), z = c * 8 + (lane >> 3);
+    bool any = false;
+    if (y < p.Y && z < p.Z) {
+        const uint8_t *row = p.state + ((size_t)z * p.Y + y) * p.X;
+        for (int x = a * 8; x < min(a * 8 + 8, p.X); ++x) any = any || cl_occupied(p, row[x]);
+    }
+    const unsigned long long m = __ballot(any);
+    if (lane == 0) tile_any[t] = m ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void closure_count_kernel(const ClosureParams p,
@@ -115,7 +150,8 @@ __global__ __launch_bounds__(256) void closure_write_kernel(const ClosureParams 
         const size_t i = base + (size_t)it * 256 + threadIdx.x;
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
         int count = 0;
-        if (i < n && !cl_occupied(p, p.state[i])) count = cl_gather<true>(p, i, sum);
+        if (i < n && !cl_occupied(p, p.state[i]) && cl_near_occupied(p, i))
+            count = cl_gather<true>(p, i, sum);
         const bool f = count > 0;
         const unsigned long long b = __ballot(f);
         if (lane == 0) wcnt[wave] = __popcll(b);

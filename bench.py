@@ -116,13 +116,13 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def run_config(base, V, steps, warmup, collective):
+    def run_config(base, V, steps, warmup, collective, no_cull=False):
         X, Y, Z = sharding.grid_for(world, base)
         sc = synthetic.sphere_scene(max(X, Y, Z), V)
         sc.X, sc.Y, sc.Z = X, Y, Z
         zlo, zhi = sharding.slab_of(Z, world, rank)
         nvox_global = X * Y * Z
-        flags = capi.CARVE_NO_CULL if args.no_cull else 0
+        flags = capi.CARVE_NO_CULL if (args.no_cull or no_cull) else 0
         # allreduce: striped (load-balanced) slabs; allgather needs contiguous ones
         layout = "striped" if (world > 1 and collective != "allgather") else "slab"
         if layout == "striped":
@@ -221,13 +221,16 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "physical_GBps": (traffic / (r["kern_ms"] * 1e-3) / 1e9) if traffic else None,
                 "kernel": "carve_fused_kernel", "kernel_ms": r["kern_ms"],
                 "algorithmic_bytes": alg_bytes,
                 "note": "algorithmic = N*V + V*W*H read bytes of the per-view streaming "
                         "formulation (SURVEY 8d); the fused kernel reads the state once and "
                         "decides most 16x8x8 sub-tiles from a pixel-rectangle test, so this "
                         "is an EFFECTIVE rate and may exceed the physical peak; `traffic` "
-                        "is the rocprofv3 PMC HBM byte count per launch (profiles/)"}
+                        "is the rocprofv3 PMC FETCH_SIZE+WRITE_SIZE byte count per launch (profiles/"
+                        "traffic.json), `physical_GBps` = traffic / kernel time: the kernel is "
+                        "bound by VALU issue and L2/Infinity-Cache latency, not by HBM"}
 
     out = {
         "metric": "Mvoxel-views/s (voxels x views / s) + carve wall-time, 512^3 grid x 36 views",
@@ -246,17 +249,36 @@ def main():
 
     if rank == 0 and world == 1 and args.extra_grid and args.extra_grid != args.grid:
         try:
-            e = run_config(args.extra_grid, args.views, max(3, args.steps // 4), 1, "none")
+            k = max(3, args.steps // 4)
+            e = run_config(args.extra_grid, args.views, k, 1, "none")
             evv = e["nvox"] * e["V"]
             eb = evv + e["V"] * e["sc"].W * e["sc"].H
             out["extra"] = {
                 "workload": f"{e['X']}^3 x {e['V']} views (north-star target config)",
-                "value": evv / (e["dt"] / max(3, args.steps // 4)) / 1e6,
+                "value": evv / (e["dt"] / k) / 1e6,
                 "unit": "Mvoxel-views/s", "carve_kernel_ms": e["kern_ms"],
                 "roofline_frac": eb / (e["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "occupied_fraction": e["occ"]}
         except Exception as ex:  # e.g. not enough memory on a shared box
             out["extra"] = {"error": str(ex)}
+
+    if rank == 0 and world == 1 and not args.no_cull:
+        # Ablation in the same run: the same kernel with the rectangle tests off, i.e.
+        # every voxel projected exactly in every view until it is carved (wave ballot
+        # early-out only).  This is the closest thing to the per-view streaming
+        # formulation the algorithmic byte count describes.
+        try:
+            k = max(3, args.steps // 4)
+            b = run_config(args.grid, args.views, k, 1, "none", no_cull=True)
+            bb = b["nvox"] * b["V"] + b["V"] * b["sc"].W * b["sc"].H
+            out["ablation_no_cull"] = {
+                "value": b["nvox"] * b["V"] / (b["dt"] / k) / 1e6, "unit": "Mvoxel-views/s",
+                "carve_kernel_ms": b["kern_ms"],
+                "roofline": {"bound": "hbm", "achieved": bb / (b["kern_ms"] * 1e-3) / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": bb / (b["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        except Exception as ex:
+            out["ablation_no_cull"] = {"error": str(ex)}
 
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(r["sc"], r["X"], r["Y"], r["Z"])
