@@ -1,0 +1,45 @@
+"""Sanitizers run on the CPU builds only (GPU ASan is unavailable on this pool):
+the oracle under ASan+UBSan, and the C++ host Model logic under ASan+UBSan."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(cmd, **kw):
+    return subprocess.run(cmd, capture_output=True, text=True, **kw)
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc missing")
+def test_oracle_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "asan_check")
+    r = run(["gcc", "-O1", "-g", "-std=c11", "-fsanitize=address,undefined",
+             "-fno-sanitize-recover=all", "-ffp-contract=off", "-fopenmp",
+             "-I" + os.path.join(ROOT, "oracle"), "-o", exe,
+             os.path.join(ROOT, "oracle", "asan_check.c"),
+             os.path.join(ROOT, "oracle", "arvx_oracle.c"), "-lm"])
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", OMP_NUM_THREADS="2")
+    r = run([exe], env=env)
+    assert r.returncode == 0 and "asan_check ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ missing")
+def test_host_model_under_asan_ubsan(tmp_path):
+    """`test_host model` touches only host code; libarvx.so is linked but not called."""
+    from ar_voxel_project_amd import build, capi
+    if not os.path.exists(capi.LIB_PATH):
+        build.build_library()
+    exe = str(tmp_path / "test_host_asan")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    r = run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined",
+             "-fno-sanitize-recover=all", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+             os.path.join(ROOT, "tests", "cpp", "test_host.cpp"), "-L" + libdir, "-larvx",
+             "-Wl,-rpath," + libdir])
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")  # the HIP runtime keeps globals
+    r = run([exe, "model"], env=env)
+    assert r.returncode == 0 and "model ok" in r.stdout, r.stdout + r.stderr
