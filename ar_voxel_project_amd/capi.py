@@ -13,7 +13,8 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libarvx.so")
+# ARVX_LIB_PATH: A/B another build of the library on the same box (tools/ab_compare.sh)
+LIB_PATH = os.environ.get("ARVX_LIB_PATH") or os.path.join(_HERE, "lib", "libarvx.so")
 
 OCC = 1
 SEEN = 2
@@ -34,7 +35,7 @@ SYMBOLS = [
     "arvx_color", "arvx_surface_count", "arvx_surface_download",
     "arvx_surface_depth_download",
     "arvx_colors_upload", "arvx_closure", "arvx_closure_count", "arvx_closure_download",
-    "arvx_export_model", "arvx_get_stats",
+    "arvx_export_model", "arvx_get_stats", "arvx_selftest_divide",
 ]
 
 
@@ -115,7 +116,12 @@ def load_library() -> C.CDLL:
     lib.arvx_closure_download.argtypes = [p, C.POINTER(C.c_int64), f32p]
     lib.arvx_export_model.argtypes = [p, f32p, C.c_int]
     lib.arvx_get_stats.argtypes = [p, C.POINTER(Stats)]
+    ab_build = bool(os.environ.get("ARVX_LIB_PATH"))  # an older build may lack newer symbols
+    if hasattr(lib, "arvx_selftest_divide") or not ab_build:
+        lib.arvx_selftest_divide.argtypes = [p, C.c_int64, f32p, f32p, f32p, f32p]
     for name in SYMBOLS:
+        if ab_build and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)
         if name not in ("arvx_last_error",):
             fn.restype = C.c_int
@@ -330,6 +336,12 @@ class Context:
     def export_model(self, apply_unseen: bool = False) -> np.ndarray:
         out = np.empty((self.nvox, 4), np.float32)
         _check(self._lib.arvx_export_model(self._h, _fp(out), int(apply_unseen)))
+        return out
+
+    def selftest_divide(self, a0, a1, b) -> np.ndarray:
+        a0, a1, b = _f32(a0).reshape(-1), _f32(a1).reshape(-1), _f32(b).reshape(-1)
+        out = np.empty((len(b), 4), np.float32)
+        _check(self._lib.arvx_selftest_divide(self._h, len(b), _fp(a0), _fp(a1), _fp(b), _fp(out)))
         return out
 
     def stats(self) -> dict:

@@ -712,6 +712,30 @@ int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen) {
     return rc;
 }
 
+int arvx_selftest_divide(arvx_ctx *ctx, int64_t n, const float *a0, const float *a1,
+                         const float *b, float *out) {
+    ARVX_CHECK_CTX(ctx);
+    if (n < 1 || !a0 || !a1 || !b || !out) return fail(ARVX_ERR_INVALID, "bad argument");
+    float *d = nullptr;
+    ARVX_HIP(hipMalloc(&d, (size_t)n * 7 * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(d, a0, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d + n, a1, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d + 2 * n, b, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(arvx::selftest_divide_kernel, dim3((unsigned)((n + 255) / 256)),
+                           dim3(256), 0, ctx->stream, d, d + n, d + 2 * n, (size_t)n, d + 3 * n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(out, d + 3 * n, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return arvx::fail_hip(e, "selftest_divide", __FILE__, __LINE__);
+    return ARVX_OK;
+}
+
 // ---- closure -------------------------------------------------------------------------
 
 int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const float *rgb) {

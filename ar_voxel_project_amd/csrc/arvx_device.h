@@ -21,7 +21,7 @@ constexpr int kCoarseX = 64;  // pre-pass tile: 64 x (8 << cyShift) x (8 << czSh
 constexpr uint32_t kDone4 = 0x02020202u;            // 4 voxels carved+seen
 constexpr int kMaxImageDim = 16384;
 
-enum : int { kClsOut = 0, kClsFg = 1, kClsCarved = 2, kClsMixed = 3 };
+enum : int { kClsOut = 0, kClsFg = 1, kClsCarved = 2, kClsMixed = 3, kFastDiv = 4 };
 
 struct CarveParams {
     uint8_t *state;         // slab state plane
@@ -52,18 +52,55 @@ __device__ __forceinline__ int global_z(const CarveParams &p, int lz) {
     return p.zoff + (((lz >> 3) * p.zstride + p.zphase) << 3) + (lz & 7);
 }
 
-// Rounded pixel of one projected voxel.  a0,a1,a2 are the fp32 row results.
-// Returns false (outside) for non-finite quotients as x86's cvttss2si does.
+// Pixel of a projected voxel from the two quotients u = a0/a2, v = a1/a2.
+// Reference: px = (int)std::round(u), inside iff 0 <= px < W (same for v,H),
+// src/VoxelCarving.cpp:44-45.  Restated without computing round() first:
+//   round(u) >= 0    <=>  u > -0.5        (round(-0.5) = -1, round(-0.4999) = -0)
+//   round(u) <= W-1  <=>  u < W - 0.5     (round(W-0.5) = W)
+// both bounds are exact floats for W <= 16384; NaN/Inf fail them, which is the
+// "outside" x86's cvttss2si gives the reference there.  For u in that range
+// round-half-away equals rint (half-to-even) except at an exact tie k+0.5, where
+// rint may return k: u - rint(u) is exact, so the tie is detected and fixed.
+__device__ __forceinline__ bool pixel_from_quotients(float u, float v, int W, float wlim,
+                                                     float hlim, int &pix) {
+    const bool in = (u > -0.5f) && (u < wlim) && (v > -0.5f) && (v < hlim);
+    float ru = rintf(u), rv = rintf(v);
+    ru += (u - ru == 0.5f) ? 1.f : 0.f;
+    rv += (v - rv == 0.5f) ? 1.f : 0.f;
+    pix = in ? (int)rv * W + (int)ru : 0;  // 0 keeps the unconditional table read in bounds
+    return in;
+}
+
+// a0/a2 and a1/a2, correctly rounded, with ONE reciprocal: the unscaled core of
+// the gfx9 fp32 division expansion (rcp, one Newton step, quotient, two residual
+// corrections).  Bit-identical to the IEEE quotient whenever the hardware's
+// v_div_scale would not rescale; callers use it only where |a2| is known to lie in
+// [2^-60, 2^60] and |a0|,|a1| <= 2^60 (sub-tile bounds from the rectangle test).
+// Then the remaining rescale cases are numerators below 2^-103 (|quotient| < 2^-43,
+// pixel 0 either way) and ratios above 2^95 (outside the image either way).
+// Checked against `/` on random and adversarial operands in tests/test_carve_gpu.py.
+__device__ __forceinline__ void divide2_shared_rcp(float a0, float a1, float b, float &u,
+                                                   float &v) {
+    float r = __builtin_amdgcn_rcpf(b);
+    const float nb = -b;
+    const float e = fmaf(nb, r, 1.0f);
+    r = fmaf(e, r, r);
+    float q = a0 * r;
+    float t = fmaf(nb, q, a0);
+    q = fmaf(t, r, q);
+    t = fmaf(nb, q, a0);
+    u = fmaf(t, r, q);
+    q = a1 * r;
+    t = fmaf(nb, q, a1);
+    q = fmaf(t, r, q);
+    t = fmaf(nb, q, a1);
+    v = fmaf(t, r, q);
+}
+
+// Rounded pixel of one projected voxel (IEEE divides); a0,a1,a2 = fp32 row results.
 __device__ __forceinline__ bool pixel_of(float a0, float a1, float a2, int W, int H,
                                          int &pix) {
-    float u = a0 / a2;
-    float v = a1 / a2;
-    float ru = roundf(u);
-    float rv = roundf(v);
-    // W,H <= 16384 are exact in fp32; ru,rv are integral, NaN fails every test.
-    bool in = (ru >= 0.f) && (ru < (float)W) && (rv >= 0.f) && (rv < (float)H);
-    pix = in ? (int)rv * W + (int)ru : 0;
-    return in;
+    return pixel_from_quotients(a0 / a2, a1 / a2, W, (float)W - 0.5f, (float)H - 0.5f, pix);
 }
 
 __device__ __forceinline__ float row_sum(double p01, double p2, double p3) {

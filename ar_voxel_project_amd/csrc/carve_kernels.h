@@ -103,9 +103,15 @@ __device__ inline int classify_box(const float *__restrict__ M, const BoxW b, in
     const float eps0 = E[0] * k19, eps1 = E[1] * k19, eps2 = E[2] * k19;
     const float cabs = (cmin > 0.f) ? cmin : ((cmax < 0.f) ? -cmax : 0.f);
     if (!(cabs > 8.f * eps2 + 1e-30f)) return kClsMixed;  // the denominator may vanish
+    // every voxel of the box then has |a2| >= cabs - eps2 > 0; kFastDiv: all row values
+    // lie in the range where divide2_shared_rcp equals the IEEE quotient (or the
+    // difference cannot matter): 2^-59 <= |a2|, and |a_r| <= 2^59
+    const int fast = (cabs >= 1.8e-18f && E[0] <= 5.7e17f && E[1] <= 5.7e17f && E[2] <= 5.7e17f)
+                         ? kFastDiv
+                         : 0;
     const float Ua = fmaxf(fabsf(umin), fabsf(umax));
     const float Va = fmaxf(fabsf(vmin), fabsf(vmax));
-    if (!(Ua < 1.0e6f && Va < 1.0e6f)) return kClsMixed;  // also NaN
+    if (!(Ua < 1.0e6f && Va < 1.0e6f)) return kClsMixed | fast;  // also NaN
     const float rden = 1.0001f / (cabs - eps2);
     const float mu = (eps0 + Ua * eps2) * rden + Ua * k20 + k12;
     const float mv = (eps1 + Va * eps2) * rden + Va * k20 + k12;
@@ -114,13 +120,13 @@ __device__ inline int classify_box(const float *__restrict__ M, const BoxW b, in
     const int pylo = (int)ceilf(vmin - mv - 0.5f);
     const int pyhi = (int)floorf(vmax + mv + 0.5f);
     if (pxhi < 0 || pxlo >= W || pyhi < 0 || pylo >= H) return kClsOut;
-    if (pxlo < 0 || pxhi >= W || pylo < 0 || pyhi >= H) return kClsMixed;
+    if (pxlo < 0 || pxhi >= W || pylo < 0 || pyhi >= H) return kClsMixed | fast;
     const int S = W + 1;
     const int cnt = sat[(pyhi + 1) * S + pxhi + 1] - sat[pylo * S + pxhi + 1] -
                     sat[(pyhi + 1) * S + pxlo] + sat[pylo * S + pxlo];
     if (cnt == 0) return kClsCarved;
     const int area = (pxhi - pxlo + 1) * (pyhi - pylo + 1);
-    return (cnt == area) ? kClsFg : kClsMixed;
+    return (cnt == area) ? kClsFg : (kClsMixed | fast);
 }
 
 // Pre-pass over coarse tiles of 64 x 32 x 32 voxels (64 sub-tiles each; striped
@@ -149,7 +155,8 @@ __global__ __launch_bounds__(256) void carve_coarse_kernel(const CarveParams p) 
         const int myv = vc + lane;
         int cls = kClsOut;
         if (myv < p.v1)
-            cls = classify_box(p.M + 12 * myv, box, p.W, p.H, p.sat + (size_t)myv * p.satStride);
+            cls = classify_box(p.M + 12 * myv, box, p.W, p.H, p.sat + (size_t)myv * p.satStride) &
+                  3;
         const unsigned long long carved = __ballot(cls == kClsCarved);
         const unsigned long long mixed = __ballot(cls == kClsMixed);
         const unsigned long long fg = __ballot(cls == kClsFg);
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(256) void carve_coarse_kernel(const CarveParams p) 
 }
 
 template <bool kAligned4>
-__global__ __launch_bounds__(256) void carve_fused_kernel(const CarveParams p) {
+__global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p) {
     // Blocks b, b+8, b+16.. share an XCD (and its L2).  A row of tiles along x (one
     // 8x8 bundle of voxel rows) stays on one XCD, so neighbouring 64-byte runs meet
     // in one L2; rows are dealt to the 8 XCDs cyclically, which spreads the
@@ -250,6 +257,8 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(const CarveParams p) {
                                        p.sat + (size_t)myv * p.satStride);
             }
         }
+        const unsigned long long fastdiv = __ballot((cls & kFastDiv) != 0);
+        cls &= 3;
         const unsigned long long carved = __ballot(cls == kClsCarved);
         unsigned long long mixed = __ballot(cls == kClsMixed);
         const unsigned long long infg = __ballot(cls == kClsFg);
@@ -310,6 +319,8 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(const CarveParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) p01[r][j] = p0 + m1 * dwx[j];
             }
+            const bool fast = (fastdiv >> b) & 1ull;  // wave-uniform
+            const float wlim = (float)p.W - 0.5f, hlim = (float)p.H - 0.5f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (!__any(st[k] != kDone4)) continue;  // these 256 voxels are finished
@@ -320,10 +331,17 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(const CarveParams p) {
                     const float a0 = row_sum(p01[0][j], p20, p3[0]);
                     const float a1 = row_sum(p01[1][j], p21, p3[1]);
                     const float a2 = row_sum(p01[2][j], p22, p3[2]);
+                    float u, v;
+                    if (fast) {
+                        divide2_shared_rcp(a0, a1, a2, u, v);
+                    } else {
+                        u = a0 / a2;
+                        v = a1 / a2;
+                    }
                     int pix;
-                    const bool in = pixel_of(a0, a1, a2, p.W, p.H, pix);
-                    const uint32_t word = in ? bgv[pix >> 5] : 0u;
-                    const uint32_t isbg = (word >> (pix & 31)) & 1u;
+                    const bool in = pixel_from_quotients(u, v, p.W, wlim, hlim, pix);
+                    const uint32_t word = bgv[(unsigned)pix >> 5];  // pix = 0 when outside
+                    const uint32_t isbg = in ? ((word >> (pix & 31)) & 1u) : 0u;
                     const uint32_t seen = in ? (2u << (8 * j)) : 0u;
                     w = (w | seen) & ~(isbg << (8 * j));
                 }
@@ -357,6 +375,21 @@ __global__ __launch_bounds__(256) void carve_fused_kernel(const CarveParams p) {
             }
         }
     }
+}
+
+// self-test support: both division forms on caller-supplied operands
+__global__ __launch_bounds__(256) void selftest_divide_kernel(const float *__restrict__ a0,
+                                                              const float *__restrict__ a1,
+                                                              const float *__restrict__ b, size_t n,
+                                                              float *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float u, v;
+    divide2_shared_rcp(a0[i], a1[i], b[i], u, v);
+    out[4 * i] = u;
+    out[4 * i + 1] = v;
+    out[4 * i + 2] = a0[i] / b[i];
+    out[4 * i + 3] = a1[i] / b[i];
 }
 
 // ---- view pre-processing ---------------------------------------------------

@@ -193,6 +193,12 @@ int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen);
 
 int arvx_get_stats(arvx_ctx *ctx, arvx_stats *out);
 
+/* Self-test hook: evaluates the kernel's shared-reciprocal division and the IEEE
+ * `/` on n host operand triples; out gets 4 floats per triple:
+ * (a0/b fast, a1/b fast, a0/b IEEE, a1/b IEEE). */
+int arvx_selftest_divide(arvx_ctx *ctx, int64_t n, const float *a0, const float *a1,
+                         const float *b, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -322,3 +322,60 @@ def test_row_stride_padding(arvx, oracle):
         assert_same(ctx.download_state(), want, "padded rows")
         assert lib.arvx_set_views(ctx._h, V, Mf.ctypes.data_as(C.POINTER(C.c_float)), None, ptrs,
                                   W, H, Cn, W * Cn - 1) == 1  # stride too small
+
+
+def test_shared_reciprocal_division_is_ieee(arvx):
+    """divide2_shared_rcp (one v_rcp for both quotients) must equal the IEEE `/` bit for
+    bit wherever the kernel uses it (|b| in [2^-59, 2^59], |a| <= 2^59) unless the
+    quotient is so small or so large that the pixel decision cannot depend on it."""
+    rng = np.random.default_rng(0)
+    n = 1 << 21
+    parts = []
+    # projection-like magnitudes
+    parts.append((rng.normal(scale=300, size=n), rng.normal(scale=300, size=n),
+                  rng.uniform(0.05, 4.0, size=n) * rng.choice([-1, 1], size=n)))
+    # whole exponent range the guard admits
+    ea, eb = rng.uniform(-59, 59, size=n), rng.uniform(-59, 59, size=n)
+    parts.append((np.ldexp(rng.uniform(1, 2, n), ea.astype(int)) * rng.choice([-1, 1], n),
+                  np.ldexp(rng.uniform(1, 2, n), rng.uniform(-140, 59, n).astype(int)),
+                  np.ldexp(rng.uniform(1, 2, n), eb.astype(int)) * rng.choice([-1, 1], n)))
+    # quotients engineered to sit on and next to rounding ties k + 0.5
+    b = rng.uniform(0.1, 3.0, size=n).astype(np.float32)
+    k = rng.integers(0, 700, size=n).astype(np.float32) + 0.5
+    a = (k * b).astype(np.float32)
+    a = np.nextafter(a, np.float32(np.inf) * rng.choice([-1, 1], n).astype(np.float32))
+    parts.append((a, (k * b).astype(np.float32), b))
+    # zeros and tiny numerators
+    parts.append((np.zeros(n), np.ldexp(rng.uniform(1, 2, n), -140), rng.uniform(0.5, 2, n)))
+    a0 = np.concatenate([p[0] for p in parts]).astype(np.float32)
+    a1 = np.concatenate([p[1] for p in parts]).astype(np.float32)
+    bb = np.concatenate([p[2] for p in parts]).astype(np.float32)
+    with arvx.Context(4, 4, 4, 0.1) as ctx:
+        out = ctx.selftest_divide(a0, a1, bb)
+    with np.errstate(all="ignore"):
+        ref0, ref1 = (a0 / bb).astype(np.float32), (a1 / bb).astype(np.float32)
+    assert np.array_equal(out[:, 2].view(np.uint32), ref0.view(np.uint32)), "GPU `/` is IEEE"
+    assert np.array_equal(out[:, 3].view(np.uint32), ref1.view(np.uint32))
+    for fast, ref in ((out[:, 0], ref0), (out[:, 1], ref1)):
+        same = fast.view(np.uint32) == ref.view(np.uint32)
+        tiny = (np.abs(ref) < 2.0 ** -40) & (np.abs(fast) < 2.0 ** -40)
+        huge = (np.abs(ref) > 2.0 ** 90) & (np.abs(fast) > 2.0 ** 90)
+        harmless = tiny | huge
+        bad = ~(same | harmless)
+        assert not bad.any(), (f"{bad.sum()} quotients differ, e.g. "
+                               f"{fast[bad][:3]} vs {ref[bad][:3]}")
+        assert same.mean() > 0.7
+
+
+def test_cull_matches_no_cull_bench_scene_512(arvx):
+    """The bench workload itself (512^3 x 36, sphere): culled == brute force, every voxel."""
+    sc = scenes.syn.sphere_scene(512, 36)
+    with arvx.Context(512, 512, 512, sc.voxel_size) as ctx:
+        ctx.set_views(sc.M, sc.masks)
+        ctx.carve(0)
+        a = ctx.download_state()
+        ctx.reset()
+        ctx.carve(arvx.CARVE_NO_CULL)
+        b = ctx.download_state()
+    assert_same(a, b, "512^3 x 36 sphere")
+    assert abs(float((a & 1).mean()) - 0.1806) < 0.001
