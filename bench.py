@@ -63,10 +63,22 @@ def cpu_baseline(sc, X, Y, Z, budget_s=12.0):
            "published_reference": {"value": 0.71, "unit": "Mvoxel-views/s",
                                    "note": "Report.pdf Fig. 4, i7 @ 4.5 GHz, real reference "
                                            "incl. cv::Mat overhead (BASELINE.md)"}}
-    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    out["cpu_model"] = model
     mt_planes = int(min(Z, max(8, planes * min(ncores, 32) // 4)))
     t0 = time.perf_counter()
-    pyoracle.carve(X, Y, mt_planes, sc.voxel_size, sc.M, sc.masks, threads=0)
+    pyoracle.carve(X, Y, mt_planes, sc.voxel_size, sc.M, sc.masks, threads=ncores)
     dmt = time.perf_counter() - t0
     out["all_cores"] = {"value": X * Y * mt_planes * sc.V / dmt / 1e6,
                         "unit": "Mvoxel-views/s", "cores": ncores, "kind": "port",

@@ -154,16 +154,21 @@ class Model {
         for (auto &b : s) b &= (uint8_t)(kOcc | kSeen);
         return s;
     }
-    // take the carve result back: occupancy and seen from the device plane
+    // take the carve result back: occupancy and seen from the device plane.  The
+    // device plane started from this model's bits, so it already holds them; a
+    // voxel that is still occupied keeps its UNSEEN paint bit, a carved one loses
+    // it and its explicit colour (set(x,y,z,(0,0,0,0)), src/VoxelCarving.cpp:52).
     void absorb_state(const uint8_t *dev_state) {
-        for (size_t i = 0; i < state_.size(); ++i) {
-            const uint8_t was = state_[i], now = dev_state[i];
-            if ((was & kOcc) && !(now & kOcc)) {
-                colors_.erase((int)i);  // carved: set(x,y,z,(0,0,0,0)), src/VoxelCarving.cpp:52
-                state_[i] = (uint8_t)(now & (kOcc | kSeen));
-            } else {
-                state_[i] = (uint8_t)((was & (kOcc | kUnseenPaint)) | (now & kSeen));
-            }
+        for (auto it = colors_.begin(); it != colors_.end();) {  // sparse: surface voxels only
+            const size_t i = (size_t)it->first;
+            if ((state_[i] & kOcc) && !(dev_state[i] & kOcc)) it = colors_.erase(it);
+            else ++it;
+        }
+        uint8_t *st = state_.data();
+        const size_t n = state_.size();
+        for (size_t i = 0; i < n; ++i) {  // branch-free, vectorises
+            const uint8_t now = (uint8_t)(dev_state[i] & (kOcc | kSeen));
+            st[i] = (uint8_t)(now | (st[i] & kUnseenPaint & (uint8_t)((now & kOcc) << 2)));
         }
     }
     void set_flat(int i, const Vec4f &v) {

@@ -379,3 +379,17 @@ def test_cull_matches_no_cull_bench_scene_512(arvx):
         b = ctx.download_state()
     assert_same(a, b, "512^3 x 36 sphere")
     assert abs(float((a & 1).mean()) - 0.1806) < 0.001
+
+
+def test_cull_matches_no_cull_target_config_1024(arvx):
+    """The north-star target configuration, 1024^3 x 36 views: culled == brute force."""
+    sc = scenes.syn.sphere_scene(1024, 36)
+    with arvx.Context(1024, 1024, 1024, sc.voxel_size) as ctx:
+        ctx.set_views(sc.M, sc.masks)
+        ctx.carve(0)
+        a = ctx.download_state()
+        ctx.reset()
+        ctx.carve(arvx.CARVE_NO_CULL)
+        b = ctx.download_state()
+    assert np.array_equal(a, b)
+    assert abs(float((a & 1).mean()) - 0.1806) < 0.001 and not np.any(a == 0)
