@@ -393,3 +393,19 @@ def test_cull_matches_no_cull_target_config_1024(arvx):
         b = ctx.download_state()
     assert np.array_equal(a, b)
     assert abs(float((a & 1).mean()) - 0.1806) < 0.001 and not np.any(a == 0)
+
+
+@pytest.mark.parametrize("which,N", [("box", 128), ("human", 96)])
+def test_dataset_silhouettes_plumbing(arvx, oracle, which, N):
+    """BASELINE config 0/1 shaped run on the reference data set's own (PIL-decoded)
+    masks with synthetic ring poses: plumbing, not a parity claim about the reference's
+    run.  Ragged real silhouettes with JPEG speckle: oracle == culled == brute force."""
+    from tests import golden_io
+    masks = golden_io.dataset_masks(which)
+    V = masks.shape[0]
+    sc = scenes.syn.sphere_scene(N, V)  # ring cameras + dataset intrinsics, 640x480
+    want = oracle.carve(N, N, N, sc.voxel_size, sc.M, masks)
+    for flags in (0, 1):
+        assert_same(run_gpu(arvx, N, N, N, sc.voxel_size, sc.M, masks, flags), want,
+                    f"{which} masks flags={flags}")
+    assert 0.0 < (want & 1).mean() < 1.0
