@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void carve_coarse_kernel(const CarveParams p) 
     const BoxW box = make_box(p.s, x0, min(x0 + kCoarseX - 1, p.X - 1), y0,
                               min(y0 + cyN - 1, p.Y - 1), global_z(p, z0),
                               global_z(p, min(z0 + czN - 1, p.Z - 1)));
-    bool any_carved = false;
+    bool any_carved = false, any_mixed = false, any_fg = false;
     int chunk = 0;
     for (int vc = p.v0; vc < p.v1; vc += 64, ++chunk) {
         const int myv = vc + lane;
@@ -161,12 +161,17 @@ __global__ __launch_bounds__(256) void carve_coarse_kernel(const CarveParams p) 
         const unsigned long long mixed = __ballot(cls == kClsMixed);
         const unsigned long long fg = __ballot(cls == kClsFg);
         any_carved = any_carved || carved;
+        any_mixed = any_mixed || mixed;
+        any_fg = any_fg || fg;
         if (lane == 0) {
             p.coarseMixed[(size_t)ct * p.nchunks + chunk] = mixed;
             p.coarseFg[(size_t)ct * p.nchunks + chunk] = fg;
         }
     }
-    if (lane == 0) p.coarseCarved[ct] = any_carved ? 1 : 0;
+    // 1: some view carves the whole tile.  2 / 3: no view needs a closer look and none
+    // carves -- every voxel keeps its occupancy and is seen (2) or not even seen (3).
+    if (lane == 0)
+        p.coarseCarved[ct] = any_carved ? 1 : (any_mixed ? 0 : (any_fg ? 2 : 3));
 }
 
 template <bool kAligned4>
@@ -188,21 +193,25 @@ __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p
     const bool cull = !(p.flags & 1u);
     const int ct =
         cull ? tx + p.coarseX * ((ty >> p.cyShift) + p.coarseY * (tz >> p.czShift)) : 0;
-    const bool coarse_carved = cull && p.coarseCarved[ct];  // workgroup-uniform (scalar load)
-    if (kAligned4 && coarse_carved && (p.X & 15) == 0 && (tx + 1) * kTileX <= p.X) {
-        // Pure fill of a 64x8x8 tile that the pre-pass decided: every voxel carved and
-        // seen.  One 16-byte store per thread, 4 lanes per 64-byte row, instead of the
+    const int code = cull ? p.coarseCarved[ct] : 0;  // workgroup-uniform (scalar load)
+    const bool coarse_carved = code == 1;
+    // Pure fill of a 64x8x8 tile that the pre-pass decided: carved+seen (code 1), or,
+    // for a fresh model, untouched occupancy with (2) / without (3) the seen bit.
+    if (kAligned4 && (coarse_carved || (code >= 2 && (p.flags & 4u))) && (p.X & 15) == 0 &&
+        (tx + 1) * kTileX <= p.X) {
+        // One 16-byte store per thread, 4 lanes per 64-byte row, instead of the
         // per-sub-tile layout's four dword stores per lane.
+        const uint32_t v4 = code == 1 ? kDone4 : (code == 2 ? 0x03030303u : 0x01010101u);
         const int yy = ty * kTileY + ((threadIdx.x >> 2) & 7);
         const int zz = tz * kTileZ + (threadIdx.x >> 5);
         if (yy < p.Y && zz < p.Z) {
             uint8_t *dst = p.state + ((size_t)zz * p.Y + yy) * p.X + tx * kTileX +
                            16 * (threadIdx.x & 3);
-            *reinterpret_cast<uint4 *>(dst) = make_uint4(kDone4, kDone4, kDone4, kDone4);
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(v4, v4, v4, v4);
         }
         if ((p.flags & 2u) && lane == 0) {
             atomicAdd(&p.stats[0], 1ull);
-            atomicAdd(&p.stats[1], 1ull);
+            if (coarse_carved) atomicAdd(&p.stats[1], 1ull);
         }
         return;
     }
