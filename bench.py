@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--no-cull", action="store_true", help="evaluate every voxel in every view")
     ap.add_argument("--collective", default="allreduce", choices=["allreduce", "allgather", "none"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-ablation", action="store_true",
+                    help="skip the NO_CULL ablation leg (keeps a profile to one kernel variant)")
     ap.add_argument("--extra-grid", type=int, default=1024,
                     help="also time this grid at N=1 (0 = skip); reported under 'extra'")
     args = ap.parse_args()
@@ -274,7 +276,7 @@ def main():
         except Exception as ex:  # e.g. not enough memory on a shared box
             out["extra"] = {"error": str(ex)}
 
-    if rank == 0 and world == 1 and not args.no_cull:
+    if rank == 0 and world == 1 and not args.no_cull and not args.no_ablation:
         # Ablation in the same run: the same kernel with the rectangle tests off, i.e.
         # every voxel projected exactly in every view until it is carved (wave ballot
         # early-out only).  This is the closest thing to the per-view streaming
