@@ -128,7 +128,12 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from ar_voxel_project_amd import capi, sharding, synthetic
+    from ar_voxel_project_amd import build, capi, sharding, synthetic
+    if not os.path.exists(capi.LIB_PATH):  # a checkout without built artefacts
+        if local_rank == 0:
+            build.build_library()
+        if world > 1:
+            dist.barrier()
 
     def barrier():
         if world > 1:
