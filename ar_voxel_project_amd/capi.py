@@ -347,4 +347,7 @@ class Context:
     def stats(self) -> dict:
         s = Stats()
         _check(self._lib.arvx_get_stats(self._h, C.byref(s)))
-        return {k: int(getattr(s, k)) for k, _ in Stats._fields_ if k != "reserved"}
+        out = {k: int(getattr(s, k)) for k, _ in Stats._fields_ if k != "reserved"}
+        out["slices_evaluated"] = int(s.reserved[0])  # 256-voxel slices projected exactly
+        out["open_voxels_in_slices"] = int(s.reserved[1])  # of those voxels, not yet finished
+        return out

@@ -391,6 +391,7 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
     p.bg = ctx->d_bg;
     p.sat = ctx->d_sat;
     p.stats = ctx->d_stats;
+    p.timeline = nullptr;
     p.X = ctx->X;
     p.Y = ctx->Y;
     p.Z = ctx->ze1 - ctx->ze0;  // owned planes plus halo (recomputed, never exchanged)
@@ -417,7 +418,7 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
     p.nchunks = (count + 63) / 64;
     p.coarseMixed = p.coarseFg = nullptr;
     p.coarseCarved = nullptr;
-    if (flags & ARVX_CARVE_STATS) ARVX_HIP(hipMemsetAsync(ctx->d_stats, 0, 32, ctx->stream));
+    if (flags & ARVX_CARVE_STATS) ARVX_HIP(hipMemsetAsync(ctx->d_stats, 0, 64, ctx->stream));
     if (!(flags & ARVX_CARVE_NO_CULL)) {
         const size_t ncoarse = (size_t)p.coarseX * p.coarseY * p.coarseZ;
         const size_t words = ncoarse * p.nchunks;
@@ -439,6 +440,14 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
     // rows of tiles (along x) are dealt to the XCDs cyclically: see the kernel
     const size_t rows8 = ((size_t)p.tilesY * p.tilesZ + 7) / 8 * 8;
     const unsigned grid = (unsigned)(rows8 * p.tilesX);
+#ifdef ARVX_TIMELINE
+    if (ctx->d_timeline) (void)hipFree(ctx->d_timeline);
+    ctx->d_timeline = nullptr;
+    ctx->timeline_n = grid;
+    ARVX_HIP(hipMalloc(&ctx->d_timeline, (size_t)grid * 32));
+    ARVX_HIP(hipMemsetAsync(ctx->d_timeline, 0, (size_t)grid * 32, ctx->stream));
+    p.timeline = (unsigned long long *)ctx->d_timeline;
+#endif
     const bool aligned = (p.X % 4 == 0) && (((uintptr_t)p.state & 3u) == 0);
     if (aligned)
         hipLaunchKernelGGL(arvx::carve_fused_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream,
@@ -491,6 +500,8 @@ int arvx_get_stats(arvx_ctx *ctx, arvx_stats *out) {
     out->subtile_views_mixed = h[2];
     out->subtile_views_total = h[3];
     out->surface_voxels = h[4];
+    out->reserved[0] = h[5];  // 256-voxel slices evaluated exactly
+    out->reserved[1] = h[6];  // voxels among them that were not yet carved+seen
     return ARVX_OK;
 }
 
@@ -735,6 +746,20 @@ int arvx_selftest_divide(arvx_ctx *ctx, int64_t n, const float *a0, const float 
     if (e != hipSuccess) return arvx::fail_hip(e, "selftest_divide", __FILE__, __LINE__);
     return ARVX_OK;
 }
+
+#ifdef ARVX_TIMELINE
+// diagnostic builds only: per-workgroup {start, end (100 MHz ticks), xcc id, 0} of the last carve
+extern "C" int arvx_debug_timeline(arvx_ctx *ctx, unsigned long long *out, int64_t *n) {
+    ARVX_CHECK_CTX(ctx);
+    *n = ctx->timeline_n;
+    if (out && ctx->d_timeline) {
+        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+        ARVX_HIP(hipMemcpy(out, ctx->d_timeline, (size_t)ctx->timeline_n * 32,
+                           hipMemcpyDeviceToHost));
+    }
+    return ARVX_OK;
+}
+#endif
 
 // ---- closure -------------------------------------------------------------------------
 

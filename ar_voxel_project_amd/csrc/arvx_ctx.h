@@ -33,6 +33,8 @@ struct Ctx {
 
     uint8_t *d_state = nullptr;  // planes ze0..ze1-1
     uint8_t *owned() const { return d_state + (size_t)(z0 - ze0) * X * Y; }
+    void *d_timeline = nullptr;  // ARVX_TIMELINE diagnostic builds only
+    int64_t timeline_n = 0;
     bool fresh_pending = false;  // arvx_state_reset is lazy (arvx_capi.hip: materialize)
     void *d_coarse = nullptr;    // coarse pre-pass masks of the carve kernel
     size_t coarse_bytes = 0;

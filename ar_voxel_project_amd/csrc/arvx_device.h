@@ -29,6 +29,7 @@ struct CarveParams {
     const uint32_t *bg;     // V x bgWords, bit = 1 where the mask pixel is background
     const int *sat;         // V x satStride, summed-area table of foreground pixels
     unsigned long long *stats;
+    unsigned long long *timeline;  // diagnostic builds only (ARVX_TIMELINE), else null
     int X, Y, Z;            // slab extent in voxels (Z = planes held)
     int zoff;               // global z of slab plane 0 (contiguous slabs)
     int zstride, zphase;    // striped slabs: local 8-plane group g is global group

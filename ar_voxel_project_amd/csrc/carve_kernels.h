@@ -174,8 +174,29 @@ __global__ __launch_bounds__(256) void carve_coarse_kernel(const CarveParams p) 
         p.coarseCarved[ct] = any_carved ? 1 : (any_mixed ? 0 : (any_fg ? 2 : 3));
 }
 
+#ifdef ARVX_TIMELINE  // diagnostic build only (tools/timeline.py): per-workgroup start/end
+struct TimelineScope {
+    unsigned long long *slot;
+    __device__ explicit TimelineScope(unsigned long long *base) : slot(nullptr) {
+        if (threadIdx.x == 0 && base) {
+            slot = base + 4ull * blockIdx.x;
+            slot[0] = __builtin_amdgcn_s_memrealtime();
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            slot[2] = xcc & 0xf;
+        }
+    }
+    __device__ ~TimelineScope() {
+        if (slot) slot[1] = __builtin_amdgcn_s_memrealtime();
+    }
+};
+#endif
+
 template <bool kAligned4>
 __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p) {
+#ifdef ARVX_TIMELINE
+    TimelineScope timeline_scope(p.timeline);
+#endif
     // Blocks b, b+8, b+16.. share an XCD (and its L2).  A row of tiles along x (one
     // 8x8 bundle of voxel rows) stays on one XCD, so neighbouring 64-byte runs meet
     // in one L2; rows are dealt to the 8 XCDs cyclically, which spreads the
@@ -333,6 +354,18 @@ __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (!__any(st[k] != kDone4)) continue;  // these 256 voxels are finished
+                if (p.flags & 2u) {  // how many of the 256 evaluations were still open
+                    const uint32_t x4 = st[k] ^ kDone4;
+                    int open = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) open += ((x4 >> (8 * j)) & 0xffu) ? 1 : 0;
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) open += __shfl_xor(open, d);
+                    if (lane == 0) {
+                        atomicAdd(&p.stats[5], 1ull);
+                        atomicAdd(&p.stats[6], (unsigned long long)open);
+                    }
+                }
                 const double p20 = m2[0] * dwz[k], p21 = m2[1] * dwz[k], p22 = m2[2] * dwz[k];
                 uint32_t w = st[k];
 #pragma unroll
