@@ -368,6 +368,10 @@ __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p
                 }
                 const double p20 = m2[0] * dwz[k], p21 = m2[1] * dwz[k], p22 = m2[2] * dwz[k];
                 uint32_t w = st[k];
+                // project the four voxels first, then issue the four table reads together:
+                // the loop is bound by the latency of these dependent reads, not by VALU
+                int pix[4];
+                bool in[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float a0 = row_sum(p01[0][j], p20, p3[0]);
@@ -380,11 +384,15 @@ __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p
                         u = a0 / a2;
                         v = a1 / a2;
                     }
-                    int pix;
-                    const bool in = pixel_from_quotients(u, v, p.W, wlim, hlim, pix);
-                    const uint32_t word = bgv[(unsigned)pix >> 5];  // pix = 0 when outside
-                    const uint32_t isbg = in ? ((word >> (pix & 31)) & 1u) : 0u;
-                    const uint32_t seen = in ? (2u << (8 * j)) : 0u;
+                    in[j] = pixel_from_quotients(u, v, p.W, wlim, hlim, pix[j]);
+                }
+                uint32_t word[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) word[j] = bgv[(unsigned)pix[j] >> 5];  // pix = 0 outside
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t isbg = in[j] ? ((word[j] >> (pix[j] & 31)) & 1u) : 0u;
+                    const uint32_t seen = in[j] ? (2u << (8 * j)) : 0u;
                     w = (w | seen) & ~(isbg << (8 * j));
                 }
                 st[k] = w;
