@@ -819,8 +819,10 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     cp.tY = (cp.Y + 7) / 8;
     cp.tZ = (cp.Z + 7) / 8;
     const size_t ntile = (size_t)cp.tX * cp.tY * cp.tZ;
-    const size_t need = (size_t)nblk * sizeof(int) + (size_t)(nblk + 1) * sizeof(long long) + 64 +
-                        ntile;
+    const size_t nrows = (size_t)cp.Y * cp.Z;
+    const size_t off_rows = ((size_t)nblk * sizeof(int) + (size_t)(nblk + 1) * sizeof(long long) +
+                             64 + ntile + 63) / 64 * 64;
+    const size_t need = off_rows + (nrows + 1) * sizeof(int);
     if (ctx->scratch_bytes < need) {
         if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
         ctx->d_scratch = nullptr;
@@ -832,6 +834,11 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     int *d_cnt = (int *)(d_off + nblk + 1);
     uint8_t *d_tiles = (uint8_t *)(d_cnt + nblk + 8);
     cp.tile_any = d_tiles;
+    int *d_rows = (int *)((uint8_t *)ctx->d_scratch + off_rows);
+    cp.row_start = d_rows;
+    hipLaunchKernelGGL(arvx::closure_rows_kernel, dim3((unsigned)((nrows + 256) / 256)), dim3(256),
+                       0, ctx->stream, cp.col_index, cp.ncol, cp.X, (long long)nrows, d_rows);
+    ARVX_HIP(hipGetLastError());
     hipLaunchKernelGGL(arvx::closure_tiles_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0,
                        ctx->stream, cp, d_tiles);
     ARVX_HIP(hipGetLastError());

@@ -502,12 +502,21 @@ __global__ __launch_bounds__(256) void sat_cols_kernel(int W, int H, int *__rest
     const int v = blockIdx.y;
     const int xcol = blockIdx.x * 256 + threadIdx.x;  // 0..W
     if (xcol > W) return;
-    int *s = sat + (size_t)v * satStride;
+    int *s = sat + (size_t)v * satStride + xcol;
+    const size_t ld = (size_t)(W + 1);
     int acc = 0;
-    s[xcol] = 0;
-    for (int yy = 1; yy <= H; ++yy) {
-        acc += s[(size_t)yy * (W + 1) + xcol];
-        s[(size_t)yy * (W + 1) + xcol] = acc;
+    s[0] = 0;
+    // 16 rows at a time: the loads of a chunk are independent of each other, so their
+    // latency overlaps (a load-add-store chain per row was 120 us for 36 views)
+    for (int y0 = 1; y0 <= H; y0 += 16) {
+        int t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = (y0 + k <= H) ? s[(size_t)(y0 + k) * ld] : 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            acc += t[k];
+            if (y0 + k <= H) s[(size_t)(y0 + k) * ld] = acc;
+        }
     }
 }
 

@@ -29,6 +29,7 @@ struct ClosureParams {
     long long ncol;
     const uint8_t *tile_any;  // per 8x8x8 tile: holds an occupied voxel (skip test)
     int tX, tY, tZ;
+    const int *row_start;  // [Y*Z + 1] first colour-list entry of each voxel row (x run)
 };
 
 // bit2 = painted with UNSEEN_COLOR by the host Model (include/arvx/model.hpp)
@@ -41,14 +42,31 @@ __device__ __forceinline__ bool cl_occupied(const ClosureParams &p, uint8_t st) 
 
 __device__ inline float4 cl_color(const ClosureParams &p, size_t i, uint8_t st) {
     if (cl_unseen(p, st)) return make_float4(204.f, 0.f, 0.f, 1.f);
-    long long lo = 0, hi = p.ncol;  // lower_bound on the sorted index list
+    // the colour list is sorted by flat index, so one voxel row is one short run of it
+    const size_t row = i / p.X;
+    int lo = p.row_start[row], hi = p.row_start[row + 1];
     while (lo < hi) {
-        const long long mid = (lo + hi) >> 1;
+        const int mid = (lo + hi) >> 1;
         if ((size_t)p.col_index[mid] < i) lo = mid + 1; else hi = mid;
     }
-    if (lo < p.ncol && (size_t)p.col_index[lo] == i && p.col_has[lo])
+    if (lo < p.row_start[row + 1] && (size_t)p.col_index[lo] == i && p.col_has[lo])
         return make_float4(p.col_rgb[3 * lo], p.col_rgb[3 * lo + 1], p.col_rgb[3 * lo + 2], 1.f);
     return make_float4(50.f, 168.f, 141.f, 1.f);
+}
+
+// row_start[r] = first list entry with index >= r*X  (r = 0..rows; row_start[rows] = ncol)
+__global__ __launch_bounds__(256) void closure_rows_kernel(const int *__restrict__ col_index,
+                                                           long long ncol, int X, long long rows,
+                                                           int *__restrict__ row_start) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r > rows) return;
+    const long long key = r * X;
+    long long lo = 0, hi = ncol;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if ((long long)col_index[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    row_start[r] = (int)lo;
 }
 
 // returns the number of occupied neighbours; with kSum also their colour sum
