@@ -58,8 +58,9 @@ __device__ __forceinline__ BoxW make_box(float s, int x0, int x1, int y0, int y1
 //   * the value the exact path computes (fp64 sum rounded to fp32) differs from
 //     the real a_r by <= 1u*E_r (+ fp64 dust);
 //   * a corner evaluated here as base + deltas (3 fma, <= 3 mul of a rounded
-//     difference, <= 3 add) differs from the real corner value by < 16u*E_r;
-//   total < 17u*E_r; eps_r = 2^-19*E_r = 32u*E_r is used.
+//     difference: 4u each, <= 3 add: 1u each) differs from the real corner value by
+//     <= 18u*E_r;
+//   total <= 19u*E_r; eps_r = 2^-19*E_r = 32u*E_r is used.
 // The quotient: |u_computed - u_real| <= (eps_0 + |u| eps_2)/(|a_2| - eps_2)
 // plus the roundings of the exact path's divide (1u|u|), of rcp+mul here (<3u|u|)
 // and of the bound arithmetic below (<2u|u|): 2^-20|u| = 16u|u| and an absolute
