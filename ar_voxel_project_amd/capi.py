@@ -20,6 +20,7 @@ OCC = 1
 SEEN = 2
 CARVE_NO_CULL = 1
 CARVE_STATS = 2
+CARVE_FUSED = 8
 COLOR_CLOSEST = 0
 COLOR_AVERAGE = 1
 

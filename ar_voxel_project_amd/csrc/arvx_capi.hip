@@ -418,11 +418,24 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
     p.nchunks = (count + 63) / 64;
     p.coarseMixed = p.coarseFg = nullptr;
     p.coarseCarved = nullptr;
+    p.workCount = p.workNext = nullptr;
+    p.workCap = 0;
+    p.itemInfo = p.itemMasks = nullptr;
     if (flags & ARVX_CARVE_STATS) ARVX_HIP(hipMemsetAsync(ctx->d_stats, 0, 64, ctx->stream));
-    if (!(flags & ARVX_CARVE_NO_CULL)) {
+    // rows of tiles (along x) are dealt to the XCDs cyclically: see carve_fused_kernel
+    const size_t rows8 = ((size_t)p.tilesY * p.tilesZ + 7) / 8 * 8;
+    const unsigned grid = (unsigned)(rows8 * p.tilesX);
+    const bool cull = !(flags & ARVX_CARVE_NO_CULL);
+    const bool split = cull && !(flags & ARVX_CARVE_FUSED) && p.nchunks <= arvx::kMaxChunks;
+    if (cull) {
         const size_t ncoarse = (size_t)p.coarseX * p.coarseY * p.coarseZ;
         const size_t words = ncoarse * p.nchunks;
-        const size_t need = 2 * words * sizeof(unsigned long long) + ncoarse + 64;
+        const size_t off_work = (2 * words * sizeof(unsigned long long) + ncoarse + 255) / 256 * 256;
+        const size_t nctr = (size_t)arvx::kWorkLists * arvx::kCounterStride;
+        const size_t cap = ((size_t)grid + arvx::kWorkLists - 1) / arvx::kWorkLists * 4;
+        const size_t nitems = cap * arvx::kWorkLists;
+        const size_t need = off_work + 2 * nctr * sizeof(int) +
+                            nitems * (1 + 2 * (size_t)p.nchunks) * sizeof(unsigned long long) + 64;
         if (ctx->coarse_bytes < need) {
             if (ctx->d_coarse) (void)hipFree(ctx->d_coarse);
             ctx->d_coarse = nullptr;
@@ -433,13 +446,49 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
         p.coarseMixed = (unsigned long long *)ctx->d_coarse;
         p.coarseFg = p.coarseMixed + words;
         p.coarseCarved = (uint8_t *)(p.coarseFg + words);
+        if (split) {
+            int *base = (int *)((uint8_t *)ctx->d_coarse + off_work);
+            p.workCount = base;
+            p.workNext = base + nctr;
+            p.workCap = (int)cap;
+            p.itemInfo = (unsigned long long *)(base + 2 * nctr);
+            p.itemMasks = p.itemInfo + nitems;
+            ARVX_HIP(hipMemsetAsync(base, 0, 2 * nctr * sizeof(int), ctx->stream));
+        }
         hipLaunchKernelGGL(arvx::carve_coarse_kernel, dim3((unsigned)((ncoarse + 3) / 4)),
                            dim3(256), 0, ctx->stream, p);
         ARVX_HIP(hipGetLastError());
     }
-    // rows of tiles (along x) are dealt to the XCDs cyclically: see the kernel
-    const size_t rows8 = ((size_t)p.tilesY * p.tilesZ + 7) / 8 * 8;
-    const unsigned grid = (unsigned)(rows8 * p.tilesX);
+    const bool aligned = (p.X % 4 == 0) && (((uintptr_t)p.state & 3u) == 0);
+    if (split) {
+        if (aligned)
+            hipLaunchKernelGGL(arvx::carve_classify_kernel<true>, dim3(grid), dim3(256), 0,
+                               ctx->stream, p);
+        else
+            hipLaunchKernelGGL(arvx::carve_classify_kernel<false>, dim3(grid), dim3(256), 0,
+                               ctx->stream, p);
+        ARVX_HIP(hipGetLastError());
+        // one workgroup per workgroup slot of the chip (4 per CU at 128 VGPRs)
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        const unsigned pgrid = (unsigned)(ncu > 0 ? ncu : 256) * 4u;
+#ifdef ARVX_TIMELINE
+        if (ctx->d_timeline) (void)hipFree(ctx->d_timeline);
+        ctx->d_timeline = nullptr;
+        ctx->timeline_n = pgrid;
+        ARVX_HIP(hipMalloc(&ctx->d_timeline, (size_t)pgrid * 32));
+        ARVX_HIP(hipMemsetAsync(ctx->d_timeline, 0, (size_t)pgrid * 32, ctx->stream));
+        p.timeline = (unsigned long long *)ctx->d_timeline;
+#endif
+        if (aligned)
+            hipLaunchKernelGGL(arvx::carve_exact_kernel<true>, dim3(pgrid), dim3(256), 0,
+                               ctx->stream, p);
+        else
+            hipLaunchKernelGGL(arvx::carve_exact_kernel<false>, dim3(pgrid), dim3(256), 0,
+                               ctx->stream, p);
+        ARVX_HIP(hipGetLastError());
+        return ARVX_OK;
+    }
 #ifdef ARVX_TIMELINE
     if (ctx->d_timeline) (void)hipFree(ctx->d_timeline);
     ctx->d_timeline = nullptr;
@@ -448,7 +497,6 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
     ARVX_HIP(hipMemsetAsync(ctx->d_timeline, 0, (size_t)grid * 32, ctx->stream));
     p.timeline = (unsigned long long *)ctx->d_timeline;
 #endif
-    const bool aligned = (p.X % 4 == 0) && (((uintptr_t)p.state & 3u) == 0);
     if (aligned)
         hipLaunchKernelGGL(arvx::carve_fused_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream,
                            p);

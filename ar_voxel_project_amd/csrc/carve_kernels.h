@@ -428,6 +428,307 @@ __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Split form of the same algorithm (the default when culling is on):
+//   carve_classify_kernel   every sub-tile: rectangle tests, and the whole job for the
+//                           sub-tiles they decide (fill / inherit / store).  Short
+//                           dependent-read chains, few registers -> 8 waves per SIMD.
+//   carve_exact_kernel      only the sub-tiles with "mixed" views, pulled from work
+//                           lists by persistent waves: uniform VALU-bound work.
+// In the fused kernel one wave goes through both kinds of phase, and with 4 waves per
+// SIMD the VALUs idle two thirds of the time while waves sit in the latency-bound
+// phases (profiles/r1_kernel_v5: 34 % VALU-active at 512^3).
+// ---------------------------------------------------------------------------------
+
+struct SubTile {
+    int sx0, sy0, sz0, sx1, sy1, sz1;  // voxel box (slab-local z)
+    int x, y, zb;                      // this lane's 4 x-voxels, its y, its first z
+    bool lane_ok;
+};
+
+__device__ __forceinline__ SubTile subtile_of(const CarveParams &p, int tx, int ty, int tz,
+                                              int wave, int lane) {
+    SubTile t;
+    t.sx0 = tx * kTileX + wave * kSubX;
+    t.sy0 = ty * kTileY;
+    t.sz0 = tz * kTileZ;
+    t.sx1 = min(t.sx0 + kSubX - 1, p.X - 1);
+    t.sy1 = min(t.sy0 + kTileY - 1, p.Y - 1);
+    t.sz1 = min(t.sz0 + kTileZ - 1, p.Z - 1);
+    t.x = t.sx0 + 4 * (lane & 3);
+    t.y = t.sy0 + ((lane >> 2) & 7);
+    t.zb = t.sz0 + 4 * (lane >> 5);
+    t.lane_ok = (t.x < p.X) && (t.y < p.Y);
+    return t;
+}
+
+template <bool kAligned4>
+__device__ __forceinline__ void subtile_load(const CarveParams &p, const SubTile &t,
+                                             uint32_t st[4]) {
+    const size_t row = (size_t)p.X, plane = (size_t)p.X * p.Y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        st[k] = kDone4;  // lanes / voxels outside the grid count as finished
+        const int z = t.zb + k;
+        if (t.lane_ok && z < p.Z) {
+            const uint8_t *src = p.state + (size_t)z * plane + (size_t)t.y * row + t.x;
+            if (p.flags & 4u) {  // fresh model: all occupied, none seen; no load
+                uint32_t w = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    w |= (uint32_t)((t.x + j < p.X) ? 1u : 2u) << (8 * j);
+                st[k] = w;
+            } else if (kAligned4) {
+                st[k] = *reinterpret_cast<const uint32_t *>(src);
+            } else {
+                uint32_t w = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    w |= (uint32_t)((t.x + j < p.X) ? src[j] : (uint8_t)2) << (8 * j);
+                st[k] = w;
+            }
+        }
+    }
+}
+
+template <bool kAligned4>
+__device__ __forceinline__ void subtile_store(const CarveParams &p, const SubTile &t,
+                                              const uint32_t st[4]) {
+    const size_t row = (size_t)p.X, plane = (size_t)p.X * p.Y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int z = t.zb + k;
+        if (t.lane_ok && z < p.Z) {
+            uint8_t *dst = p.state + (size_t)z * plane + (size_t)t.y * row + t.x;
+            if (kAligned4) {
+                *reinterpret_cast<uint32_t *>(dst) = st[k];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (t.x + j < p.X) dst[j] = (uint8_t)(st[k] >> (8 * j));
+            }
+        }
+    }
+}
+
+template <bool kAligned4>
+__global__ __launch_bounds__(256, 8) void carve_classify_kernel(const CarveParams p) {
+    // same block -> tile map as carve_fused_kernel (rows of tiles dealt to the XCDs)
+    const unsigned k = blockIdx.x >> 3;
+    const unsigned trow = (k / p.tilesX) * 8u + (blockIdx.x & 7u);
+    if (trow >= (unsigned)(p.tilesY * p.tilesZ)) return;
+    const int tx = k % p.tilesX;
+    const int ty = trow % p.tilesY;
+    const int tz = trow / p.tilesY;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int ct = tx + p.coarseX * ((ty >> p.cyShift) + p.coarseY * (tz >> p.czShift));
+    const int code = p.coarseCarved[ct];
+    if (kAligned4 && (code == 1 || (code >= 2 && (p.flags & 4u))) && (p.X & 15) == 0 &&
+        (tx + 1) * kTileX <= p.X) {  // pure fill, as in carve_fused_kernel
+        const uint32_t v4 = code == 1 ? kDone4 : (code == 2 ? 0x03030303u : 0x01010101u);
+        const int yy = ty * kTileY + ((threadIdx.x >> 2) & 7);
+        const int zz = tz * kTileZ + (threadIdx.x >> 5);
+        if (yy < p.Y && zz < p.Z) {
+            uint8_t *dst = p.state + ((size_t)zz * p.Y + yy) * p.X + tx * kTileX +
+                           16 * (threadIdx.x & 3);
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(v4, v4, v4, v4);
+        }
+        if ((p.flags & 2u) && lane == 0) {
+            atomicAdd(&p.stats[0], 1ull);
+            if (code == 1) atomicAdd(&p.stats[1], 1ull);
+        }
+        return;
+    }
+    if (tx * kTileX + wave * kSubX >= p.X) return;  // wave-uniform
+    const SubTile t = subtile_of(p, tx, ty, tz, wave, lane);
+    const BoxW box = make_box(p.s, t.sx0, t.sx1, t.sy0, t.sy1, global_z(p, t.sz0),
+                              global_z(p, t.sz1));
+    bool any_carved = code == 1, any_fg = false, any_mixed = false;
+    unsigned long long mixed_c[kMaxChunks], fast_c[kMaxChunks];
+#pragma unroll
+    for (int chunk = 0; chunk < kMaxChunks; ++chunk) {  // unrolled: the arrays stay in SGPRs
+        mixed_c[chunk] = fast_c[chunk] = 0;
+        const int vc = p.v0 + 64 * chunk;
+        if (vc >= p.v1 || any_carved) continue;
+        const int myv = vc + lane;
+        int cls = kClsOut;
+        if (myv < p.v1) {
+            const unsigned long long cm = p.coarseMixed[(size_t)ct * p.nchunks + chunk];
+            const unsigned long long cf = p.coarseFg[(size_t)ct * p.nchunks + chunk];
+            if ((cf >> lane) & 1ull)
+                cls = kClsFg;  // inherited: the coarse rectangle contains this one
+            else if ((cm >> lane) & 1ull)
+                cls = classify_box(p.M + 12 * myv, box, p.W, p.H,
+                                   p.sat + (size_t)myv * p.satStride);
+        }
+        fast_c[chunk] = __ballot((cls & kFastDiv) != 0);
+        cls &= 3;
+        mixed_c[chunk] = __ballot(cls == kClsMixed);
+        any_carved = __ballot(cls == kClsCarved) != 0;
+        any_fg = any_fg || __ballot(cls == kClsFg) != 0;
+        any_mixed = any_mixed || mixed_c[chunk] != 0;
+        if ((p.flags & 2u) && lane == 0) {
+            atomicAdd(&p.stats[2], (unsigned long long)__popcll(mixed_c[chunk]));
+            atomicAdd(&p.stats[3], (unsigned long long)min(64, p.v1 - vc));
+        }
+    }
+    if ((p.flags & 2u) && lane == 0) {
+        atomicAdd(&p.stats[0], 1ull);
+        if (any_carved) atomicAdd(&p.stats[1], 1ull);
+    }
+    uint32_t st[4];
+    if (any_carved) {  // carved implies seen (src/VoxelCarving.cpp:50-54): no load needed
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) st[kk] = kDone4;
+        subtile_store<kAligned4>(p, t, st);
+    } else if (!any_mixed) {
+        subtile_load<kAligned4>(p, t, st);
+        if (any_fg) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) st[kk] |= kDone4;  // seen, src/VoxelCarving.cpp:54
+        }
+        subtile_store<kAligned4>(p, t, st);
+    } else if (lane == 0) {
+        // hand the sub-tile to carve_exact_kernel: where it is, whether some view sees
+        // all of it, and per chunk of 64 views which ones to evaluate (and how to divide)
+        const int cls = blockIdx.x & (kWorkLists - 1);
+        const int pos = atomicAdd(&p.workCount[cls * kCounterStride], 1);
+        const size_t it = (size_t)cls * p.workCap + pos;
+        p.itemInfo[it] = (unsigned long long)tx | ((unsigned long long)ty << 16) |
+                         ((unsigned long long)tz << 32) | ((unsigned long long)wave << 48) |
+                         ((unsigned long long)(any_fg ? 1 : 0) << 50);
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; ++c)
+            if (c < p.nchunks) {
+                p.itemMasks[(it * p.nchunks + c) * 2] = mixed_c[c];
+                p.itemMasks[(it * p.nchunks + c) * 2 + 1] = fast_c[c];
+            }
+    }
+}
+
+// One view applied exactly to the 16 voxels of every lane.  Returns true when all
+// 1024 voxels of the sub-tile are carved and seen.
+__device__ __forceinline__ bool exact_view(const CarveParams &p, const int view, const bool fast,
+                                           const double dwy, const double (&dwx)[4],
+                                           const double (&dwz)[4], uint32_t (&st)[4],
+                                           const int lane) {
+    const float *__restrict__ Mv = p.M + 12 * view;
+    const uint32_t *__restrict__ bgv = p.bg + (size_t)view * p.bgWords;
+    double p01[3][4], p3[3], m2[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double p0 = (double)Mv[4 * r] * dwy;
+        const double m1 = (double)Mv[4 * r + 1];
+        m2[r] = (double)Mv[4 * r + 2];
+        p3[r] = (double)Mv[4 * r + 3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p01[r][j] = p0 + m1 * dwx[j];
+    }
+    const float wlim = (float)p.W - 0.5f, hlim = (float)p.H - 0.5f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!__any(st[k] != kDone4)) continue;  // these 256 voxels are finished
+        if (p.flags & 2u) {
+            const uint32_t x4 = st[k] ^ kDone4;
+            int open = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) open += ((x4 >> (8 * j)) & 0xffu) ? 1 : 0;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) open += __shfl_xor(open, d);
+            if (lane == 0) {
+                atomicAdd(&p.stats[5], 1ull);
+                atomicAdd(&p.stats[6], (unsigned long long)open);
+            }
+        }
+        const double p20 = m2[0] * dwz[k], p21 = m2[1] * dwz[k], p22 = m2[2] * dwz[k];
+        uint32_t w = st[k];
+        int pix[4];
+        bool in[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a0 = row_sum(p01[0][j], p20, p3[0]);
+            const float a1 = row_sum(p01[1][j], p21, p3[1]);
+            const float a2 = row_sum(p01[2][j], p22, p3[2]);
+            float u, v;
+            if (fast) {
+                divide2_shared_rcp(a0, a1, a2, u, v);
+            } else {
+                u = a0 / a2;
+                v = a1 / a2;
+            }
+            in[j] = pixel_from_quotients(u, v, p.W, wlim, hlim, pix[j]);
+        }
+        uint32_t word[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) word[j] = bgv[(unsigned)pix[j] >> 5];  // pix = 0 outside
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t isbg = in[j] ? ((word[j] >> (pix[j] & 31)) & 1u) : 0u;
+            const uint32_t seen = in[j] ? (2u << (8 * j)) : 0u;
+            w = (w | seen) & ~(isbg << (8 * j));
+        }
+        st[k] = w;
+    }
+    return __all(st[0] == kDone4 && st[1] == kDone4 && st[2] == kDone4 && st[3] == kDone4);
+}
+
+// Persistent waves pull sub-tiles from kWorkLists lists (one padded counter each: a
+// single atomic word sustains only ~90 pulls per microsecond, and counters sharing a
+// line serialise).  A wave starts on its own list and moves on when it is empty, so
+// every wave ends once all lists are drained.
+template <bool kAligned4>
+__global__ __launch_bounds__(256, 4) void carve_exact_kernel(const CarveParams p) {
+#ifdef ARVX_TIMELINE
+    TimelineScope timeline_scope(p.timeline);
+#endif
+    const int lane = threadIdx.x & 63;
+    const int first = (blockIdx.x * 4 + (threadIdx.x >> 6)) & (kWorkLists - 1);
+    for (int r = 0; r < kWorkLists; ++r) {
+        const int cls = (first + r) & (kWorkLists - 1);
+        const int n = p.workCount[cls * kCounterStride];
+        for (;;) {
+            if (__hip_atomic_load(&p.workNext[cls * kCounterStride], __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT) >= n)
+                break;  // (a relaxed look first: drained lists are not hammered)
+            int item = 0;
+            if (lane == 0) item = atomicAdd(&p.workNext[cls * kCounterStride], 1);
+            item = __builtin_amdgcn_readfirstlane(item);
+            if (item >= n) break;
+            const size_t it = (size_t)cls * p.workCap + item;
+            const unsigned long long info = p.itemInfo[it];
+            const int tx = (int)(info & 0xffffu), ty = (int)((info >> 16) & 0xffffu);
+            const int tz = (int)((info >> 32) & 0xffffu), wave = (int)((info >> 48) & 3u);
+            const SubTile t = subtile_of(p, tx, ty, tz, wave, lane);
+            const double dwy = (double)((float)t.y * p.s);
+            double dwx[4], dwz[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dwx[j] = (double)((float)(t.x + j) * p.s);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                dwz[k] = (double)((float)(-global_z(p, t.zb + k)) * p.s);
+            uint32_t st[4];
+            subtile_load<kAligned4>(p, t, st);
+            if ((info >> 50) & 1ull) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) st[k] |= kDone4;  // seen by an all-foreground view
+            }
+            bool done = false;
+            for (int c = 0; c < p.nchunks && !done; ++c) {
+                unsigned long long mixed = p.itemMasks[(it * p.nchunks + c) * 2];
+                const unsigned long long fastdiv = p.itemMasks[(it * p.nchunks + c) * 2 + 1];
+                while (mixed && !done) {
+                    const int b = __ffsll((long long)mixed) - 1;
+                    mixed &= mixed - 1;
+                    done = exact_view(p, p.v0 + 64 * c + b, (fastdiv >> b) & 1ull, dwy, dwx, dwz,
+                                      st, lane);
+                }
+            }
+            subtile_store<kAligned4>(p, t, st);
+        }
+    }
+}
+
 // self-test support: both division forms on caller-supplied operands
 __global__ __launch_bounds__(256) void selftest_divide_kernel(const float *__restrict__ a0,
                                                               const float *__restrict__ a1,

@@ -48,6 +48,7 @@ enum {
 /* flags of arvx_carve / arvx_carve_views */
 #define ARVX_CARVE_NO_CULL 1u /* evaluate every voxel in every view (ablation) */
 #define ARVX_CARVE_STATS 2u   /* fill the counters read by arvx_get_stats */
+#define ARVX_CARVE_FUSED 8u   /* one kernel for rectangle tests and per-voxel work (A/B) */
 
 /* colour modes: reference -color=1 / -color=2 (src/main.cpp:276-288) */
 #define ARVX_COLOR_CLOSEST 0

@@ -29,7 +29,7 @@ def assert_same(got, want, what=""):
             f"gpu={got[z, y, x]} oracle={want[z, y, x]}")
 
 
-@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("flags", [0, 1, 8])  # split kernels, brute force, fused kernel
 @pytest.mark.parametrize("N,V", [(32, 6), (64, 8)])
 def test_sphere_parity(arvx, oracle, N, V, flags):
     sc = scenes.small_sphere(N, V)
@@ -39,7 +39,7 @@ def test_sphere_parity(arvx, oracle, N, V, flags):
     assert (want == 3).sum() > 0 and (want == 2).sum() > 0
 
 
-@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("flags", [0, 1, 8])
 @pytest.mark.parametrize("dims", [(10, 10, 5), (50, 50, 25), (100, 100, 50), (33, 17, 9),
                                   (64, 8, 8), (1, 1, 1), (130, 7, 19)])
 def test_ragged_grids(arvx, oracle, dims, flags):
@@ -52,7 +52,7 @@ def test_ragged_grids(arvx, oracle, dims, flags):
     assert_same(got, want, f"grid {dims} flags={flags}")
 
 
-@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("flags", [0, 1, 8])
 @pytest.mark.parametrize("C,block", [(1, 1), (3, 1), (1, 8), (3, 16)])
 def test_noise_masks_random_cameras(arvx, oracle, C, block, flags):
     """Noise masks make every rounding decision visible; random cameras put
@@ -113,7 +113,7 @@ def test_many_views_chunks(arvx, oracle):
     N, V = 24, 70
     sc = scenes.small_sphere(N, V, W=96, H=72)
     want = oracle.carve(N, N, N, sc.voxel_size, sc.M, sc.masks)
-    for flags in (0, 1):
+    for flags in (0, 1, 8):
         got = run_gpu(arvx, N, N, N, sc.voxel_size, sc.M, sc.masks, flags)
         assert_same(got, want, f"70 views flags={flags}")
 
@@ -184,6 +184,7 @@ def test_cull_matches_no_cull_block_noise(arvx, seed, block, inside):
     a = run_gpu(arvx, N, N, N, s, M, masks, 0)
     b = run_gpu(arvx, N, N, N, s, M, masks, 1)
     assert_same(a, b, f"cull vs no-cull, block noise seed={seed}")
+    assert_same(run_gpu(arvx, N, N, N, s, M, masks, 8), b, "fused kernel")
     # slabs and view sub-ranges go through the same coarse tables
     c = np.concatenate([run_gpu(arvx, N, N, N, s, M, masks, 0, z_range=r)
                         for r in [(0, 70), (70, 71), (71, 192)]], axis=0)

@@ -41,6 +41,7 @@ def main():
         ctx.carve(capi.CARVE_STATS)
         st = ctx.stats()
         cull = timed(ctx, stream, 0, 7)
+        fused_ms = timed(ctx, stream, getattr(capi, "CARVE_FUSED", 0), 7)
         reps = 3 if N >= 1024 else 5
         nocull = timed(ctx, stream, capi.CARVE_NO_CULL, reps)
         vv = N ** 3 * V
@@ -48,7 +49,8 @@ def main():
             "grid": N, "views": V, "stats": st,
             "mixed_pair_fraction": st["subtile_views_mixed"] / max(1, st["subtile_views_total"]),
             "carved_subtile_fraction": st["subtiles_carved"] / max(1, st["subtiles"]),
-            "cull_ms_median_min": cull, "nocull_ms_median_min": nocull,
+            "cull_ms_median_min": cull, "fused_ms_median_min": fused_ms,
+            "nocull_ms_median_min": nocull,
             "cull_Mvvps": vv / cull[0] / 1e3, "nocull_Mvvps": vv / nocull[0] / 1e3}))
         ctx.close()
 
