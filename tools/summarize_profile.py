@@ -13,6 +13,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def kernel_key(name):
+    for k in ("coarse", "classify", "exact", "fused"):
+        if "carve_" + k in name:
+            return k
+    return "other"
+
+
 def main():
     name = sys.argv[1]
     tags = sys.argv[2:]
@@ -27,7 +34,7 @@ def main():
                 agg = collections.defaultdict(lambda: collections.defaultdict(list))
                 for r in csv.DictReader(open(f)):
                     if "carve_" in r["Kernel_Name"]:
-                        k = "coarse" if "coarse" in r["Kernel_Name"] else "fused"
+                        k = kernel_key(r["Kernel_Name"])
                         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 for k, cs in agg.items():
                     for c, v in cs.items():
@@ -37,7 +44,7 @@ def main():
             shutil.copy(f, os.path.join(out_dir, tag, "kernel_stats.csv"))
             for r in csv.DictReader(open(f)):
                 if "carve_" in r["Name"]:
-                    k = "coarse" if "coarse" in r["Name"] else "fused"
+                    k = kernel_key(r["Name"])
                     d.setdefault(k, {})["kernel_avg_ns"] = float(r["AverageNs"])
                     d[k]["kernel_calls"] = int(r["Calls"])
         summary[tag] = d
