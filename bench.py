@@ -250,8 +250,8 @@ def main():
                 "kernel_ms": r["kern_ms"],
                 "algorithmic_bytes": alg_bytes,
                 "note": "algorithmic = N*V + V*W*H read bytes of the per-view streaming "
-                        "formulation (SURVEY 8d); the fused kernel reads the state once and "
-                        "decides most 16x8x8 sub-tiles from a pixel-rectangle test, so this "
+                        "formulation (SURVEY 8d); the kernels read the state at most once and "
+                        "decide most 16x8x8 sub-tiles from a pixel-rectangle test, so this "
                         "is an EFFECTIVE rate and may exceed the physical peak; `traffic` "
                         "is the rocprofv3 PMC FETCH_SIZE+WRITE_SIZE byte count per launch (profiles/"
                         "traffic.json), `physical_GBps` = traffic / kernel time: the kernel is "
@@ -263,7 +263,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"synthetic sphere silhouettes, {r['X']}x{r['Y']}x{r['Z']} grid, "
-                               f"{r['V']} views 640x480, dense carve (all views fused)",
+                               f"{r['V']} views 640x480, dense carve, all views in one arvx_carve call",
                    "grid": [r["X"], r["Y"], r["Z"]], "views": r["V"],
                    "parallelism": f"z-slab x{world} ({r['layout']})" if world > 1 else "single GPU",
                    "collective": args.collective if world > 1 else "none",
