@@ -410,3 +410,35 @@ def test_dataset_silhouettes_plumbing(arvx, oracle, which, N):
         assert_same(run_gpu(arvx, N, N, N, sc.voxel_size, sc.M, masks, flags), want,
                     f"{which} masks flags={flags}")
     assert 0.0 < (want & 1).mean() < 1.0
+
+
+@pytest.mark.parametrize("case", ["tiny_voxels", "huge_voxels", "long_focal", "short_focal",
+                                  "far_camera", "offcentre_principal", "grazing"])
+def test_extreme_geometry(arvx, oracle, case):
+    """Margins of the rectangle tests scale with |M|, |w| and 1/depth: push each."""
+    N, V, W, H = 40, 5, 200, 150
+    rng = np.random.default_rng(sum(ord(c) for c in case))  # fixed per case
+    s = {"tiny_voxels": 1e-4, "huge_voxels": 7.5}.get(case, 0.512 / N)
+    E = s * N
+    f = {"long_focal": 6000.0, "short_focal": 25.0}.get(case, 160.0)
+    cxp, cyp = (W / 2, H / 2) if case != "offcentre_principal" else (-300.0, 900.0)
+    K = np.array([[f, 0, cxp], [0, f * 1.01, cyp], [0, 0, 1]], np.float64)
+    centre = np.array([E / 2, E / 2, -E / 2])
+    Rts = []
+    for i in range(V):
+        d = {"far_camera": 200.0, "grazing": 0.75}.get(case, 2.0) * E
+        dirv = rng.normal(size=3)
+        dirv /= np.linalg.norm(dirv)
+        cam = centre + d * dirv
+        target = centre + rng.normal(scale=0.2 * E, size=3)
+        if case == "grazing":  # look along a face of the grid: many voxels near depth 0
+            target = cam + np.array([1.0, 0.02, 0.01]) * E
+        Rts.append(scenes.syn.look_at_rt(cam, target, rng.normal(size=3)))
+    Rt = np.array(Rts).astype(np.float32)
+    M = scenes.syn.compose_m(K.astype(np.float32), Rt)
+    for block in (1, 12):
+        masks = scenes.noise_masks(V, H, W, block=block, p_bg=0.5, seed=block)
+        want = oracle.carve(N, N, N, np.float32(s), M, masks)
+        for flags in (0, 1, 8):
+            assert_same(run_gpu(arvx, N, N, N, np.float32(s), M, masks, flags), want,
+                        f"{case} block={block} flags={flags}")
