@@ -442,3 +442,18 @@ def test_extreme_geometry(arvx, oracle, case):
         for flags in (0, 1, 8):
             assert_same(run_gpu(arvx, N, N, N, np.float32(s), M, masks, flags), want,
                         f"{case} block={block} flags={flags}")
+
+
+def test_more_than_256_views_uses_fused_kernel(arvx, oracle):
+    """The split launch carries up to 4 chunks of 64 views; beyond that arvx_carve falls
+    back to the fused kernel.  Same answer either way."""
+    N, V, W, H = 16, 260, 48, 36
+    s = np.float32(0.512 / N)
+    _, _, M = scenes.random_cameras(V, 0.512, seed=9, W=W, H=H, inside=False)
+    masks = scenes.noise_masks(V, H, W, block=6, p_bg=0.25, seed=10)
+    want = oracle.carve(N, N, N, s, M, masks)
+    for flags in (0, 1, 8):
+        assert_same(run_gpu(arvx, N, N, N, s, M, masks, flags), want, f"260 views flags={flags}")
+    # 256 views: the largest count the split launch takes
+    want = oracle.carve(N, N, N, s, M[:256], masks[:256])
+    assert_same(run_gpu(arvx, N, N, N, s, M[:256], masks[:256], 0), want, "256 views")
