@@ -10,6 +10,7 @@
 #include <iostream>
 #include <vector>
 
+#include "arvx/calibration.hpp"
 #include "arvx/postprocessing.hpp"
 #include "arvx/voxel_carving.hpp"
 
@@ -137,8 +138,21 @@ static int run_carve(const char *scene, const char *out, const char *mode) {
     return 0;
 }
 
+static int test_calibration(const char *path) {
+    double K[9];
+    std::vector<double> dist;
+    EXPECT(arvx::readCameraParameters(path, K, dist));
+    EXPECT(K[0] == 4.9650601017248454e+02 && K[2] == 3.1217886794504733e+02 && K[1] == 0.);
+    EXPECT(K[4] == 4.9678498089444867e+02 && K[5] == 2.5089544695238374e+02 && K[8] == 1.);
+    EXPECT(dist.size() == 5 && dist[1] == -3.2859270046436123e-01);
+    EXPECT(!arvx::readCameraParameters("/nonexistent.yml", K, dist));
+    std::puts("calibration ok");
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc >= 2 && !std::strcmp(argv[1], "model")) return test_model();
+    if (argc == 3 && !std::strcmp(argv[1], "calibration")) return test_calibration(argv[2]);
     if (argc == 5 && !std::strcmp(argv[1], "carve")) return run_carve(argv[2], argv[3], argv[4]);
     std::fprintf(stderr, "usage: test_host model | test_host carve <scene> <out> <mode>\n");
     return 2;

@@ -28,6 +28,13 @@ def test_model_host_logic(host_bin):
     assert "model ok" in r.stdout
 
 
+def test_calibration_file_reader(host_bin):
+    """loadCalibrationFile's file format (OpenCV FileStorage YAML), parsed without OpenCV."""
+    yml = os.path.join(ROOT, "tests", "golden", "cameracalibration.yml")
+    r = subprocess.run([host_bin, "calibration", yml], capture_output=True, text=True)
+    assert r.returncode == 0 and "calibration ok" in r.stdout, r.stderr
+
+
 def write_scene(path, X, Y, Z, s, K, Rt, masks, images, st0):
     m4 = masks if masks.ndim == 4 else masks[..., None]
     V, H, W, C = m4.shape
