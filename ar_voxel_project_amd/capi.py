@@ -36,6 +36,7 @@ SYMBOLS = [
     "arvx_color", "arvx_surface_count", "arvx_surface_download",
     "arvx_surface_depth_download",
     "arvx_colors_upload", "arvx_closure", "arvx_closure_count", "arvx_closure_download",
+    "arvx_mc_cells", "arvx_mc_cells_download",
     "arvx_export_model", "arvx_get_stats", "arvx_selftest_divide",
 ]
 
@@ -120,6 +121,9 @@ def load_library() -> C.CDLL:
     ab_build = bool(os.environ.get("ARVX_LIB_PATH"))  # an older build may lack newer symbols
     if hasattr(lib, "arvx_selftest_divide") or not ab_build:
         lib.arvx_selftest_divide.argtypes = [p, C.c_int64, f32p, f32p, f32p, f32p]
+    if hasattr(lib, "arvx_mc_cells") or not ab_build:
+        lib.arvx_mc_cells.argtypes = [p, C.POINTER(C.c_int64)]
+        lib.arvx_mc_cells_download.argtypes = [p, C.POINTER(C.c_int32)]
     for name in SYMBOLS:
         if ab_build and not hasattr(lib, name):
             continue
@@ -333,6 +337,17 @@ class Context:
             _check(self._lib.arvx_closure_download(
                 self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)), _fp(rgba)))
         return idx, rgba
+
+    def mc_cells(self) -> np.ndarray:
+        """(n, 4) int32 -- x, y, z, cube index of the cells marchingCubes would
+        triangulate, in its visiting order (x outermost, z innermost)."""
+        n = C.c_int64()
+        _check(self._lib.arvx_mc_cells(self._h, C.byref(n)))
+        cells = np.empty((n.value, 4), np.int32)
+        if n.value:
+            _check(self._lib.arvx_mc_cells_download(
+                self._h, cells.ctypes.data_as(C.POINTER(C.c_int32))))
+        return cells
 
     def export_model(self, apply_unseen: bool = False) -> np.ndarray:
         out = np.empty((self.nvox, 4), np.float32)

@@ -18,6 +18,7 @@
 #include "color_kernels.h"
 #include "closure_kernels.h"
 #include "fast_carve_kernels.h"
+#include "mc_kernels.h"
 #include <algorithm>
 
 namespace {
@@ -159,6 +160,8 @@ int arvx_ctx_destroy(arvx_ctx *ctx) {
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     ctx->free_views();
     ctx->free_color();
+    ctx->free_mc();
+    if (ctx->d_flood) (void)hipFree(ctx->d_flood);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -940,6 +943,82 @@ int arvx_closure_download(arvx_ctx *ctx, int64_t *index, float *rgba) {
     return ARVX_OK;
 }
 
+// ---- marching-cubes hand-off ----------------------------------------------------------
+
+int arvx_mc_cells(arvx_ctx *ctx, int64_t *count) {
+    ARVX_CHECK_CTX(ctx);
+    if (!count) return fail(ARVX_ERR_INVALID, "null argument");
+    if (int mrc = materialize(ctx)) return mrc;
+    if (ctx->stripe_world > 1)
+        return fail(ARVX_ERR_STATE, "the cell walk needs contiguous slabs (neighbour planes)");
+    ctx->free_mc();
+    arvx::McParams mp;
+    mp.state = ctx->d_state;
+    mp.X = ctx->X;
+    mp.Y = ctx->Y;
+    mp.Z = ctx->Z;
+    mp.ze0 = ctx->ze0;
+    mp.ze1 = ctx->ze1;
+    // a cell belongs to the slab that owns its upper plane; the last slab also takes
+    // the cells whose upper plane is outside the grid
+    mp.cz0 = ctx->z0 - 1;
+    mp.cz1 = (ctx->z1 == ctx->Z) ? ctx->Z : ctx->z1 - 1;
+    const long long ncol = (long long)(ctx->X + 1) * (ctx->Y + 1);
+    const int nsb = (int)((ncol + arvx::kScanBlock - 1) / arvx::kScanBlock);
+    const size_t need = (size_t)(ncol + nsb + 1) * sizeof(long long) +
+                        (size_t)(ncol + nsb) * sizeof(int) + 64;
+    if (ctx->scratch_bytes < need) {
+        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        ARVX_HIP(hipMalloc(&ctx->d_scratch, need));
+        ctx->scratch_bytes = need;
+    }
+    long long *d_off = (long long *)ctx->d_scratch;  // ncol column offsets
+    long long *d_boff = d_off + ncol;                // nsb + 1 block offsets, last = total
+    int *d_cnt = (int *)(d_boff + nsb + 1);
+    int *d_bsum = d_cnt + ncol;
+    const unsigned nblk = (unsigned)((ncol + 255) / 256);
+    hipLaunchKernelGGL(arvx::mc_count_kernel, dim3(nblk), dim3(256), 0, ctx->stream, mp, d_cnt);
+    ARVX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(arvx::mc_block_sum_kernel, dim3(nsb), dim3(256), 0, ctx->stream, d_cnt,
+                       (int)ncol, d_bsum);
+    ARVX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(arvx::mc_scan_blocks_kernel, dim3(1), dim3(256), 0, ctx->stream, d_bsum, nsb,
+                       d_boff);
+    ARVX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(arvx::mc_block_scan_kernel, dim3(nsb), dim3(256), 0, ctx->stream, d_cnt,
+                       (int)ncol, d_boff, d_off);
+    ARVX_HIP(hipGetLastError());
+    long long total = 0;
+    ARVX_HIP(hipMemcpyAsync(&total, d_boff + nsb, sizeof total, hipMemcpyDeviceToHost,
+                            ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    if (total > 0) {
+        ARVX_HIP(hipMalloc(&ctx->d_mc_cells, (size_t)total * sizeof(int4)));
+        hipLaunchKernelGGL(arvx::mc_write_kernel, dim3(nblk), dim3(256), 0, ctx->stream, mp, d_off,
+                           (int4 *)ctx->d_mc_cells);
+        ARVX_HIP(hipGetLastError());
+        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->mc_count = total;
+    ctx->mc_ready = true;
+    *count = total;
+    return ARVX_OK;
+}
+
+int arvx_mc_cells_download(arvx_ctx *ctx, int32_t *cells) {
+    ARVX_CHECK_CTX(ctx);
+    if (!cells) return fail(ARVX_ERR_INVALID, "null argument");
+    if (!ctx->mc_ready) return fail(ARVX_ERR_STATE, "no cell list (call arvx_mc_cells)");
+    if (ctx->mc_count) {
+        ARVX_HIP(hipMemcpyAsync(cells, ctx->d_mc_cells, (size_t)ctx->mc_count * sizeof(int4),
+                                hipMemcpyDeviceToHost, ctx->stream));
+        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return ARVX_OK;
+}
+
 // ---- greedy carve -------------------------------------------------------------------
 
 int arvx_fast_carve(arvx_ctx *ctx) {
@@ -957,59 +1036,94 @@ int arvx_fast_carve(arvx_ctx *ctx) {
     fp.Z = ctx->Z;
     fp.XW = (ctx->X + 63) / 64;
     const size_t nwords = (size_t)fp.XW * fp.Y * fp.Z;
-    uint8_t *d_tmp = nullptr;
-    unsigned long long *d_bits = nullptr;
-    int *d_changed = nullptr;
-    int rc = ARVX_OK;
-    hipError_t e = hipMalloc(&d_tmp, ctx->nvox);
-    if (e == hipSuccess) e = hipMalloc(&d_bits, 2 * nwords * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc(&d_changed, sizeof(int));
-    if (e != hipSuccess) rc = arvx::fail_hip(e, "hipMalloc(fast carve)", __FILE__, __LINE__);
-    if (rc == ARVX_OK) {
-        fp.open = d_bits;
-        fp.reach = d_bits + nwords;
-        fp.changed = d_changed;
-        // carvable = what the dense carve clears on a fresh plane (not read: `fresh`)
+    const int tilesY = (fp.Y + 15) / 16, tilesZ = (fp.Z + 15) / 16;
+    const int tile_rows = tilesY * tilesZ;
+    const unsigned gflood = (unsigned)((size_t)fp.XW * tile_rows);
+    const bool prepass = fp.XW <= 64 && tile_rows <= arvx::kFloodMaxTileRows;
+    const bool by8 = (fp.X % 8 == 0);  // 8 voxels per thread, 8-byte accesses
+
+    // one work buffer, kept by the context: carvable plane | open, reach bit planes |
+    // whole-tile rows (full, reached) | wake flags (2 x tiles) | changed flag
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_bits = up(ctx->nvox);
+    const size_t o_tiles = o_bits + up(2 * nwords * sizeof(unsigned long long));
+    const size_t o_dirty = o_tiles + up(2 * (size_t)tile_rows * sizeof(unsigned long long));
+    const size_t o_changed = o_dirty + up(2 * (size_t)gflood);
+    const size_t need = o_changed + 256;
+    if (ctx->flood_bytes < need) {
+        if (ctx->d_flood) (void)hipFree(ctx->d_flood);
+        ctx->d_flood = nullptr;
+        ctx->flood_bytes = 0;
+        ARVX_HIP(hipMalloc(&ctx->d_flood, need));
+        ctx->flood_bytes = need;
     }
-    if (rc == ARVX_OK) rc = launch_carve(ctx, d_tmp, 0, ctx->V, 0, true);
-    if (rc == ARVX_OK) {
-        const unsigned gpack = (unsigned)((nwords + 3) / 4);
-        hipLaunchKernelGGL(arvx::flood_pack_open_kernel, dim3(gpack), dim3(256), 0, ctx->stream,
+    uint8_t *base = (uint8_t *)ctx->d_flood;
+    uint8_t *d_tmp = base;
+    fp.open = (unsigned long long *)(base + o_bits);
+    fp.reach = fp.open + nwords;
+    unsigned long long *d_tiles = (unsigned long long *)(base + o_tiles);
+    uint8_t *d_dirty = base + o_dirty;
+    fp.changed = (int *)(base + o_changed);
+    fp.dirty_cur = fp.dirty_next = nullptr;  // set per launch of flood_step_kernel
+
+    // carvable = what the dense carve clears on a fresh plane (not read: `fresh`)
+    if (int rc = launch_carve(ctx, d_tmp, 0, ctx->V, 0, true)) return rc;
+    if (by8) {
+        ARVX_HIP(hipMemsetAsync(fp.reach, 0, nwords * sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(arvx::flood_pack_open8_kernel,
+                           dim3((unsigned)((nwords * 8 + 255) / 256)), dim3(256), 0, ctx->stream,
                            d_tmp, ctx->d_state, fp);
-        const unsigned gflood =
-            (unsigned)((size_t)fp.XW * ((fp.Y + 15) / 16) * ((fp.Z + 15) / 16));
-        // every launch that is not the last grows at least one word; the flag is
-        // checked every 8 launches
-        const long max_batches = 16 + (long)gflood * 16;
-        for (long batch = 0; batch < max_batches && rc == ARVX_OK; ++batch) {
-            int changed = 0;
-            e = hipMemsetAsync(d_changed, 0, sizeof(int), ctx->stream);
-            for (int k = 0; k < 8 && e == hipSuccess; ++k) {
-                hipLaunchKernelGGL(arvx::flood_step_kernel, dim3(gflood), dim3(256), 0,
-                                   ctx->stream, fp);
-                e = hipGetLastError();
-            }
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(&changed, d_changed, sizeof(int), hipMemcpyDeviceToHost,
-                                   ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess) rc = arvx::fail_hip(e, "flood fill", __FILE__, __LINE__);
-            if (!changed) break;
-            if (batch + 1 == max_batches)
-                rc = fail(ARVX_ERR_HIP, "flood fill did not converge");
-        }
+    } else {
+        hipLaunchKernelGGL(arvx::flood_pack_open_kernel, dim3((unsigned)((nwords + 3) / 4)),
+                           dim3(256), 0, ctx->stream, d_tmp, ctx->d_state, fp);
     }
-    if (rc == ARVX_OK) {
+    ARVX_HIP(hipGetLastError());
+    // whole-tile pre-pass (fast_carve_kernels.h): seeds every completely open tile
+    // that is connected to the origin tile through completely open tiles
+    if (prepass) {
+        const size_t tile_bytes = 2 * (size_t)tile_rows * sizeof(unsigned long long);
+        ARVX_HIP(hipMemsetAsync(d_tiles, 0, tile_bytes, ctx->stream));
+        hipLaunchKernelGGL(arvx::flood_tile_full_kernel, dim3(gflood), dim3(256), 0, ctx->stream,
+                           fp, d_tiles);
+        hipLaunchKernelGGL(arvx::flood_tile_fill_kernel, dim3(1), dim3(1024), tile_bytes,
+                           ctx->stream, d_tiles, d_tiles + tile_rows, tilesY, tilesZ);
+        hipLaunchKernelGGL(arvx::flood_tile_seed_kernel, dim3(gflood), dim3(256), 0, ctx->stream,
+                           fp, d_tiles + tile_rows);
+        ARVX_HIP(hipGetLastError());
+    }
+    // per-tile wake flags, two buffers swapped every launch; all awake at first
+    ARVX_HIP(hipMemsetAsync(d_dirty, 1, gflood, ctx->stream));
+    ARVX_HIP(hipMemsetAsync(d_dirty + gflood, 0, gflood, ctx->stream));
+    // every launch that is not the last grows at least one word; the flag is read
+    // back after 2, 2, 4, 8, 8, ... launches
+    const long max_launches = 128 + (long)gflood * 256;
+    long launched = 0;
+    for (int batch = 2, round = 0;; ++round) {
+        int changed = 0;
+        ARVX_HIP(hipMemsetAsync(fp.changed, 0, sizeof(int), ctx->stream));
+        for (int k = 0; k < batch; ++k, ++launched) {
+            fp.dirty_cur = d_dirty + (launched & 1) * (size_t)gflood;
+            fp.dirty_next = d_dirty + ((launched + 1) & 1) * (size_t)gflood;
+            hipLaunchKernelGGL(arvx::flood_step_kernel, dim3(gflood), dim3(256), 0, ctx->stream,
+                               fp);
+            ARVX_HIP(hipGetLastError());
+        }
+        ARVX_HIP(hipMemcpyAsync(&changed, fp.changed, sizeof(int), hipMemcpyDeviceToHost,
+                                ctx->stream));
+        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+        if (!changed) break;
+        if (launched >= max_launches) return fail(ARVX_ERR_HIP, "flood fill did not converge");
+        if (round >= 1 && batch < 8) batch *= 2;
+    }
+    if (by8)
+        hipLaunchKernelGGL(arvx::flood_apply8_kernel, dim3((unsigned)((ctx->nvox / 8 + 255) / 256)),
+                           dim3(256), 0, ctx->stream, ctx->d_state, fp);
+    else
         hipLaunchKernelGGL(arvx::flood_apply_kernel, dim3((unsigned)((ctx->nvox + 255) / 256)),
                            dim3(256), 0, ctx->stream, ctx->d_state, fp);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) rc = arvx::fail_hip(e, "flood apply", __FILE__, __LINE__);
-    }
-    if (d_tmp) (void)hipFree(d_tmp);
-    if (d_bits) (void)hipFree(d_bits);
-    if (d_changed) (void)hipFree(d_changed);
-    return rc;
+    ARVX_HIP(hipGetLastError());
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    return ARVX_OK;
 }
 
 }  // extern "C"

@@ -41,6 +41,8 @@ struct Ctx {
     unsigned long long *d_stats = nullptr;
     void *d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    void *d_flood = nullptr;  // work buffer of arvx_fast_carve, kept between calls
+    size_t flood_bytes = 0;
 
     // views
     bool views_ready = false;
@@ -72,6 +74,17 @@ struct Ctx {
     bool closure_ready = false;
     int closure_unseen = 0;
     std::vector<int> h_clo_index;
+
+    // marching-cubes hand-off: active cells (x, y, z, cube index), reference order
+    void *d_mc_cells = nullptr;
+    int64_t mc_count = 0;
+    bool mc_ready = false;
+    void free_mc() {
+        if (d_mc_cells) (void)hipFree(d_mc_cells);
+        d_mc_cells = nullptr;
+        mc_count = 0;
+        mc_ready = false;
+    }
 
     void free_closure() {
         if (d_clo_index) (void)hipFree(d_clo_index);

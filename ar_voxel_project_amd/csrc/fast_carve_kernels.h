@@ -15,6 +15,14 @@
 // thread owns one word, fills it along x with a Kogge-Stone occluded fill, and
 // exchanges with its four row neighbours through LDS until its 64x16x16 tile
 // is stable; launches repeat until no tile changes.
+//
+// A front that moves one tile per launch would need as many launches as the grid
+// is wide in tiles.  Most of `open` is empty space far from the object, though:
+// tiles that are open in every voxel.  Two such tiles that share a face are
+// connected, so the component is first grown over WHOLE tiles (one bit per tile,
+// a row of tiles per 64-bit word, one workgroup, LDS only) and every tile reached
+// that way is seeded completely; the word-level launches then only have to enter
+// the partly open tiles around the object.
 #pragma once
 
 #include "arvx_device.h"
@@ -27,6 +35,8 @@ struct FloodParams {
     unsigned long long *open;
     unsigned long long *reach;
     int *changed;
+    uint8_t *dirty_cur;   // per tile: some word of the tile or of a face neighbour changed
+    uint8_t *dirty_next;  //           in the previous launch (flood_step_kernel)
 };
 
 // open = carvable & !seen0, one wave per (row, word)
@@ -51,6 +61,32 @@ __global__ __launch_bounds__(256) void flood_pack_open_kernel(const uint8_t *__r
     }
 }
 
+// The same for X % 8 == 0: one thread packs 8 voxels into one BYTE of the bit plane
+// (byte j of a little-endian 64-bit word = voxels 8j..8j+7), 8-byte loads, byte store.
+// Rows are padded to whole words; the padding bytes are written as zero.  `reach`
+// is cleared by the host; the thread of voxel (0,0,0) plants the seed.
+__global__ __launch_bounds__(256) void flood_pack_open8_kernel(const uint8_t *__restrict__ carved_tmp,
+                                                               const uint8_t *__restrict__ state,
+                                                               const FloodParams p) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int rowBytes = p.XW * 8;
+    const size_t nrows = (size_t)p.Y * p.Z;
+    if (t >= nrows * rowBytes) return;
+    const size_t row = t / rowBytes;
+    const int g = (int)(t % rowBytes);
+    uint8_t b = 0;
+    if (g * 8 < p.X) {
+        const size_t i = row * p.X + (size_t)g * 8;
+        const unsigned long long c = *(const unsigned long long *)(carved_tmp + i);
+        const unsigned long long s = *(const unsigned long long *)(state + i);
+        // open = carved on the fresh plane (bit0 clear) and not seen (bit1 clear)
+        const unsigned long long m = ~c & ~(s >> 1) & 0x0101010101010101ull;
+        b = (uint8_t)((m * 0x0102040810204080ull) >> 56);  // byte j's bit 0 -> bit j
+    }
+    ((uint8_t *)p.open)[t] = b;
+    if (t == 0) ((uint8_t *)p.reach)[0] = b & 1u;
+}
+
 __device__ __forceinline__ unsigned long long fill_row(unsigned long long seed,
                                                        unsigned long long open) {
     // Kogge-Stone occluded fill, both directions, within one 64-voxel word
@@ -72,6 +108,83 @@ __device__ __forceinline__ unsigned long long fill_row(unsigned long long seed,
     return g | h;
 }
 
+// ---- whole-tile pre-pass ---------------------------------------------------------------
+
+constexpr int kFloodMaxTileRows = 4096;  // rows of tiles (tilesY * tilesZ): 2 words each = 64 KB of LDS
+
+// full[(bz * tilesY + by)] bit xw = every voxel of tile (xw, by, bz) that lies inside
+// the grid is open.  One workgroup per tile, thread = one 64-voxel word.
+__global__ __launch_bounds__(256) void flood_tile_full_kernel(const FloodParams p,
+                                                              unsigned long long *__restrict__ full) {
+    const int ty = threadIdx.x & 15, tz = threadIdx.x >> 4;
+    const int tilesY = (p.Y + 15) >> 4;
+    const int xw = blockIdx.x % p.XW;
+    const int by = (blockIdx.x / p.XW) % tilesY;
+    const int bz = blockIdx.x / (p.XW * tilesY);
+    const int y = by * 16 + ty, z = bz * 16 + tz;
+    bool f = true;
+    if (y < p.Y && z < p.Z) {
+        const int nbits = min(64, p.X - xw * 64);
+        const unsigned long long want = (nbits == 64) ? ~0ull : ((1ull << nbits) - 1ull);
+        f = p.open[((size_t)z * p.Y + y) * p.XW + xw] == want;
+    }
+    if (__syncthreads_and(f) && threadIdx.x == 0)
+        atomicOr(&full[(size_t)bz * tilesY + by], 1ull << xw);
+}
+
+// Component of the tile (0,0,0) among the full tiles, 6-connected.  ONE workgroup;
+// rows of tiles live in LDS as 64-bit words (bit = tile along x).  reached[] is
+// written for every row.  Requires XW <= 64 and tilesY*tilesZ <= kFloodMaxTileRows.
+__global__ __launch_bounds__(1024) void flood_tile_fill_kernel(
+    const unsigned long long *__restrict__ full, unsigned long long *__restrict__ reached,
+    int tilesY, int tilesZ) {
+    extern __shared__ unsigned long long lds[];  // [rows] full, then [rows] reached
+    const int rows = tilesY * tilesZ;
+    unsigned long long *f = lds, *r = lds + rows;
+    for (int i = threadIdx.x; i < rows; i += 1024) {
+        f[i] = full[i];
+        r[i] = 0ull;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) r[0] = f[0] & 1ull;  // seed: the tile of voxel (0,0,0), if full
+    __syncthreads();
+    // every round that reports a change adds at least one tile, so this ends
+    for (;;) {
+        int ch = 0;
+        for (int i = threadIdx.x; i < rows; i += 1024) {
+            const int by = i % tilesY, bz = i / tilesY;
+            unsigned long long in = r[i];
+            if (by > 0) in |= r[i - 1];
+            if (by + 1 < tilesY) in |= r[i + 1];
+            if (bz > 0) in |= r[i - tilesY];
+            if (bz + 1 < tilesZ) in |= r[i + tilesY];
+            const unsigned long long rn = fill_row(f[i] & in, f[i]);
+            if (rn != r[i]) {
+                r[i] = rn;  // racing readers see the old or the new word: both are sound
+                ch = 1;
+            }
+        }
+        if (!__syncthreads_or(ch)) break;
+    }
+    for (int i = threadIdx.x; i < rows; i += 1024) reached[i] = r[i];
+}
+
+// reach = open in every tile the pre-pass reached
+__global__ __launch_bounds__(256) void flood_tile_seed_kernel(
+    const FloodParams p, const unsigned long long *__restrict__ reached) {
+    const int ty = threadIdx.x & 15, tz = threadIdx.x >> 4;
+    const int tilesY = (p.Y + 15) >> 4;
+    const int xw = blockIdx.x % p.XW;
+    const int by = (blockIdx.x / p.XW) % tilesY;
+    const int bz = blockIdx.x / (p.XW * tilesY);
+    if (!((reached[(size_t)bz * tilesY + by] >> xw) & 1ull)) return;
+    const int y = by * 16 + ty, z = bz * 16 + tz;
+    if (y < p.Y && z < p.Z) {
+        const size_t w = ((size_t)z * p.Y + y) * p.XW + xw;
+        p.reach[w] = p.open[w];
+    }
+}
+
 __global__ __launch_bounds__(256) void flood_step_kernel(const FloodParams p) {
     __shared__ unsigned long long tile[18][18];  // [z][y] with a one-row halo
     const int ty = threadIdx.x & 15, tz = threadIdx.x >> 4;
@@ -79,6 +192,10 @@ __global__ __launch_bounds__(256) void flood_step_kernel(const FloodParams p) {
     const int xw = blockIdx.x % p.XW;
     const int by = (blockIdx.x / p.XW) % tilesY;
     const int bz = blockIdx.x / (p.XW * tilesY);
+    // nothing that this tile reads changed in the previous launch: it is stable
+    if (!p.dirty_cur[blockIdx.x]) return;
+    __syncthreads();  // every thread has read the flag
+    if (threadIdx.x == 0) p.dirty_cur[blockIdx.x] = 0;  // this buffer is "next" two launches on
     const int y = by * 16 + ty, z = bz * 16 + tz;
     const bool ok = (y < p.Y) && (z < p.Z);
     auto word = [&](const unsigned long long *a, int yy, int zz, int xx) -> unsigned long long {
@@ -108,9 +225,17 @@ __global__ __launch_bounds__(256) void flood_step_kernel(const FloodParams p) {
         tile[tz + 1][ty + 1] = r;
         if (!__syncthreads_or(ch)) break;
     }
-    if (ok && r != r0) {
-        p.reach[((size_t)z * p.Y + y) * p.XW + xw] = r;
-        *p.changed = 1;
+    const bool mine = ok && r != r0;
+    if (mine) p.reach[((size_t)z * p.Y + y) * p.XW + xw] = r;
+    if (__syncthreads_or(mine) && threadIdx.x < 7) {
+        // wake this tile and its face neighbours for the next launch
+        const int tilesZ = (p.Z + 15) >> 4;
+        const int dx[7] = {0, -1, 1, 0, 0, 0, 0}, dy[7] = {0, 0, 0, -1, 1, 0, 0},
+                  dz[7] = {0, 0, 0, 0, 0, -1, 1};
+        const int nx = xw + dx[threadIdx.x], ny = by + dy[threadIdx.x], nz = bz + dz[threadIdx.x];
+        if (nx >= 0 && nx < p.XW && ny >= 0 && ny < tilesY && nz >= 0 && nz < tilesZ)
+            p.dirty_next[((size_t)nz * tilesY + ny) * p.XW + nx] = 1;
+        if (threadIdx.x == 0) *p.changed = 1;
     }
 }
 
@@ -136,6 +261,40 @@ __global__ __launch_bounds__(256) void flood_apply_kernel(uint8_t *__restrict__ 
         if (nb || i == 0) s |= 2u;  // pushed by a carved neighbour (:132-163) or the seed (:100)
     }
     state[i] = s;
+}
+
+// The same for X % 8 == 0: one thread owns the 8 voxels of one byte of the bit plane.
+__global__ __launch_bounds__(256) void flood_apply8_kernel(uint8_t *__restrict__ state,
+                                                           const FloodParams p) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int rowBytes = p.XW * 8, gmax = p.X / 8;
+    const size_t nrows = (size_t)p.Y * p.Z;
+    if (t >= nrows * gmax) return;
+    const size_t row = t / gmax;
+    const int g = (int)(t % gmax);
+    const int y = (int)(row % p.Y), z = (int)(row / p.Y);
+    const uint8_t *rb = (const uint8_t *)p.reach + row * rowBytes + g;
+    const unsigned e = rb[0];
+    unsigned nb = ((e << 1) | (e >> 1)) & 0xFFu;
+    if (g > 0) nb |= rb[-1] >> 7;
+    if (g + 1 < gmax) nb |= (rb[1] & 1u) << 7;
+    if (y > 0) nb |= rb[-(ptrdiff_t)rowBytes];
+    if (y + 1 < p.Y) nb |= rb[rowBytes];
+    if (z > 0) nb |= rb[-(ptrdiff_t)rowBytes * p.Y];
+    if (z + 1 < p.Z) nb |= rb[(ptrdiff_t)rowBytes * p.Y];
+    if (t == 0) nb |= 1u;  // the seed is visited whatever happens (:100)
+    if ((e | nb) == 0u) return;
+    // bit j -> 0x01 in byte j
+    auto spread = [](unsigned b) -> unsigned long long {
+        const unsigned long long v = (b * 0x0101010101010101ull) & 0x8040201008040201ull;
+        return ((v + 0x7F7F7F7F7F7F7F7Full) >> 7) & 0x0101010101010101ull;
+    };
+    unsigned long long *sp = (unsigned long long *)(state + row * p.X + (size_t)g * 8);
+    const unsigned long long s = *sp;
+    const unsigned long long E = spread(e), N = spread(nb);
+    // carved: clear bit0, set bit1; pushed by a carved neighbour: set bit1
+    const unsigned long long ns = (s & ~E) | ((E | N) << 1);
+    if (ns != s) *sp = ns;
 }
 
 }  // namespace arvx

@@ -57,6 +57,18 @@ def stripe_planes(Z: int, world: int, rank: int):
     return [g * 8 + k for g in range(rank, Z // 8, world) for k in range(8)]
 
 
+def merge_mc_cells(per_rank):
+    """Marching-cubes cell lists of the slab contexts (Context.mc_cells, one (n,4)
+    array per rank) -> one list in the reference's visiting order (x outermost,
+    then y, then z; src/MarchingCubes.cpp:12-18).  Slabs own disjoint z ranges, so
+    this is a stable sort of the concatenation by (x, y, z)."""
+    import numpy as np
+    parts = [np.asarray(c, np.int32).reshape(-1, 4) for c in per_rank]
+    cells = np.concatenate(parts) if parts else np.zeros((0, 4), np.int32)
+    order = np.lexsort((cells[:, 2], cells[:, 1], cells[:, 0]))
+    return cells[order]
+
+
 def words_of(nvox: int) -> int:
     return (nvox + 31) // 32
 

@@ -188,6 +188,21 @@ int arvx_closure_count(arvx_ctx *ctx, int64_t *count);
 /* Filled voxels, ascending flat index, 4 floats RGBA each. */
 int arvx_closure_download(arvx_ctx *ctx, int64_t *index, float *rgba);
 
+/* Marching-cubes hand-off.  The reference's marchingCubes() visits every cell
+ * (x,y,z) of [-1,X) x [-1,Y) x [-1,Z), x outermost and z innermost
+ * (src/MarchingCubes.cpp:12-18); a cell emits triangles only when its cube index
+ * -- bit i set when corner i (order of src/MarchingCubes.h:537-552) is not part
+ * of the model, :479-484 -- is neither 0 nor 255 (:486-488).  arvx_mc_cells
+ * finds those cells on the device from the current occupancy and returns how
+ * many there are; arvx_mc_cells_download copies them out, 4 ints per cell
+ * (x, y, z, cube index), in the reference's visiting order, so that calling
+ * ProcessVoxel on this list alone builds the same mesh.  Slab contexts list the
+ * cells whose upper plane they own (global z; the last slab also those above the
+ * grid); striped contexts are refused.  Valid for 0 < threshold <= 1, which
+ * covers the 0.5 every reference call site passes. */
+int arvx_mc_cells(arvx_ctx *ctx, int64_t *count);
+int arvx_mc_cells_download(arvx_ctx *ctx, int32_t *cells);
+
 /* Model::voxels as the reference would hold it after carve [+ colour]
  * [+ handleUnseen]: n*4 floats (RGBA), n = slab voxels. */
 int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen);

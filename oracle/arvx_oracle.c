@@ -441,3 +441,39 @@ void arvx_oracle_closure(int X, int Y, int Z, float *rgba) {
             }
     free(temp);
 }
+
+/* Model::get, src/Model.h:119-124: w of a voxel, zero outside the grid. */
+static float w_at(int X, int Y, int Z, const float *rgba, int x, int y, int z) {
+    if (x < 0 || x >= X || y < 0 || y >= Y || z < 0 || z >= Z) return 0.f;
+    return rgba[4 * ((size_t)x + (size_t)X * ((size_t)y + (size_t)Y * z)) + 3];
+}
+
+/* The cell walk of marchingCubes (src/MarchingCubes.cpp:12-18: x, then y, then
+ * z, each from -1), the corner order of ProcessVoxel (src/MarchingCubes.h:537-552)
+ * and the cube index of Polygonise (:479-484).  A cell whose edgeTable entry is
+ * zero returns before it emits anything (:486-488); the table holds zero at
+ * index 0 and 255 only. */
+long arvx_oracle_mc_cells(int X, int Y, int Z, const float *rgba, float threshold,
+                          int32_t *cells, long cap) {
+    static const int corner[8][3] = {{1, 0, 0}, {0, 0, 0}, {0, 1, 0}, {1, 1, 0},
+                                     {1, 0, 1}, {0, 0, 1}, {0, 1, 1}, {1, 1, 1}};
+    long n = 0;
+    for (int x = -1; x < X; x++)
+        for (int y = -1; y < Y; y++)
+            for (int z = -1; z < Z; z++) {
+                int idx = 0;
+                for (int i = 0; i < 8; i++)
+                    if (w_at(X, Y, Z, rgba, x + corner[i][0], y + corner[i][1],
+                             z + corner[i][2]) < threshold)
+                        idx |= 1 << i;
+                if (idx == 0 || idx == 255) continue;
+                if (n < cap) {
+                    cells[4 * n + 0] = x;
+                    cells[4 * n + 1] = y;
+                    cells[4 * n + 2] = z;
+                    cells[4 * n + 3] = idx;
+                }
+                n++;
+            }
+    return n;
+}

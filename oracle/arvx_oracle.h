@@ -94,6 +94,12 @@ float arvx_oracle_depth(const float campos[3], float s, int x, int y, int z);
 /* 3x3x3 closure (applyClosure with thresh=0: dilation with colour mean). */
 void arvx_oracle_closure(int X, int Y, int Z, float *rgba);
 
+/* Cells marchingCubes() would triangulate (cube index not 0/255), in its
+ * visiting order; 4 ints per cell (x, y, z, cube index).  Returns the number of
+ * such cells; writes at most `cap` of them. */
+long arvx_oracle_mc_cells(int X, int Y, int Z, const float *rgba, float threshold,
+                          int32_t *cells, long cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -160,3 +160,14 @@ def closure(X, Y, Z, rgba):
     out = _f32(rgba).copy()
     lib().arvx_oracle_closure(X, Y, Z, _p(out))
     return out
+
+
+def mc_cells(X, Y, Z, rgba, threshold=0.5):
+    """(n, 4) int32: x, y, z, cube index of the cells marchingCubes triangulates."""
+    r = _f32(rgba)
+    L = lib()
+    L.arvx_oracle_mc_cells.restype = C.c_long
+    n = L.arvx_oracle_mc_cells(X, Y, Z, _p(r), C.c_float(threshold), None, C.c_long(0))
+    out = np.zeros((max(n, 1), 4), np.int32)
+    L.arvx_oracle_mc_cells(X, Y, Z, _p(r), C.c_float(threshold), _p(out), C.c_long(n))
+    return out[:n]

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "arvx/calibration.hpp"
+#include "arvx/marching_cubes.hpp"
 #include "arvx/postprocessing.hpp"
 #include "arvx/voxel_carving.hpp"
 
@@ -97,6 +98,7 @@ static int run_carve(const char *scene, const char *out, const char *mode) {
                 if (b & 2) model.see(x, y, z);
             }
     int hooks = 0;
+    std::vector<arvx::McCell> cells;
     try {
         if (!std::strcmp(mode, "carve")) arvx::carve(intr, model, views);
         else if (!std::strcmp(mode, "carve_steps"))
@@ -115,6 +117,12 @@ static int run_carve(const char *scene, const char *out, const char *mode) {
             model.handleUnseen();
             if (arvx::applyClosure(&model, 3) != 0) return 5;
             if (arvx::applyClosure(&model, 4) != -1) return 6;  // even size: skipped
+        } else if (!std::strcmp(mode, "closure_mc")) {  // ... src/main.cpp:303
+            arvx::carve(intr, model, views);
+            arvx::reconstructAvgColor(intr, model, views);
+            model.handleUnseen();
+            if (arvx::applyClosure(&model, 3) != 0) return 5;
+            cells = arvx::marchingCubesCells(model);
         } else { std::fprintf(stderr, "unknown mode %s\n", mode); return 2; }
     } catch (const arvx::Error &e) {
         std::fprintf(stderr, "arvx::Error %d: %s\n", e.code, e.what());
@@ -135,6 +143,10 @@ static int run_carve(const char *scene, const char *out, const char *mode) {
                 char b = model.visited(Vec3i(x, y, z)) ? 1 : 0;
                 o.write(&b, 1);
             }
+    // then the marching-cubes cells (closure_mc): int32 count, 4 ints each
+    const int32_t nc = (int32_t)cells.size();
+    o.write((const char *)&nc, 4);
+    o.write((const char *)cells.data(), (std::streamsize)(cells.size() * sizeof(arvx::McCell)));
     return 0;
 }
 

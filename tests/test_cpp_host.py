@@ -57,7 +57,7 @@ def read_result(path, n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["carve", "carve_steps", "closest", "average_unseen", "fast",
-                                  "closure"])
+                                  "closure", "closure_mc"])
 def test_cpp_entry_points_match_oracle(host_bin, oracle, tmp_path, mode):
     X, Y, Z, V = 30, 20, 12, 5
     sc = scenes.syn.sphere_scene(32, V, W=96, H=72, with_images=True)
@@ -80,14 +80,19 @@ def test_cpp_entry_points_match_oracle(host_bin, oracle, tmp_path, mode):
     if mode == "closest":
         want = oracle.color(X, Y, Z, s, M, sc.campos, sc.images, 0, want)
         assert "LOG - CR: starting color reconstruction (closest color)." in r.stdout
-    if mode in ("average_unseen", "closure"):
+    if mode in ("average_unseen", "closure", "closure_mc"):
         want = oracle.color(X, Y, Z, s, M, sc.campos, sc.images, 1, want)
         want = oracle.handle_unseen(st, want)
-    if mode == "closure":
+    if mode in ("closure", "closure_mc"):
         want = oracle.closure(X, Y, Z, want)
         assert "LOG - PP: starting dilution." in r.stdout
     assert np.array_equal(seen, (st.reshape(-1) & 2) == 2)
     assert np.array_equal(rgba, want)
+    if mode == "closure_mc":  # the cells the reference's marchingCubes would triangulate
+        raw = np.fromfile(out, np.uint8)[17 * X * Y * Z:]
+        n = int(raw[:4].view(np.int32)[0])
+        cells = raw[4:4 + 16 * n].view(np.int32).reshape(n, 4)
+        assert n > 0 and np.array_equal(cells, oracle.mc_cells(X, Y, Z, want))
 
 
 @pytest.mark.gpu

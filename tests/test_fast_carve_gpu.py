@@ -58,6 +58,27 @@ def test_fast_carve_respects_previsited_walls(arvx, oracle):
     assert_same(gpu_fast(arvx, N, N, N, sc.voxel_size, sc.M, sc.masks, state=st1), want, "dead")
 
 
+@pytest.mark.parametrize("hole", [False, True])
+def test_fast_carve_whole_tile_prepass_is_blocked_by_walls(arvx, oracle, hole):
+    """Many 64x16x16 tiles are completely open here, on both sides of a seen wall: the
+    whole-tile pre-pass may only take the side of the origin; the far side is reached
+    through the hole (a partly open tile) or not at all."""
+    X, Y, Z, V, W, H = 192, 48, 96, 4, 160, 120
+    sc = scenes.small_sphere(32, V, W=W, H=H)
+    masks = sc.masks.copy()
+    masks[:, :, :] = 0  # background everywhere: every voxel some view sees is carvable
+    s = np.float32(0.512 / X)
+    st0 = np.full((Z, Y, X), 1, np.uint8)
+    st0[40, :, :] |= 2  # wall: plane z = 40 already visited
+    if hole:
+        st0[40, 30, 100] = 1
+    want = oracle.fast_carve(X, Y, Z, s, sc.M, masks, state=st0)
+    got = gpu_fast(arvx, X, Y, Z, s, sc.M, masks, state=st0)
+    assert_same(got, want, f"wall hole={hole}")
+    beyond = (want[41:] & 1) == 0
+    assert beyond.any() == hole  # the far side is carved only through the hole
+
+
 def test_fast_carve_origin_not_carvable(arvx, oracle):
     N, V, W, H = 24, 3, 96, 72
     sc = scenes.small_sphere(N, V, W=W, H=H)

@@ -231,3 +231,44 @@ def test_oracle_reproduces_golden(oracle, name):
 
 def test_golden_fixtures_exist():
     assert set(golden_io.names()) >= {"sphere32", "box50x50x25", "noise24"}
+
+
+# ---- marching-cubes cell walk (src/MarchingCubes.cpp:12-18, MarchingCubes.h:479-488,537-552)
+
+def np_mc_cells(st):
+    """Independent numpy restatement: pad with empty, combine the 8 corner planes."""
+    Z, Y, X = st.shape
+    occ = np.zeros((Z + 2, Y + 2, X + 2), bool)
+    occ[1:-1, 1:-1, 1:-1] = (st & 1) == 1
+    corner = [(1, 0, 0), (0, 0, 0), (0, 1, 0), (1, 1, 0), (1, 0, 1), (0, 0, 1), (0, 1, 1), (1, 1, 1)]
+    idx = np.zeros((Z + 1, Y + 1, X + 1), np.int32)
+    for i, (dx, dy, dz) in enumerate(corner):
+        idx |= (~occ[dz:dz + Z + 1, dy:dy + Y + 1, dx:dx + X + 1]).astype(np.int32) << i
+    zz, yy, xx = np.nonzero((idx != 0) & (idx != 255))
+    order = np.lexsort((zz, yy, xx))  # x outermost, z innermost
+    zz, yy, xx = zz[order], yy[order], xx[order]
+    return np.stack([xx - 1, yy - 1, zz - 1, idx[zz, yy, xx]], axis=1).astype(np.int32)
+
+
+def test_mc_cells_oracle_matches_numpy(oracle):
+    rng = np.random.default_rng(11)
+    for dims, fill in [((5, 4, 3), 0.4), ((16, 9, 12), 0.1), ((7, 7, 7), 1.0), ((6, 5, 4), 0.0)]:
+        X, Y, Z = dims
+        st = np.where(rng.random((Z, Y, X)) < fill, 3, 2).astype(np.uint8)
+        got = oracle.mc_cells(X, Y, Z, oracle.model_from_state(st))
+        assert np.array_equal(got, np_mc_cells(st))
+
+
+def test_mc_cells_oracle_threshold_and_colours(oracle):
+    """The walk looks at w only: colours do not matter, and any threshold in (0,1]
+    gives the same cells as the 0.5 the reference passes."""
+    rng = np.random.default_rng(12)
+    X, Y, Z = 9, 8, 7
+    st = np.where(rng.random((Z, Y, X)) < 0.3, 3, 2).astype(np.uint8)
+    model = oracle.model_from_state(st)
+    base = oracle.mc_cells(X, Y, Z, model)
+    painted = model.copy()
+    painted[:, :3] = rng.integers(0, 256, size=(X * Y * Z, 3))
+    assert np.array_equal(oracle.mc_cells(X, Y, Z, painted), base)
+    for thr in (0.01, 0.5, 1.0):
+        assert np.array_equal(oracle.mc_cells(X, Y, Z, model, thr), base)
