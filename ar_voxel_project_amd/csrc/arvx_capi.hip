@@ -17,6 +17,7 @@
 #include "carve_kernels.h"
 #include "color_kernels.h"
 #include "closure_kernels.h"
+#include "bitplane_kernels.h"
 #include "fast_carve_kernels.h"
 #include "mc_kernels.h"
 #include <algorithm>
@@ -51,6 +52,57 @@ using arvx::Ctx;
         if (!(ctx)) return fail(ARVX_ERR_INVALID, "null context");   \
         ARVX_HIP(hipSetDevice((ctx)->device));                       \
     } while (0)
+
+// ---- bit-plane helpers (bitplane_kernels.h) ----------------------------------------------
+
+static int ensure_scratch(Ctx *ctx, size_t need) {
+    if (ctx->scratch_bytes >= need) return ARVX_OK;
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    ctx->d_scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    ARVX_HIP(hipMalloc(&ctx->d_scratch, need));
+    ctx->scratch_bytes = need;
+    return ARVX_OK;
+}
+
+template <int PRED>
+static int launch_bit_pack(Ctx *ctx, const uint8_t *state, const arvx::BitGrid &g,
+                           int apply_unseen, unsigned long long *bits) {
+    const size_t nwords = (size_t)g.XW * g.Y * g.Z;
+    if (g.X % 8 == 0)
+        hipLaunchKernelGGL(arvx::bit_pack8_kernel<PRED>, dim3((unsigned)((nwords * 8 + 255) / 256)),
+                           dim3(256), 0, ctx->stream, state, g, apply_unseen, bits);
+    else
+        hipLaunchKernelGGL(arvx::bit_pack_kernel<PRED>, dim3((unsigned)((nwords + 3) / 4)),
+                           dim3(256), 0, ctx->stream, state, g, apply_unseen, bits);
+    ARVX_HIP(hipGetLastError());
+    return ARVX_OK;
+}
+
+// counts the set bits per block and scans the counts; *total = number of set bits
+static int bit_compact_count(Ctx *ctx, const unsigned long long *bits, size_t nwords, int *d_cnt,
+                             long long *d_off, long long *total) {
+    const int nblk = (int)((nwords + arvx::kBitChunk - 1) / arvx::kBitChunk);
+    hipLaunchKernelGGL(arvx::bit_count_kernel, dim3(nblk), dim3(256), 0, ctx->stream, bits, nwords,
+                       d_cnt);
+    ARVX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(arvx::surface_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, d_cnt, nblk,
+                       d_off);
+    ARVX_HIP(hipGetLastError());
+    ARVX_HIP(hipMemcpyAsync(total, d_off + nblk, sizeof *total, hipMemcpyDeviceToHost,
+                            ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    return ARVX_OK;
+}
+
+static int bit_compact_write(Ctx *ctx, const unsigned long long *bits, size_t nwords,
+                             const arvx::BitGrid &g, const long long *d_off, int *d_index) {
+    const int nblk = (int)((nwords + arvx::kBitChunk - 1) / arvx::kBitChunk);
+    hipLaunchKernelGGL(arvx::bit_write_kernel, dim3(nblk), dim3(256), 0, ctx->stream, bits, nwords,
+                       g, d_off, d_index);
+    ARVX_HIP(hipGetLastError());
+    return ARVX_OK;
+}
 
 extern "C" {
 
@@ -161,6 +213,7 @@ int arvx_ctx_destroy(arvx_ctx *ctx) {
     ctx->free_views();
     ctx->free_color();
     ctx->free_mc();
+    ctx->release_pools();
     if (ctx->d_flood) (void)hipFree(ctx->d_flood);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
@@ -589,44 +642,39 @@ int arvx_color(arvx_ctx *ctx, int mode) {
     if (ctx->stripe_world > 1)
         return fail(ARVX_ERR_STATE, "the colour pass needs contiguous slabs (neighbour planes)");
     ctx->free_surface();
-    arvx::SurfaceParams sp;
-    sp.state_ext = ctx->d_state;
-    sp.X = ctx->X;
-    sp.Y = ctx->Y;
-    sp.Zown = ctx->z1 - ctx->z0;
-    sp.halo_lo = ctx->z0 - ctx->ze0;
-    sp.Zext = ctx->ze1 - ctx->ze0;
-    sp.nown = ctx->nvox;
-    const int nblk = (int)((ctx->nvox + arvx::kSurfChunk - 1) / arvx::kSurfChunk);
-    const size_t need = (size_t)nblk * sizeof(int) + (size_t)(nblk + 1) * sizeof(long long) + 64;
-    if (ctx->scratch_bytes < need) {
-        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
-        ctx->d_scratch = nullptr;
-        ctx->scratch_bytes = 0;
-        ARVX_HIP(hipMalloc(&ctx->d_scratch, need));
-        ctx->scratch_bytes = need;
-    }
-    long long *d_off = (long long *)ctx->d_scratch;
+    // surface = occupied and not inner, on bit planes; the halo planes of a slab take
+    // part as neighbours only
+    const int XW = (ctx->X + 63) / 64;
+    const int Zown = ctx->z1 - ctx->z0, Zext = ctx->ze1 - ctx->ze0;
+    const arvx::BitGrid gext{ctx->X, ctx->Y, Zext, XW}, gown{ctx->X, ctx->Y, Zown, XW};
+    const size_t nw_ext = (size_t)XW * ctx->Y * Zext, nw_own = (size_t)XW * ctx->Y * Zown;
+    const int nblk = (int)((nw_own + arvx::kBitChunk - 1) / arvx::kBitChunk);
+    if (int rc = ensure_scratch(ctx, (nw_ext + nw_own) * sizeof(unsigned long long) +
+                                         (size_t)(nblk + 1) * sizeof(long long) +
+                                         (size_t)nblk * sizeof(int) + 64))
+        return rc;
+    unsigned long long *d_occ = (unsigned long long *)ctx->d_scratch;
+    unsigned long long *d_surf = d_occ + nw_ext;
+    long long *d_off = (long long *)(d_surf + nw_own);
     int *d_cnt = (int *)(d_off + nblk + 1);
-    hipLaunchKernelGGL(arvx::surface_count_kernel, dim3(nblk), dim3(256), 0, ctx->stream, sp,
-                       d_cnt);
-    ARVX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(arvx::surface_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, d_cnt, nblk,
-                       d_off);
+    if (int rc = launch_bit_pack<arvx::kBitOccupied>(ctx, ctx->d_state, gext, 0, d_occ)) return rc;
+    hipLaunchKernelGGL(arvx::bit_surface_kernel, dim3((unsigned)((nw_own + 255) / 256)), dim3(256),
+                       0, ctx->stream, d_occ, gext, ctx->z0 - ctx->ze0, Zown, d_surf);
     ARVX_HIP(hipGetLastError());
     long long total = 0;
-    ARVX_HIP(hipMemcpyAsync(&total, d_off + nblk, sizeof total, hipMemcpyDeviceToHost,
-                            ctx->stream));
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    if (int rc = bit_compact_count(ctx, d_surf, nw_own, d_cnt, d_off, &total)) return rc;
     ctx->surf_count = total;
     if (total > 0) {
-        ARVX_HIP(hipMalloc(&ctx->d_surf_index, (size_t)total * sizeof(int)));
-        ARVX_HIP(hipMalloc(&ctx->d_surf_rgb, (size_t)total * 3 * sizeof(float)));
-        ARVX_HIP(hipMalloc(&ctx->d_surf_depth, (size_t)total * sizeof(float)));
-        ARVX_HIP(hipMalloc(&ctx->d_surf_has, (size_t)total));
-        hipLaunchKernelGGL(arvx::surface_write_kernel, dim3(nblk), dim3(256), 0, ctx->stream, sp,
-                           d_off, ctx->d_surf_index);
-        ARVX_HIP(hipGetLastError());
+        ARVX_HIP(ctx->pool_surf_index.reserve((size_t)total * sizeof(int)));
+        ctx->d_surf_index = (int *)ctx->pool_surf_index.p;
+        ARVX_HIP(ctx->pool_surf_rgb.reserve((size_t)total * 3 * sizeof(float)));
+        ctx->d_surf_rgb = (float *)ctx->pool_surf_rgb.p;
+        ARVX_HIP(ctx->pool_surf_depth.reserve((size_t)total * sizeof(float)));
+        ctx->d_surf_depth = (float *)ctx->pool_surf_depth.p;
+        ARVX_HIP(ctx->pool_surf_has.reserve((size_t)total));
+        ctx->d_surf_has = (uint8_t *)ctx->pool_surf_has.p;
+        if (int rc = bit_compact_write(ctx, d_surf, nw_own, gown, d_off, ctx->d_surf_index))
+            return rc;
         arvx::VoteParams vp;
         vp.index = ctx->d_surf_index;
         vp.n = total;
@@ -828,10 +876,14 @@ int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const flo
     ctx->h_surf_index = idx;
     ctx->h_surf_has.assign((size_t)n, 1);
     if (n > 0) {
-        ARVX_HIP(hipMalloc(&ctx->d_surf_index, (size_t)n * sizeof(int)));
-        ARVX_HIP(hipMalloc(&ctx->d_surf_rgb, (size_t)n * 3 * sizeof(float)));
-        ARVX_HIP(hipMalloc(&ctx->d_surf_depth, (size_t)n * sizeof(float)));
-        ARVX_HIP(hipMalloc(&ctx->d_surf_has, (size_t)n));
+        ARVX_HIP(ctx->pool_surf_index.reserve((size_t)n * sizeof(int)));
+        ctx->d_surf_index = (int *)ctx->pool_surf_index.p;
+        ARVX_HIP(ctx->pool_surf_rgb.reserve((size_t)n * 3 * sizeof(float)));
+        ctx->d_surf_rgb = (float *)ctx->pool_surf_rgb.p;
+        ARVX_HIP(ctx->pool_surf_depth.reserve((size_t)n * sizeof(float)));
+        ctx->d_surf_depth = (float *)ctx->pool_surf_depth.p;
+        ARVX_HIP(ctx->pool_surf_has.reserve((size_t)n));
+        ctx->d_surf_has = (uint8_t *)ctx->pool_surf_has.p;
         ARVX_HIP(hipMemcpyAsync(ctx->d_surf_index, idx.data(), (size_t)n * sizeof(int),
                                 hipMemcpyHostToDevice, ctx->stream));
         ARVX_HIP(hipMemcpyAsync(ctx->d_surf_rgb, rgb, (size_t)n * 3 * sizeof(float),
@@ -865,50 +917,48 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     cp.col_rgb = ctx->color_ready ? ctx->d_surf_rgb : nullptr;
     cp.col_has = ctx->color_ready ? ctx->d_surf_has : nullptr;
     cp.ncol = ctx->color_ready ? ctx->surf_count : 0;
-    const int nblk = (int)((ctx->nvox + arvx::kSurfChunk - 1) / arvx::kSurfChunk);
-    cp.tX = (cp.X + 7) / 8;
-    cp.tY = (cp.Y + 7) / 8;
-    cp.tZ = (cp.Z + 7) / 8;
-    const size_t ntile = (size_t)cp.tX * cp.tY * cp.tZ;
+    // filled = dilate(occupied, box of radius r) and not occupied, on bit planes
+    const int XW = (cp.X + 63) / 64;
+    const arvx::BitGrid g{cp.X, cp.Y, cp.Z, XW};
+    const size_t nwords = (size_t)XW * cp.Y * cp.Z;
+    const int nblk = (int)((nwords + arvx::kBitChunk - 1) / arvx::kBitChunk);
     const size_t nrows = (size_t)cp.Y * cp.Z;
-    const size_t off_rows = ((size_t)nblk * sizeof(int) + (size_t)(nblk + 1) * sizeof(long long) +
-                             64 + ntile + 63) / 64 * 64;
-    const size_t need = off_rows + (nrows + 1) * sizeof(int);
-    if (ctx->scratch_bytes < need) {
-        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
-        ctx->d_scratch = nullptr;
-        ctx->scratch_bytes = 0;
-        ARVX_HIP(hipMalloc(&ctx->d_scratch, need));
-        ctx->scratch_bytes = need;
-    }
-    long long *d_off = (long long *)ctx->d_scratch;
+    if (int rc = ensure_scratch(ctx, 3 * nwords * sizeof(unsigned long long) +
+                                         (size_t)(nblk + 1) * sizeof(long long) +
+                                         (size_t)(nblk + nrows + 1) * sizeof(int) + 64))
+        return rc;
+    unsigned long long *d_occ = (unsigned long long *)ctx->d_scratch;
+    unsigned long long *d_a = d_occ + nwords, *d_b = d_a + nwords;
+    long long *d_off = (long long *)(d_b + nwords);
     int *d_cnt = (int *)(d_off + nblk + 1);
-    uint8_t *d_tiles = (uint8_t *)(d_cnt + nblk + 8);
-    cp.tile_any = d_tiles;
-    int *d_rows = (int *)((uint8_t *)ctx->d_scratch + off_rows);
+    int *d_rows = d_cnt + nblk;
     cp.row_start = d_rows;
     hipLaunchKernelGGL(arvx::closure_rows_kernel, dim3((unsigned)((nrows + 256) / 256)), dim3(256),
                        0, ctx->stream, cp.col_index, cp.ncol, cp.X, (long long)nrows, d_rows);
     ARVX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(arvx::closure_tiles_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0,
-                       ctx->stream, cp, d_tiles);
-    ARVX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(arvx::closure_count_kernel, dim3(nblk), dim3(256), 0, ctx->stream, cp,
-                       d_cnt);
-    ARVX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(arvx::surface_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, d_cnt, nblk,
-                       d_off);
+    if (int rc = launch_bit_pack<arvx::kBitClosureOccupied>(ctx, ctx->d_state, g, cp.apply_unseen,
+                                                            d_occ))
+        return rc;
+    const unsigned gw = (unsigned)((nwords + 255) / 256);
+    hipLaunchKernelGGL(arvx::bit_dilate_x_kernel, dim3(gw), dim3(256), 0, ctx->stream, d_occ, g,
+                       cp.radius, d_a);
+    hipLaunchKernelGGL(arvx::bit_dilate_yz_kernel, dim3(gw), dim3(256), 0, ctx->stream, d_a, g,
+                       cp.radius, 1, (const unsigned long long *)nullptr, d_b);
+    hipLaunchKernelGGL(arvx::bit_dilate_yz_kernel, dim3(gw), dim3(256), 0, ctx->stream, d_b, g,
+                       cp.radius, 2, (const unsigned long long *)d_occ, d_a);
     ARVX_HIP(hipGetLastError());
     long long total = 0;
-    ARVX_HIP(hipMemcpyAsync(&total, d_off + nblk, sizeof total, hipMemcpyDeviceToHost,
-                            ctx->stream));
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    if (int rc = bit_compact_count(ctx, d_a, nwords, d_cnt, d_off, &total)) return rc;
     ctx->clo_count = total;
     if (total > 0) {
-        ARVX_HIP(hipMalloc(&ctx->d_clo_index, (size_t)total * sizeof(int)));
-        ARVX_HIP(hipMalloc(&ctx->d_clo_rgba, (size_t)total * sizeof(float4)));
-        hipLaunchKernelGGL(arvx::closure_write_kernel, dim3(nblk), dim3(256), 0, ctx->stream, cp,
-                           d_off, ctx->d_clo_index, (float4 *)ctx->d_clo_rgba);
+        ARVX_HIP(ctx->pool_clo_index.reserve((size_t)total * sizeof(int)));
+        ctx->d_clo_index = (int *)ctx->pool_clo_index.p;
+        ARVX_HIP(ctx->pool_clo_rgba.reserve((size_t)total * sizeof(float4)));
+        ctx->d_clo_rgba = (void *)ctx->pool_clo_rgba.p;
+        if (int rc = bit_compact_write(ctx, d_a, nwords, g, d_off, ctx->d_clo_index)) return rc;
+        hipLaunchKernelGGL(arvx::closure_fill_kernel, dim3((unsigned)((total + 255) / 256)),
+                           dim3(256), 0, ctx->stream, cp, ctx->d_clo_index, total,
+                           (float4 *)ctx->d_clo_rgba);
         ARVX_HIP(hipGetLastError());
         hipLaunchKernelGGL(arvx::closure_mark_kernel, dim3((unsigned)((total + 255) / 256)),
                            dim3(256), 0, ctx->stream, ctx->d_state, ctx->d_clo_index, total);
@@ -995,7 +1045,8 @@ int arvx_mc_cells(arvx_ctx *ctx, int64_t *count) {
                             ctx->stream));
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
     if (total > 0) {
-        ARVX_HIP(hipMalloc(&ctx->d_mc_cells, (size_t)total * sizeof(int4)));
+        ARVX_HIP(ctx->pool_mc_cells.reserve((size_t)total * sizeof(int4)));
+        ctx->d_mc_cells = (void *)ctx->pool_mc_cells.p;
         hipLaunchKernelGGL(arvx::mc_write_kernel, dim3(nblk), dim3(256), 0, ctx->stream, mp, d_off,
                            (int4 *)ctx->d_mc_cells);
         ARVX_HIP(hipGetLastError());

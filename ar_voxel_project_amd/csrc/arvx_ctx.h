@@ -18,6 +18,28 @@ int fail_msg(int code, const char *msg);
             return ::arvx::fail_hip(arvx_e_, #call, __FILE__, __LINE__);      \
     } while (0)
 
+// grow-only device buffer: results of repeated calls reuse the allocation
+// (hipMalloc / hipFree of tens of MB cost more than the kernels that fill them)
+struct DevPool {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4;
+        const hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
 struct Ctx {
     int device = 0;
     int X = 0, Y = 0, Z = 0;  // full grid
@@ -79,16 +101,25 @@ struct Ctx {
     void *d_mc_cells = nullptr;
     int64_t mc_count = 0;
     bool mc_ready = false;
+    // storage behind the d_surf_* / d_clo_* / d_mc_cells views (kept until destroy)
+    DevPool pool_surf_index, pool_surf_rgb, pool_surf_depth, pool_surf_has, pool_clo_index,
+        pool_clo_rgba, pool_mc_cells;
+    void release_pools() {
+        pool_surf_index.release();
+        pool_surf_rgb.release();
+        pool_surf_depth.release();
+        pool_surf_has.release();
+        pool_clo_index.release();
+        pool_clo_rgba.release();
+        pool_mc_cells.release();
+    }
     void free_mc() {
-        if (d_mc_cells) (void)hipFree(d_mc_cells);
         d_mc_cells = nullptr;
         mc_count = 0;
         mc_ready = false;
     }
 
     void free_closure() {
-        if (d_clo_index) (void)hipFree(d_clo_index);
-        if (d_clo_rgba) (void)hipFree(d_clo_rgba);
         d_clo_index = nullptr;
         d_clo_rgba = nullptr;
         clo_count = 0;
@@ -108,10 +139,6 @@ struct Ctx {
     }
     void free_surface() {
         free_closure();
-        if (d_surf_index) (void)hipFree(d_surf_index);
-        if (d_surf_rgb) (void)hipFree(d_surf_rgb);
-        if (d_surf_depth) (void)hipFree(d_surf_depth);
-        if (d_surf_has) (void)hipFree(d_surf_has);
         d_surf_index = nullptr;
         d_surf_rgb = d_surf_depth = nullptr;
         d_surf_has = nullptr;

@@ -9,8 +9,9 @@
 // The model a neighbour's colour is read from is the one main.cpp has at that
 // point (src/main.cpp:291-299): carve -> colour pass -> handleUnseen.
 //
-// Two passes over the state plane, block-ordered like the surface compaction:
-// count the voxels that get filled, then write (index, rgba) in ascending order.
+// The voxels that get filled are found on bit planes (bitplane_kernels.h: pack
+// "occupied", dilate along x, y, z, remove the occupied ones) and compacted in
+// ascending index order; one thread per filled voxel then gathers the colours.
 #pragma once
 
 #include "arvx_device.h"
@@ -27,8 +28,6 @@ struct ClosureParams {
     const float *col_rgb;
     const uint8_t *col_has;
     long long ncol;
-    const uint8_t *tile_any;  // per 8x8x8 tile: holds an occupied voxel (skip test)
-    int tX, tY, tZ;
     const int *row_start;  // [Y*Z + 1] first colour-list entry of each voxel row (x run)
 };
 
@@ -103,88 +102,17 @@ __device__ inline int cl_gather(const ClosureParams &p, size_t i, float4 &sum) {
     return count;
 }
 
-// can the box of radius r around voxel i contain an occupied voxel at all?
-// (most of the grid is far from the hull: this keeps the 27-neighbour scan off it)
-__device__ __forceinline__ bool cl_near_occupied(const ClosureParams &p, size_t i) {
-    const int x = (int)(i % p.X);
-    const size_t t = i / p.X;
-    const int y = (int)(t % p.Y), z = (int)(t / p.Y);
-    const int x0 = max(x - p.radius, 0) >> 3, x1 = min(x + p.radius, p.X - 1) >> 3;
-    const int y0 = max(y - p.radius, 0) >> 3, y1 = min(y + p.radius, p.Y - 1) >> 3;
-    const int z0 = max(z - p.radius, 0) >> 3, z1 = min(z + p.radius, p.Z - 1) >> 3;
-    for (int c = z0; c <= z1; ++c)
-        for (int b = y0; b <= y1; ++b)
-            for (int a = x0; a <= x1; ++a)
-                if (p.tile_any[a + p.tX * (b + p.tY * c)]) return true;
-    return false;
-}
-
-__device__ __forceinline__ bool cl_fills(const ClosureParams &p, size_t i, size_t n) {
-    if (i >= n || cl_occupied(p, p.state[i]) || !cl_near_occupied(p, i)) return false;
-    float4 dummy;
-    return cl_gather<false>(p, i, dummy) > 0;
-}
-
-// one wave per 8x8x8 tile: lane = one x-row of 8 voxels
-__global__ __launch_bounds__(256) void closure_tiles_kernel(const ClosureParams p,
-                                                            uint8_t *__restrict__ tile_any) {
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= p.tX * p.tY * p.tZ) return;
-    const int lane = threadIdx.x & 63;
-    const int a = t % p.tX, b = (t / p.tX) % p.tY, c = t / (p.tX * p.tY);
-    const int y = b * 8 + (lane & 7), z = c * 8 + (lane >> 3);
-    bool any = false;
-    if (y < p.Y && z < p.Z) {
-        const uint8_t *row = p.state + ((size_t)z * p.Y + y) * p.X;
-        for (int x = a * 8; x < min(a * 8 + 8, p.X); ++x) any = any || cl_occupied(p, row[x]);
-    }
-    const unsigned long long m = __ballot(any);
-    if (lane == 0) tile_any[t] = m ? 1 : 0;
-}
-
-__global__ __launch_bounds__(256) void closure_count_kernel(const ClosureParams p,
-                                                            int *__restrict__ counts) {
-    __shared__ int wsum[4];
-    const size_t n = (size_t)p.X * p.Y * p.Z;
-    const size_t base = (size_t)blockIdx.x * kSurfChunk;
-    int mine = 0;
-    for (int it = 0; it < kSurfChunk / 256; ++it)
-        mine += __popcll(__ballot(cl_fills(p, base + (size_t)it * 256 + threadIdx.x, n)));
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-__global__ __launch_bounds__(256) void closure_write_kernel(const ClosureParams p,
-                                                            const long long *__restrict__ offsets,
-                                                            int *__restrict__ index,
-                                                            float4 *__restrict__ rgba) {
-    __shared__ int wcnt[4];
-    const size_t n = (size_t)p.X * p.Y * p.Z;
-    const size_t base = (size_t)blockIdx.x * kSurfChunk;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    long long run = offsets[blockIdx.x];
-    for (int it = 0; it < kSurfChunk / 256; ++it) {
-        const size_t i = base + (size_t)it * 256 + threadIdx.x;
-        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        int count = 0;
-        if (i < n && !cl_occupied(p, p.state[i]) && cl_near_occupied(p, i))
-            count = cl_gather<true>(p, i, sum);
-        const bool f = count > 0;
-        const unsigned long long b = __ballot(f);
-        if (lane == 0) wcnt[wave] = __popcll(b);
-        __syncthreads();
-        long long pre = run;
-        for (int w = 0; w < wave; ++w) pre += wcnt[w];
-        if (f) {
-            const long long slot = pre + __popcll(b & ((1ull << lane) - 1ull));
-            const float fc = (float)count;  // Eigen `sum /= count`, src/Postprocessing3d.cpp:49-51
-            index[slot] = (int)i;
-            rgba[slot] = make_float4(sum.x / fc, sum.y / fc, sum.z / fc, sum.w / fc);
-        }
-        run += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        __syncthreads();
-    }
+// one thread per filled voxel (index ascending): mean RGBA of its occupied neighbours
+__global__ __launch_bounds__(256) void closure_fill_kernel(const ClosureParams p,
+                                                           const int *__restrict__ index,
+                                                           long long n,
+                                                           float4 *__restrict__ rgba) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float4 sum;
+    const int count = cl_gather<true>(p, (size_t)index[e], sum);
+    const float fc = (float)count;  // Eigen `sum /= count`, src/Postprocessing3d.cpp:49-51
+    rgba[e] = make_float4(sum.x / fc, sum.y / fc, sum.z / fc, sum.w / fc);
 }
 
 // the filled voxels are occupied from now on (their w is count/count = 1)

@@ -7,61 +7,14 @@
 //
 // The reference walks all N voxels and votes only on occupied voxels that are
 // not "inner" (all six neighbours occupied, src/Model.h:126-132).  Here the
-// surface is first compacted into an index list in ascending flat-index order
-// (two passes over the u8 state plane, block-ordered so no sort is needed), then
-// one thread per surface voxel gathers its samples from the BGR images.
+// surface is first found on a bit plane and compacted into an index list in
+// ascending flat-index order (bitplane_kernels.h), then one thread per surface
+// voxel gathers its samples from the BGR images.
 #pragma once
 
 #include "arvx_device.h"
 
 namespace arvx {
-
-constexpr int kSurfChunk = 65536;  // voxels scanned by one workgroup
-
-struct SurfaceParams {
-    const uint8_t *state_ext;  // extended slab (with halo planes)
-    int X, Y;
-    int Zown;     // owned planes
-    int halo_lo;  // planes in front of the owned range inside state_ext (0/1)
-    int Zext;     // planes in state_ext
-    size_t nown;  // owned voxels
-};
-
-// occupied and not inner; neighbours outside the GRID count as empty
-// (Model::get returns zero there, reference src/Model.h:119-122); neighbours
-// outside the slab but inside the grid are read from the halo planes.
-__device__ __forceinline__ bool is_surface(const SurfaceParams &p, size_t i) {
-    const int x = (int)(i % p.X);
-    const size_t t = i / p.X;
-    const int y = (int)(t % p.Y);
-    const int ze = (int)(t / p.Y) + p.halo_lo;  // plane index inside state_ext
-    const size_t row = (size_t)p.X, plane = (size_t)p.X * p.Y;
-    const uint8_t *c = p.state_ext + (size_t)ze * plane + (size_t)y * row + x;
-    if (!(c[0] & 1u)) return false;
-    bool inner = true;
-    inner = inner && (x > 0) && (c[-1] & 1u);
-    inner = inner && (x + 1 < p.X) && (c[1] & 1u);
-    inner = inner && (y > 0) && (c[-(ptrdiff_t)row] & 1u);
-    inner = inner && (y + 1 < p.Y) && (c[row] & 1u);
-    inner = inner && (ze > 0) && (c[-(ptrdiff_t)plane] & 1u);
-    inner = inner && (ze + 1 < p.Zext) && (c[plane] & 1u);
-    return !inner;
-}
-
-__global__ __launch_bounds__(256) void surface_count_kernel(const SurfaceParams p,
-                                                            int *__restrict__ counts) {
-    __shared__ int wsum[4];
-    const size_t base = (size_t)blockIdx.x * kSurfChunk;
-    int mine = 0;
-    for (int it = 0; it < kSurfChunk / 256; ++it) {
-        const size_t i = base + (size_t)it * 256 + threadIdx.x;
-        const bool f = (i < p.nown) && is_surface(p, i);
-        mine += __popcll(__ballot(f));  // same value in every lane of the wave
-    }
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
 
 // exclusive scan of `counts` (n entries) by ONE workgroup; offsets[n] = total
 __global__ __launch_bounds__(256) void surface_scan_kernel(const int *__restrict__ counts, int n,
@@ -90,27 +43,6 @@ __global__ __launch_bounds__(256) void surface_scan_kernel(const int *__restrict
         __syncthreads();
     }
     if (threadIdx.x == 0) offsets[n] = carry_s;
-}
-
-__global__ __launch_bounds__(256) void surface_write_kernel(const SurfaceParams p,
-                                                            const long long *__restrict__ offsets,
-                                                            int *__restrict__ index) {
-    __shared__ int wcnt[4];
-    const size_t base = (size_t)blockIdx.x * kSurfChunk;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    long long run = offsets[blockIdx.x];
-    for (int it = 0; it < kSurfChunk / 256; ++it) {
-        const size_t i = base + (size_t)it * 256 + threadIdx.x;
-        const bool f = (i < p.nown) && is_surface(p, i);
-        const unsigned long long b = __ballot(f);
-        if (lane == 0) wcnt[wave] = __popcll(b);
-        __syncthreads();
-        long long pre = run;
-        for (int w = 0; w < wave; ++w) pre += wcnt[w];
-        if (f) index[pre + __popcll(b & ((1ull << lane) - 1ull))] = (int)i;
-        run += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        __syncthreads();
-    }
 }
 
 struct VoteParams {
