@@ -411,10 +411,16 @@ int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
     ARVX_CHECK_CTX(ctx);
     if (int mrc = materialize(ctx)) return mrc;
     if (!dev_words) return fail(ARVX_ERR_INVALID, "null dev_words");
-    const size_t nround = (ctx->nvox + 255) / 256;
-    const unsigned grid = (unsigned)(nround < 8192 ? (nround ? nround : 1) : 8192);
-    hipLaunchKernelGGL(arvx::pack_occupancy_kernel, dim3(grid), dim3(256), 0, ctx->stream,
-                       ctx->owned(), ctx->nvox, (uint32_t *)dev_words);
+    if (ctx->nvox % 32 == 0 && (uintptr_t)ctx->owned() % 8 == 0) {
+        const size_t nbytes = ctx->nvox / 8;
+        hipLaunchKernelGGL(arvx::pack_occupancy8_kernel, dim3((unsigned)((nbytes + 255) / 256)),
+                           dim3(256), 0, ctx->stream, ctx->owned(), nbytes, (uint8_t *)dev_words);
+    } else {
+        const size_t nround = (ctx->nvox + 255) / 256;
+        const unsigned grid = (unsigned)(nround < 8192 ? (nround ? nround : 1) : 8192);
+        hipLaunchKernelGGL(arvx::pack_occupancy_kernel, dim3(grid), dim3(256), 0, ctx->stream,
+                           ctx->owned(), ctx->nvox, (uint32_t *)dev_words);
+    }
     ARVX_HIP(hipGetLastError());
     return ARVX_OK;
 }
@@ -425,12 +431,12 @@ int arvx_pack_occupancy_global(arvx_ctx *ctx, void *dev_global_words) {
     if (!dev_global_words) return fail(ARVX_ERR_INVALID, "null dev_global_words");
     const size_t plane = (size_t)ctx->X * ctx->Y;
     if (plane % 64) return fail(ARVX_ERR_INVALID, "X*Y must be a multiple of 64");
-    const size_t nround = ctx->nvox / 256 + 1;
-    const unsigned grid = (unsigned)(nround < 8192 ? nround : 8192);
-    hipLaunchKernelGGL(arvx::pack_occupancy_global_kernel, dim3(grid), dim3(256), 0, ctx->stream,
-                       ctx->owned(), plane, ctx->z1 - ctx->z0,
+    // plane % 64 == 0 and an aligned allocation: every plane starts on an 8-byte boundary
+    const size_t nbytes = ctx->nvox / 8;
+    hipLaunchKernelGGL(arvx::pack_occupancy_global8_kernel, dim3((unsigned)((nbytes + 255) / 256)),
+                       dim3(256), 0, ctx->stream, ctx->owned(), plane, ctx->z1 - ctx->z0,
                        ctx->stripe_world > 1 ? 0 : ctx->z0, ctx->stripe_world, ctx->stripe_rank,
-                       (uint32_t *)dev_global_words);
+                       (uint8_t *)dev_global_words);
     ARVX_HIP(hipGetLastError());
     return ARVX_OK;
 }

@@ -840,26 +840,30 @@ __global__ __launch_bounds__(256) void pack_occupancy_kernel(const uint8_t *__re
     }
 }
 
-// Same, written at each stripe's place in the GLOBAL word plane (striped or
-// contiguous slabs): local 8-plane group g lands at global group g*zstride+zphase.
-__global__ __launch_bounds__(256) void pack_occupancy_global_kernel(
+// 8 voxels per thread (8-byte load, one byte of the plane out: voxel i is bit i%8 of
+// byte i/8 in the little-endian words).  Needs an 8-aligned plane and n % 8 == 0.
+__global__ __launch_bounds__(256) void pack_occupancy8_kernel(const uint8_t *__restrict__ state,
+                                                              size_t nbytes,
+                                                              uint8_t *__restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nbytes) return;
+    const unsigned long long s = ((const unsigned long long *)state)[t];
+    out[t] = (uint8_t)(((s & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+}
+
+// the global (slab / striped) form of the same; plane % 64 == 0
+__global__ __launch_bounds__(256) void pack_occupancy_global8_kernel(
     const uint8_t *__restrict__ state, size_t plane, int Zloc, int zoff, int zstride, int zphase,
-    uint32_t *__restrict__ words) {
-    // plane (= X*Y) is a multiple of 32: every plane starts on a word
-    const size_t n = plane * (size_t)Zloc;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const bool occ = state[i] & 1u;  // n is a multiple of 64 when plane % 64 == 0
-        const unsigned long long b = __ballot(occ);
-        if ((threadIdx.x & 63) == 0) {
-            const int lz = (int)(i / plane);
-            const size_t in_plane = i % plane;
-            const int gz = zoff + (((lz >> 3) * zstride + zphase) << 3) + (lz & 7);
-            uint32_t *dst = words + ((size_t)gz * plane + in_plane) / 32;
-            dst[0] = (uint32_t)b;
-            dst[1] = (uint32_t)(b >> 32);
-        }
-    }
+    uint8_t *__restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t pbytes = plane / 8;
+    if (t >= pbytes * (size_t)Zloc) return;
+    const int lz = (int)(t / pbytes);
+    const size_t in_plane = t % pbytes;
+    const int gz = zoff + (((lz >> 3) * zstride + zphase) << 3) + (lz & 7);
+    const unsigned long long s = ((const unsigned long long *)state)[t];
+    out[(size_t)gz * pbytes + in_plane] =
+        (uint8_t)(((s & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
 }
 
 }  // namespace arvx
