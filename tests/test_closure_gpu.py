@@ -50,6 +50,51 @@ def test_closure_parity(arvx, oracle, dims, mode, unseen):
     assert np.array_equal(occ_got, occ_want)
 
 
+@pytest.mark.parametrize("dims", [(136, 12, 9), (130, 10, 7), (64, 8, 8), (200, 6, 5)])
+@pytest.mark.parametrize("ksize", [3, 5, 9])
+def test_closure_multiword_rows_random_occupancy(arvx, oracle, dims, ksize):
+    """Sparse random occupancy on rows of one to four 64-bit words: the box dilation has
+    to carry across word borders and stop at the row ends, for every kernel size."""
+    X, Y, Z = dims
+    rng = np.random.default_rng(X + ksize)
+    st0 = np.where(rng.random((Z, Y, X)) < 0.01, 3, 2).astype(np.uint8)
+    st0[Z // 2, Y // 2, 63 if X > 64 else X - 1] = 3  # one voxel right at a word / row border
+    model = oracle.model_from_state(st0)
+    want = closure_any_kernel(model, X, Y, Z, ksize)
+    with arvx.Context(X, Y, Z, 0.01) as ctx:
+        ctx.upload_state(st0)
+        idx, rgba = ctx.closure(ksize, False)
+        out = ctx.export_model(False)
+    assert np.array_equal(out, want)
+    filled = np.nonzero((want[:, 3] != 0) & (model[:, 3] == 0))[0]
+    assert np.array_equal(idx, filled) and len(idx) > 0
+
+
+def closure_any_kernel(model, X, Y, Z, ksize):
+    """numpy restatement of applyClosure for any odd kernel size (the oracle's C
+    version is the literal 3x3x3 one): mean RGBA of the occupied neighbours, summed in
+    the reference's x, y, z offset order in fp32."""
+    r = (ksize - 1) // 2
+    m = model.reshape(Z, Y, X, 4)
+    occ = m[..., 3] != 0
+    out = m.copy()
+    pad = np.zeros((Z + 2 * r, Y + 2 * r, X + 2 * r, 4), np.float32)
+    pad[r:r + Z, r:r + Y, r:r + X] = np.where(occ[..., None], m, 0)
+    pocc = np.zeros((Z + 2 * r, Y + 2 * r, X + 2 * r), np.float32)
+    pocc[r:r + Z, r:r + Y, r:r + X] = occ
+    acc = np.zeros((Z, Y, X, 4), np.float32)
+    cnt = np.zeros((Z, Y, X), np.float32)
+    for a in range(-r, r + 1):          # x offset outermost (src/Postprocessing3d.cpp:31-48)
+        for b in range(-r, r + 1):
+            for c in range(-r, r + 1):
+                sl = (slice(r + c, r + c + Z), slice(r + b, r + b + Y), slice(r + a, r + a + X))
+                acc = (acc + pad[sl]).astype(np.float32)
+                cnt += pocc[sl]
+    fill = (~occ) & (cnt > 0)
+    out[fill] = (acc[fill] / cnt[fill][:, None]).astype(np.float32)
+    return out.reshape(-1, 4)
+
+
 def test_closure_kernel_5_and_uploaded_colors(arvx, oracle):
     """Bigger box, and a model whose colours come from the caller (arvx_colors_upload)."""
     X, Y, Z = 18, 15, 12

@@ -81,11 +81,15 @@ def test_color_on_z_slabs_uses_halo(arvx, oracle, mode):
     assert np.array_equal(np.concatenate(parts), want)
 
 
-def test_color_of_uploaded_model_with_random_occupancy(arvx, oracle):
-    """Random occupancy makes almost every voxel a surface voxel with odd neighbours."""
-    X, Y, Z, V = 21, 13, 11, 4
+@pytest.mark.parametrize("dims", [(21, 13, 11), (136, 12, 9), (130, 10, 7), (64, 8, 8), (8, 8, 8)])
+def test_color_of_uploaded_model_with_random_occupancy(arvx, oracle, dims):
+    """Random occupancy makes almost every voxel a surface voxel with odd neighbours;
+    rows of one, two and three 64-bit words of the bit plane, with and without the
+    8-voxels-per-thread pack (X % 8 == 0)."""
+    X, Y, Z = dims
+    V = 4
     sc = scenes.syn.sphere_scene(32, V, W=96, H=72, with_images=True)
-    s = np.float32(0.512 / 21)
+    s = np.float32(0.512 / X)
     rng = np.random.default_rng(9)
     st0 = rng.choice(np.array([0, 1, 2, 3], np.uint8), p=[0.1, 0.3, 0.2, 0.4], size=(Z, Y, X))
     model = oracle.model_from_state(st0)
