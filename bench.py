@@ -200,6 +200,7 @@ def main():
             step(i)
         drain()
         barrier()
+        torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         if world > 1:
