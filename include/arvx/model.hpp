@@ -71,6 +71,7 @@ class Model {
 
     void set(int x, int y, int z, const Vec4f &v) {  // src/Model.cpp:16-18
         const int i = flatten(x, y, z);
+        pristine_ = false;
         uint8_t &s = state_[i];
         s = (uint8_t)((s & kSeen) | (v.w() != 0 ? kOcc : 0));
         if (v == model_color() || (v.w() == 0 && v.x() == 0 && v.y() == 0 && v.z() == 0))
@@ -115,12 +116,16 @@ class Model {
         return it == color_lists_.end() ? std::vector<DCLR>() : it->second;
     }
 
-    void see(int x, int y, int z) { state_[flatten(x, y, z)] |= kSeen; }  // src/Model.h:151
+    void see(int x, int y, int z) {  // src/Model.h:151
+        pristine_ = false;
+        state_[flatten(x, y, z)] |= kSeen;
+    }
     void visit(Vec3i v) { see(v(0), v(1), v(2)); }                        // :154-156
     bool visited(Vec3i v) const { return state_[flatten(v(0), v(1), v(2))] & kSeen; }  // :158-160
 
     void handleUnseen() {  // src/Model.cpp:36-47
         std::cout << "LOG - PP: marking unseen voxels from model." << std::endl;
+        pristine_ = false;
         for (size_t i = 0; i < state_.size(); ++i)
             if (!(state_[i] & kSeen)) {
                 state_[i] = (uint8_t)(kOcc | kUnseenPaint);
@@ -146,7 +151,13 @@ class Model {
 
     // ---- access for the GPU path (not in the reference) ----
     size_t voxels() const { return state_.size(); }
-    uint8_t *state_data() { return state_.data(); }
+    // still exactly as constructed (every voxel MODEL_COLOR, nothing seen): the GPU
+    // side can start from arvx_state_reset instead of an N-byte upload
+    bool pristine() const { return pristine_; }
+    uint8_t *state_data() {
+        pristine_ = false;  // the caller may write through the pointer
+        return state_.data();
+    }
     const uint8_t *state_data() const { return state_.data(); }
     // state bytes as the C-ABI wants them (bit2 is host-only)
     std::vector<uint8_t> device_state() const {
@@ -159,6 +170,7 @@ class Model {
     // voxel that is still occupied keeps its UNSEEN paint bit, a carved one loses
     // it and its explicit colour (set(x,y,z,(0,0,0,0)), src/VoxelCarving.cpp:52).
     void absorb_state(const uint8_t *dev_state) {
+        pristine_ = false;
         for (auto it = colors_.begin(); it != colors_.end();) {  // sparse: surface voxels only
             const size_t i = (size_t)it->first;
             if ((state_[i] & kOcc) && !(dev_state[i] & kOcc)) it = colors_.erase(it);
@@ -193,6 +205,7 @@ class Model {
     const int size_x, size_y, size_z;
     const float voxel_size;
     std::vector<uint8_t> state_;
+    bool pristine_ = true;
     std::unordered_map<int, Vec4f> colors_;
     std::unordered_map<int, std::vector<DCLR>> color_lists_;
 

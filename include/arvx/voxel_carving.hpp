@@ -101,8 +101,12 @@ class Session {
         check(arvx_set_views(ctx_, V, M.data(), cam.data(), masks.data(), m0.width, m0.height,
                              m0.channels, m0.stride),
               "arvx_set_views");
-        const std::vector<uint8_t> st = model.device_state();
-        check(arvx_state_upload(ctx_, st.data()), "arvx_state_upload");
+        if (model.pristine()) {  // a new Model: nothing to send
+            check(arvx_state_reset(ctx_), "arvx_state_reset");
+        } else {
+            const std::vector<uint8_t> st = model.device_state();
+            check(arvx_state_upload(ctx_, st.data()), "arvx_state_upload");
+        }
     }
     ~Session() { arvx_ctx_destroy(ctx_); }
     Session(const Session &) = delete;

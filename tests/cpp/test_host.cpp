@@ -36,7 +36,12 @@ static int test_model() {
     EXPECT(!m.isInner(1, 1, 0));                         // z-1 is outside the grid
     Model big(3, 3, 3, 1.f);
     EXPECT(big.isInner(1, 1, 1));
+    EXPECT(big.pristine() && big.get(1, 1, 1).w() == 1 && big.pristine());  // reads keep it
     big.set(1, 1, 2, Vec4f(0, 0, 0, 0));
+    EXPECT(!big.pristine());
+    Model seen1(2, 2, 2, 1.f);
+    seen1.see(0, 0, 0);
+    EXPECT(!seen1.pristine());
     EXPECT(!big.isInner(1, 1, 1));
     EXPECT(big.get(1, 1, 2).w() == 0);
     // toWord swaps x/y and negates z

@@ -96,6 +96,28 @@ def test_cpp_entry_points_match_oracle(host_bin, oracle, tmp_path, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["carve", "fast", "closest"])
+def test_cpp_entry_points_on_a_new_model(host_bin, oracle, tmp_path, mode):
+    """A Model nobody touched goes to the GPU as arvx_state_reset, not as an upload."""
+    X, Y, Z, V = 24, 20, 16, 4
+    sc = scenes.syn.sphere_scene(32, V, W=96, H=72, with_images=True)
+    s = np.float32(0.512 / 24)
+    st0 = np.ones((Z, Y, X), np.uint8)  # occupied, unseen: the C++ side never calls set()/see()
+    scene, out = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
+    write_scene(scene, X, Y, Z, s, sc.K, sc.Rt, sc.masks, sc.images, st0)
+    r = subprocess.run([host_bin, "carve", scene, out, mode], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    rgba, seen = read_result(out, X * Y * Z)
+    M = oracle.compose(sc.K, sc.Rt)
+    st = (oracle.fast_carve if mode == "fast" else oracle.carve)(X, Y, Z, s, M, sc.masks)
+    want = oracle.model_from_state(st)
+    if mode == "closest":
+        want = oracle.color(X, Y, Z, s, M, sc.campos, sc.images, 0, want)
+    assert np.array_equal(seen, (st.reshape(-1) & 2) == 2)
+    assert np.array_equal(rgba, want)
+
+
+@pytest.mark.gpu
 def test_bench6_table(host_bin, oracle, tmp_path):
     """The reference's -c=6 benchmark sequence (src/main.cpp:306-440) through the C++
     layer: eight runs, reference table layout, occupancy equal to the oracle's."""
