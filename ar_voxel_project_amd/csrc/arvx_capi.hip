@@ -1019,21 +1019,26 @@ int arvx_mc_cells(arvx_ctx *ctx, int64_t *count) {
     // the cells whose upper plane is outside the grid
     mp.cz0 = ctx->z0 - 1;
     mp.cz1 = (ctx->z1 == ctx->Z) ? ctx->Z : ctx->z1 - 1;
+    mp.ZW = (mp.cz1 - mp.cz0 + 1 + 63) / 64;
+    const size_t nzw = (size_t)mp.ZW * ctx->X * ctx->Y;  // z-packed occupancy words
     const long long ncol = (long long)(ctx->X + 1) * (ctx->Y + 1);
     const int nsb = (int)((ncol + arvx::kScanBlock - 1) / arvx::kScanBlock);
-    const size_t need = (size_t)(ncol + nsb + 1) * sizeof(long long) +
-                        (size_t)(ncol + nsb) * sizeof(int) + 64;
-    if (ctx->scratch_bytes < need) {
-        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
-        ctx->d_scratch = nullptr;
-        ctx->scratch_bytes = 0;
-        ARVX_HIP(hipMalloc(&ctx->d_scratch, need));
-        ctx->scratch_bytes = need;
-    }
-    long long *d_off = (long long *)ctx->d_scratch;  // ncol column offsets
-    long long *d_boff = d_off + ncol;                // nsb + 1 block offsets, last = total
+    if (int rc = ensure_scratch(ctx, nzw * sizeof(unsigned long long) +
+                                         (size_t)(ncol + nsb + 1) * sizeof(long long) +
+                                         (size_t)(ncol + nsb) * sizeof(int) + 64))
+        return rc;
+    mp.zbits = (unsigned long long *)ctx->d_scratch;
+    long long *d_off = (long long *)(mp.zbits + nzw);  // ncol column offsets
+    long long *d_boff = d_off + ncol;                   // nsb + 1 block offsets, last = total
     int *d_cnt = (int *)(d_boff + nsb + 1);
     int *d_bsum = d_cnt + ncol;
+    if (ctx->X % 4 == 0)
+        hipLaunchKernelGGL(arvx::mc_zpack_kernel<4>, dim3((unsigned)((nzw / 4 + 255) / 256)),
+                           dim3(256), 0, ctx->stream, mp);
+    else
+        hipLaunchKernelGGL(arvx::mc_zpack_kernel<1>, dim3((unsigned)((nzw + 255) / 256)), dim3(256),
+                           0, ctx->stream, mp);
+    ARVX_HIP(hipGetLastError());
     const unsigned nblk = (unsigned)((ncol + 255) / 256);
     hipLaunchKernelGGL(arvx::mc_count_kernel, dim3(nblk), dim3(256), 0, ctx->stream, mp, d_cnt);
     ARVX_HIP(hipGetLastError());

@@ -9,11 +9,14 @@
 // With w in {0,1} and the threshold 0.5 every caller passes (src/main.cpp:303,
 // src/VoxelCarving.cpp:67) "w < threshold" is "not occupied".
 //
-// One lane owns one (x,y) column of cells and walks it along z, so the four corner
-// bytes of a plane are read once and reused as the lower face of the next cell;
-// lanes run along x (coalesced rows).  Column counts are written transposed
-// (x-major), scanned, and the second walk writes each column's cells at its offset:
-// the list comes out in the reference's emission order without a sort.
+// The occupancy is first packed ALONG Z: one 64-bit word holds 64 consecutive planes
+// of one voxel column (mc_zpack_kernel; the byte plane is read once, coalesced).
+// One lane then owns one (x,y) column of cells and walks it 64 cells at a time: the
+// eight corner bits of 64 cells are eight words (four voxel columns, each shifted by
+// 0 and 1 plane), "triangulates" is any & ~all, counting is a popcount.  Lanes run
+// along x (coalesced rows).  Column counts are written transposed (x-major), scanned,
+// and the second walk writes each column's cells at its offset: the list comes out
+// in the reference's emission order without a sort.
 #pragma once
 
 #include "arvx_device.h"
@@ -25,42 +28,48 @@ struct McParams {
     int X, Y, Z;
     int ze0, ze1;
     int cz0, cz1;  // cells with z in [cz0, cz1) are listed by this context
+    // z-packed occupancy: word (w, y, x), bit b = voxel (x, y, cz0 + 64 w + b) occupied;
+    // planes outside the grid are empty.  ZW words per column cover planes cz0 .. cz1.
+    unsigned long long *zbits;
+    int ZW;
 };
 
-// One (cx,cy) column of cells.  The four corner bytes of a plane sit at fixed
-// offsets inside the plane; corners outside the grid (Model::get returns zero
-// there, src/Model.h:119-122 => empty) are read from offset 0 and masked, so the
-// loads carry no branches and kMcBatch planes are in flight at once -- the walk is
-// a chain of dependent steps only through the 4 bits handed from cell to cell.
-constexpr int kMcBatch = 16;
-
-struct McColumn {
-    unsigned off[4];   // (cx+1,cy) (cx,cy) (cx,cy+1) (cx+1,cy+1): the reference's corner order
-    unsigned keep[4];  // 1 if that corner is inside the grid in x and y
-};
-
-__device__ __forceinline__ McColumn mc_column(const McParams &p, int cx, int cy) {
-    const bool x0 = cx >= 0, x1 = cx + 1 < p.X, y0 = cy >= 0, y1 = cy + 1 < p.Y;
-    const bool in[4] = {x1 && y0, x0 && y0, x0 && y1, x1 && y1};
-    const int dx[4] = {1, 0, 0, 1}, dy[4] = {0, 0, 1, 1};
-    McColumn c;
+// COLS = 4: a lane packs 4 neighbouring columns from dword loads (X % 4 == 0);
+// COLS = 1: one column from byte loads.
+template <int COLS>
+__global__ __launch_bounds__(256) void mc_zpack_kernel(const McParams p) {
+    const int xg = p.X / COLS;  // column groups per row
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)xg * p.Y * p.ZW) return;
+    const int gx = (int)(t % xg);
+    const int y = (int)((t / xg) % p.Y);
+    const int w = (int)(t / ((size_t)xg * p.Y));
+    const size_t plane = (size_t)p.X * p.Y;
+    const uint8_t *col = p.state + (size_t)y * p.X + (size_t)gx * COLS;
+    unsigned long long acc[COLS];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        c.keep[k] = in[k] ? 1u : 0u;
-        c.off[k] = in[k] ? (unsigned)((cy + dy[k]) * p.X + (cx + dx[k])) : 0u;
+    for (int c = 0; c < COLS; ++c) acc[c] = 0ull;
+    const int zbase = p.cz0 + 64 * w;
+#pragma clang loop vectorize(disable) unroll(disable)
+    for (int b0 = 0; b0 < 64; b0 += 16) {
+        unsigned v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {  // 16 planes in flight; invalid planes read plane ze0
+            const int zg = zbase + b0 + k;
+            const bool ok = zg >= 0 && zg < p.Z && zg <= p.cz1;
+            const uint8_t *q = col + (size_t)((ok ? zg : p.ze0) - p.ze0) * plane;
+            const unsigned raw = (COLS == 4) ? *(const unsigned *)q : (unsigned)*q;
+            v[k] = ok ? raw : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+#pragma unroll
+            for (int c = 0; c < COLS; ++c)
+                acc[c] |= (unsigned long long)((v[k] >> (8 * c)) & 1u) << (b0 + k);
     }
-    return c;
-}
-
-// bit set = corner EMPTY, for plane zg (any integer: planes outside the grid are empty)
-__device__ __forceinline__ unsigned mc_face(const McParams &p, const McColumn &c, int zg) {
-    const bool inz = zg >= 0 && zg < p.Z;
-    const int zc = inz ? zg : p.ze0;  // any plane that is held
-    const uint8_t *pl = p.state + (size_t)(zc - p.ze0) * p.X * p.Y;
-    unsigned o = 0;
+    unsigned long long *out = p.zbits + ((size_t)w * p.Y + y) * p.X + (size_t)gx * COLS;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o |= (pl[c.off[k]] & c.keep[k]) << k;
-    return inz ? (o ^ 0xFu) : 0xFu;
+    for (int c = 0; c < COLS; ++c) out[c] = acc[c];
 }
 
 __device__ __forceinline__ bool mc_column_of_thread(const McParams &p, int &cx, int &cy) {
@@ -72,22 +81,50 @@ __device__ __forceinline__ bool mc_column_of_thread(const McParams &p, int &cx, 
     return true;
 }
 
-// walks the column and calls emit(cz, cubeIndex) for every cell that triangulates
+// walks the column and calls emit(cz, cubeIndex) for every cell that triangulates,
+// cz ascending.  Corner order of the reference (src/MarchingCubes.h:537-552):
+// (cx+1,cy) (cx,cy) (cx,cy+1) (cx+1,cy+1) on plane cz, then the same on plane cz+1.
 template <class Emit>
 __device__ __forceinline__ void mc_walk(const McParams &p, int cx, int cy, Emit emit) {
-    const McColumn c = mc_column(p, cx, cy);
-    unsigned lo = mc_face(p, c, p.cz0);
+    const bool x0 = cx >= 0, x1 = cx + 1 < p.X, y0 = cy >= 0, y1 = cy + 1 < p.Y;
+    const bool in[4] = {x1 && y0, x0 && y0, x0 && y1, x1 && y1};
+    const int dx[4] = {1, 0, 0, 1}, dy[4] = {0, 0, 1, 1};
+    const unsigned long long *colp[4];
+    const size_t wstride = (size_t)p.X * p.Y;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)  // columns outside the grid read column 0 and are masked
+        colp[c] = p.zbits + (in[c] ? (size_t)(cy + dy[c]) * p.X + (cx + dx[c]) : 0);
+    const int ncell = p.cz1 - p.cz0;  // cells of this column; cell q uses planes q, q+1
+    unsigned long long cur[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) cur[c] = in[c] ? colp[c][0] : 0ull;
 #pragma clang loop vectorize(disable) unroll(disable)
-    for (int cz = p.cz0; cz < p.cz1; cz += kMcBatch) {
-        unsigned f[kMcBatch];
+    for (int w = 0; w * 64 < ncell; ++w) {
+        unsigned long long nxt[4], lo[4], hi[4];
 #pragma unroll
-        for (int k = 0; k < kMcBatch; ++k) f[k] = mc_face(p, c, min(cz + k, p.cz1 - 1) + 1);
-#pragma unroll
-        for (int k = 0; k < kMcBatch; ++k) {
-            const unsigned idx = lo | (f[k] << 4);
-            if (cz + k < p.cz1 && idx != 0u && idx != 255u) emit(cz + k, idx);
-            lo = f[k];
+        for (int c = 0; c < 4; ++c) {
+            nxt[c] = (in[c] && w + 1 < p.ZW) ? colp[c][(size_t)(w + 1) * wstride] : 0ull;
+            lo[c] = cur[c];
+            hi[c] = (cur[c] >> 1) | (nxt[c] << 63);
         }
+        const unsigned long long any = lo[0] | lo[1] | lo[2] | lo[3] | hi[0] | hi[1] | hi[2] | hi[3];
+        const unsigned long long all = lo[0] & lo[1] & lo[2] & lo[3] & hi[0] & hi[1] & hi[2] & hi[3];
+        unsigned long long act = any & ~all;
+        const int left = ncell - w * 64;
+        if (left < 64) act &= (1ull << left) - 1ull;
+        while (act) {
+            const int b = __ffsll((long long)act) - 1;
+            act &= act - 1ull;
+            unsigned idx = 0;  // bit i set = corner i EMPTY (src/MarchingCubes.h:479-484)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                idx |= (unsigned)((~lo[c] >> b) & 1ull) << c;
+                idx |= (unsigned)((~hi[c] >> b) & 1ull) << (4 + c);
+            }
+            emit(p.cz0 + w * 64 + b, idx);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
     }
 }
 

@@ -43,6 +43,20 @@ def test_mc_cells_random(arvx, oracle, dims, fill):
         assert len(got) == (X + 1) * (Y + 1) * (Z + 1) - max(X - 1, 0) * max(Y - 1, 0) * max(Z - 1, 0)
 
 
+@pytest.mark.parametrize("Z", [62, 63, 64, 65, 127, 128, 129])
+@pytest.mark.parametrize("X", [8, 6])
+def test_mc_cells_z_word_borders(arvx, oracle, X, Z):
+    """The walk handles 64 cells of a column per word of the z-packed plane: cell
+    counts around the word borders, with the dword (X % 4 == 0) and the byte pack."""
+    rng = np.random.default_rng(Z * 10 + X)
+    st = np.where(rng.random((Z, 5, X)) < 0.5, 3, 2).astype(np.uint8)
+    st[-1] |= 1  # the top plane full: every column has a cell at z = Z-1
+    assert np.array_equal(got_cells(arvx, st), want_cells(oracle, st))
+    if Z > 70:  # and as two slabs cut near a word border
+        parts = [got_cells(arvx, st, (0, 64)), got_cells(arvx, st, (64, Z))]
+        assert np.array_equal(sharding.merge_mc_cells(parts), want_cells(oracle, st))
+
+
 def test_mc_cells_single_voxel(arvx, oracle):
     """One voxel in the middle: its 8 cells, each seeing it at a different corner."""
     st = np.full((3, 3, 3), 2, np.uint8)
