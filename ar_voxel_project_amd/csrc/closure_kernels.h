@@ -68,8 +68,7 @@ __global__ __launch_bounds__(256) void closure_rows_kernel(const int *__restrict
     row_start[r] = (int)lo;
 }
 
-// returns the number of occupied neighbours; with kSum also their colour sum
-template <bool kSum>
+// returns the number of occupied neighbours and their colour sum
 __device__ inline int cl_gather(const ClosureParams &p, size_t i, float4 &sum) {
     const int x = (int)(i % p.X);
     const size_t t = i / p.X;
@@ -89,13 +88,11 @@ __device__ inline int cl_gather(const ClosureParams &p, size_t i, float4 &sum) {
                 const uint8_t st = p.state[q];
                 if (!cl_occupied(p, st)) continue;
                 ++count;
-                if (kSum) {
-                    const float4 v = cl_color(p, q, st);
-                    sum.x = sum.x + v.x;
-                    sum.y = sum.y + v.y;
-                    sum.z = sum.z + v.z;
-                    sum.w = sum.w + v.w;
-                }
+                const float4 v = cl_color(p, q, st);
+                sum.x = sum.x + v.x;
+                sum.y = sum.y + v.y;
+                sum.z = sum.z + v.z;
+                sum.w = sum.w + v.w;
             }
         }
     }
@@ -110,7 +107,7 @@ __global__ __launch_bounds__(256) void closure_fill_kernel(const ClosureParams p
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
     float4 sum;
-    const int count = cl_gather<true>(p, (size_t)index[e], sum);
+    const int count = cl_gather(p, (size_t)index[e], sum);
     const float fc = (float)count;  // Eigen `sum /= count`, src/Postprocessing3d.cpp:49-51
     rgba[e] = make_float4(sum.x / fc, sum.y / fc, sum.z / fc, sum.w / fc);
 }
