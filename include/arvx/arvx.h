@@ -156,7 +156,8 @@ int arvx_carve(arvx_ctx *ctx, unsigned flags);
  * intermediate meshes (:65-68). */
 int arvx_carve_views(arvx_ctx *ctx, int first, int count, unsigned flags);
 /* Greedy carve: reference fastCarve(), src/VoxelCarving.cpp:74-167.
- * Needs the whole grid in one context (no slab). */
+ * Needs the whole grid in one context (no slab).  The context keeps the work
+ * buffer of the flood fill (about 1.25 bytes per voxel) for later calls. */
 int arvx_fast_carve(arvx_ctx *ctx);
 /* Colour vote on the occupied surface voxels (reference
  * reconstructClosestColor / reconstructAvgColor). Result stays on the device
