@@ -1146,21 +1146,22 @@ int arvx_fast_carve(arvx_ctx *ctx) {
         const size_t tile_bytes = 2 * (size_t)tile_rows * sizeof(unsigned long long);
         ARVX_HIP(hipMemsetAsync(d_tiles, 0, tile_bytes, ctx->stream));
         hipLaunchKernelGGL(arvx::flood_tile_full_kernel, dim3(gflood), dim3(256), 0, ctx->stream,
-                           fp, d_tiles);
+                           fp, d_tiles, d_dirty);
         hipLaunchKernelGGL(arvx::flood_tile_fill_kernel, dim3(1), dim3(1024), tile_bytes,
                            ctx->stream, d_tiles, d_tiles + tile_rows, tilesY, tilesZ);
         hipLaunchKernelGGL(arvx::flood_tile_seed_kernel, dim3(gflood), dim3(256), 0, ctx->stream,
                            fp, d_tiles + tile_rows);
         ARVX_HIP(hipGetLastError());
     }
-    // per-tile wake flags, two buffers swapped every launch; all awake at first
-    ARVX_HIP(hipMemsetAsync(d_dirty, 1, gflood, ctx->stream));
+    // per-tile wake flags, two buffers swapped every launch; without the pre-pass
+    // (which sets the first buffer) all tiles are awake at first
+    if (!prepass) ARVX_HIP(hipMemsetAsync(d_dirty, 1, gflood, ctx->stream));
     ARVX_HIP(hipMemsetAsync(d_dirty + gflood, 0, gflood, ctx->stream));
     // every launch that is not the last grows at least one word; the flag is read
-    // back after 2, 2, 4, 8, 8, ... launches
+    // back after 4, 4, 8, 8, ... launches (a launch with no tile awake costs microseconds)
     const long max_launches = 128 + (long)gflood * 256;
     long launched = 0;
-    for (int batch = 2, round = 0;; ++round) {
+    for (int batch = 4, round = 0;; ++round) {
         int changed = 0;
         ARVX_HIP(hipMemsetAsync(fp.changed, 0, sizeof(int), ctx->stream));
         for (int k = 0; k < batch; ++k, ++launched) {

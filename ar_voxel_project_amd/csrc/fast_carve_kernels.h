@@ -113,23 +113,33 @@ __device__ __forceinline__ unsigned long long fill_row(unsigned long long seed,
 constexpr int kFloodMaxTileRows = 4096;  // rows of tiles (tilesY * tilesZ): 2 words each = 64 KB of LDS
 
 // full[(bz * tilesY + by)] bit xw = every voxel of tile (xw, by, bz) that lies inside
-// the grid is open.  One workgroup per tile, thread = one 64-voxel word.
+// the grid is open.  One workgroup per tile, thread = one 64-voxel word.  Also sets the
+// tile's first wake flag: only a PARTLY open tile can grow on its own account -- a full
+// one is either seeded completely by the pre-pass or woken later by a neighbour, one
+// without open voxels never changes.
 __global__ __launch_bounds__(256) void flood_tile_full_kernel(const FloodParams p,
-                                                              unsigned long long *__restrict__ full) {
+                                                              unsigned long long *__restrict__ full,
+                                                              uint8_t *__restrict__ wake) {
     const int ty = threadIdx.x & 15, tz = threadIdx.x >> 4;
     const int tilesY = (p.Y + 15) >> 4;
     const int xw = blockIdx.x % p.XW;
     const int by = (blockIdx.x / p.XW) % tilesY;
     const int bz = blockIdx.x / (p.XW * tilesY);
     const int y = by * 16 + ty, z = bz * 16 + tz;
-    bool f = true;
+    bool f = true, any = false;
     if (y < p.Y && z < p.Z) {
         const int nbits = min(64, p.X - xw * 64);
         const unsigned long long want = (nbits == 64) ? ~0ull : ((1ull << nbits) - 1ull);
-        f = p.open[((size_t)z * p.Y + y) * p.XW + xw] == want;
+        const unsigned long long o = p.open[((size_t)z * p.Y + y) * p.XW + xw];
+        f = o == want;
+        any = o != 0ull;
     }
-    if (__syncthreads_and(f) && threadIdx.x == 0)
-        atomicOr(&full[(size_t)bz * tilesY + by], 1ull << xw);
+    const bool is_full = __syncthreads_and(f);
+    const bool has_open = __syncthreads_or(any);
+    if (threadIdx.x == 0) {
+        if (is_full) atomicOr(&full[(size_t)bz * tilesY + by], 1ull << xw);
+        wake[blockIdx.x] = (has_open && !is_full) ? 1 : 0;
+    }
 }
 
 // Component of the tile (0,0,0) among the full tiles, 6-connected.  ONE workgroup;
