@@ -1144,13 +1144,12 @@ int arvx_fast_carve(arvx_ctx *ctx) {
     // that is connected to the origin tile through completely open tiles
     if (prepass) {
         const size_t tile_bytes = 2 * (size_t)tile_rows * sizeof(unsigned long long);
-        ARVX_HIP(hipMemsetAsync(d_tiles, 0, tile_bytes, ctx->stream));
-        hipLaunchKernelGGL(arvx::flood_tile_full_kernel, dim3(gflood), dim3(256), 0, ctx->stream,
-                           fp, d_tiles, d_dirty);
+        hipLaunchKernelGGL(arvx::flood_tile_full_kernel, dim3(tile_rows), dim3(256), 0,
+                           ctx->stream, fp, d_tiles, d_dirty);
         hipLaunchKernelGGL(arvx::flood_tile_fill_kernel, dim3(1), dim3(1024), tile_bytes,
                            ctx->stream, d_tiles, d_tiles + tile_rows, tilesY, tilesZ);
-        hipLaunchKernelGGL(arvx::flood_tile_seed_kernel, dim3(gflood), dim3(256), 0, ctx->stream,
-                           fp, d_tiles + tile_rows);
+        hipLaunchKernelGGL(arvx::flood_tile_seed_kernel, dim3(tile_rows), dim3(256), 0,
+                           ctx->stream, fp, d_tiles + tile_rows);
         ARVX_HIP(hipGetLastError());
     }
     // per-tile wake flags, two buffers swapped every launch; without the pre-pass
@@ -1178,9 +1177,14 @@ int arvx_fast_carve(arvx_ctx *ctx) {
         if (launched >= max_launches) return fail(ARVX_ERR_HIP, "flood fill did not converge");
         if (round >= 1 && batch < 8) batch *= 2;
     }
-    if (by8)
-        hipLaunchKernelGGL(arvx::flood_apply8_kernel, dim3((unsigned)((ctx->nvox / 8 + 255) / 256)),
-                           dim3(256), 0, ctx->stream, ctx->d_state, fp);
+    if (fp.X % 16 == 0)
+        hipLaunchKernelGGL(arvx::flood_apply_wide_kernel<uint16_t>,
+                           dim3((unsigned)((ctx->nvox / 16 + 255) / 256)), dim3(256), 0,
+                           ctx->stream, ctx->d_state, fp);
+    else if (by8)
+        hipLaunchKernelGGL(arvx::flood_apply_wide_kernel<uint8_t>,
+                           dim3((unsigned)((ctx->nvox / 8 + 255) / 256)), dim3(256), 0,
+                           ctx->stream, ctx->d_state, fp);
     else
         hipLaunchKernelGGL(arvx::flood_apply_kernel, dim3((unsigned)((ctx->nvox + 255) / 256)),
                            dim3(256), 0, ctx->stream, ctx->d_state, fp);

@@ -120,26 +120,37 @@ constexpr int kFloodMaxTileRows = 4096;  // rows of tiles (tilesY * tilesZ): 2 w
 __global__ __launch_bounds__(256) void flood_tile_full_kernel(const FloodParams p,
                                                               unsigned long long *__restrict__ full,
                                                               uint8_t *__restrict__ wake) {
-    const int ty = threadIdx.x & 15, tz = threadIdx.x >> 4;
+    // one workgroup per row of tiles (by, bz); consecutive threads read consecutive
+    // words of a voxel row (xw fastest), several voxel rows per step.  XW <= 64.
+    __shared__ unsigned s_notfull[2], s_any[2];  // bit xw, as two 32-bit halves
     const int tilesY = (p.Y + 15) >> 4;
-    const int xw = blockIdx.x % p.XW;
-    const int by = (blockIdx.x / p.XW) % tilesY;
-    const int bz = blockIdx.x / (p.XW * tilesY);
-    const int y = by * 16 + ty, z = bz * 16 + tz;
-    bool f = true, any = false;
-    if (y < p.Y && z < p.Z) {
+    const int by = blockIdx.x % tilesY, bz = blockIdx.x / tilesY;
+    if (threadIdx.x < 2) s_notfull[threadIdx.x] = s_any[threadIdx.x] = 0u;
+    __syncthreads();
+    const int per = 256 / p.XW;  // voxel rows per step
+    const int xw = threadIdx.x % p.XW, sub = threadIdx.x / p.XW;
+    bool notfull = false, any = false;
+    if (sub < per) {
         const int nbits = min(64, p.X - xw * 64);
         const unsigned long long want = (nbits == 64) ? ~0ull : ((1ull << nbits) - 1ull);
-        const unsigned long long o = p.open[((size_t)z * p.Y + y) * p.XW + xw];
-        f = o == want;
-        any = o != 0ull;
+        for (int r = sub; r < 256; r += per) {  // r = tz * 16 + ty inside the tile row
+            const int y = by * 16 + (r & 15), z = bz * 16 + (r >> 4);
+            if (y >= p.Y || z >= p.Z) continue;
+            const unsigned long long o = p.open[((size_t)z * p.Y + y) * p.XW + xw];
+            notfull = notfull || (o != want);
+            any = any || (o != 0ull);
+        }
+        if (notfull) atomicOr(&s_notfull[xw >> 5], 1u << (xw & 31));
+        if (any) atomicOr(&s_any[xw >> 5], 1u << (xw & 31));
     }
-    const bool is_full = __syncthreads_and(f);
-    const bool has_open = __syncthreads_or(any);
-    if (threadIdx.x == 0) {
-        if (is_full) atomicOr(&full[(size_t)bz * tilesY + by], 1ull << xw);
-        wake[blockIdx.x] = (has_open && !is_full) ? 1 : 0;
-    }
+    __syncthreads();
+    const unsigned long long nf = s_notfull[0] | ((unsigned long long)s_notfull[1] << 32);
+    const unsigned long long an = s_any[0] | ((unsigned long long)s_any[1] << 32);
+    const unsigned long long valid = (p.XW == 64) ? ~0ull : ((1ull << p.XW) - 1ull);
+    if (threadIdx.x == 0) full[blockIdx.x] = ~nf & valid;
+    if (threadIdx.x < p.XW)
+        wake[(size_t)blockIdx.x * p.XW + threadIdx.x] =
+            (((an >> threadIdx.x) & 1ull) && ((nf >> threadIdx.x) & 1ull)) ? 1 : 0;
 }
 
 // Component of the tile (0,0,0) among the full tiles, 6-connected.  ONE workgroup;
@@ -158,38 +169,50 @@ __global__ __launch_bounds__(1024) void flood_tile_fill_kernel(
     __syncthreads();
     if (threadIdx.x == 0) r[0] = f[0] & 1ull;  // seed: the tile of voxel (0,0,0), if full
     __syncthreads();
-    // every round that reports a change adds at least one tile, so this ends
+    // every round that reports a change adds at least one tile, so this ends.  Inside a
+    // round the rows are relaxed a few times without a barrier: a racing reader sees the
+    // old or the new word of a neighbour, both are sound (the set only grows), and most
+    // of the front moves on without waiting for the whole workgroup.
+    volatile unsigned long long *rv = r;
     for (;;) {
         int ch = 0;
-        for (int i = threadIdx.x; i < rows; i += 1024) {
-            const int by = i % tilesY, bz = i / tilesY;
-            unsigned long long in = r[i];
-            if (by > 0) in |= r[i - 1];
-            if (by + 1 < tilesY) in |= r[i + 1];
-            if (bz > 0) in |= r[i - tilesY];
-            if (bz + 1 < tilesZ) in |= r[i + tilesY];
-            const unsigned long long rn = fill_row(f[i] & in, f[i]);
-            if (rn != r[i]) {
-                r[i] = rn;  // racing readers see the old or the new word: both are sound
-                ch = 1;
+        for (int rep = 0; rep < 4; ++rep)
+            for (int i = threadIdx.x; i < rows; i += 1024) {
+                const unsigned long long mine = rv[i];
+                if (mine == f[i]) continue;  // every full tile of this row is in already
+                const int by = i % tilesY, bz = i / tilesY;
+                unsigned long long in = mine;
+                if (by > 0) in |= rv[i - 1];
+                if (by + 1 < tilesY) in |= rv[i + 1];
+                if (bz > 0) in |= rv[i - tilesY];
+                if (bz + 1 < tilesZ) in |= rv[i + tilesY];
+                if (!(f[i] & in & ~mine) && !((mine << 1 | mine >> 1) & f[i] & ~mine))
+                    continue;  // no new seed from the four neighbours, none along x
+                const unsigned long long rn = fill_row(f[i] & in, f[i]);
+                if (rn != mine) {
+                    rv[i] = rn;
+                    ch = 1;
+                }
             }
-        }
         if (!__syncthreads_or(ch)) break;
     }
     for (int i = threadIdx.x; i < rows; i += 1024) reached[i] = r[i];
 }
 
-// reach = open in every tile the pre-pass reached
+// reach = open in every tile the pre-pass reached; one workgroup per row of tiles,
+// threads along the words of a voxel row
 __global__ __launch_bounds__(256) void flood_tile_seed_kernel(
     const FloodParams p, const unsigned long long *__restrict__ reached) {
-    const int ty = threadIdx.x & 15, tz = threadIdx.x >> 4;
+    const unsigned long long rbits = reached[blockIdx.x];
+    if (!rbits) return;
     const int tilesY = (p.Y + 15) >> 4;
-    const int xw = blockIdx.x % p.XW;
-    const int by = (blockIdx.x / p.XW) % tilesY;
-    const int bz = blockIdx.x / (p.XW * tilesY);
-    if (!((reached[(size_t)bz * tilesY + by] >> xw) & 1ull)) return;
-    const int y = by * 16 + ty, z = bz * 16 + tz;
-    if (y < p.Y && z < p.Z) {
+    const int by = blockIdx.x % tilesY, bz = blockIdx.x / tilesY;
+    const int per = 256 / p.XW;
+    const int xw = threadIdx.x % p.XW, sub = threadIdx.x / p.XW;
+    if (sub >= per || !((rbits >> xw) & 1ull)) return;
+    for (int r = sub; r < 256; r += per) {
+        const int y = by * 16 + (r & 15), z = bz * 16 + (r >> 4);
+        if (y >= p.Y || z >= p.Z) continue;
         const size_t w = ((size_t)z * p.Y + y) * p.XW + xw;
         p.reach[w] = p.open[w];
     }
@@ -273,38 +296,53 @@ __global__ __launch_bounds__(256) void flood_apply_kernel(uint8_t *__restrict__ 
     state[i] = s;
 }
 
-// The same for X % 8 == 0: one thread owns the 8 voxels of one byte of the bit plane.
-__global__ __launch_bounds__(256) void flood_apply8_kernel(uint8_t *__restrict__ state,
-                                                           const FloodParams p) {
+// The same for X % 8 == 0 (T = uint8_t: one thread owns the 8 voxels of one byte of
+// the bit plane, 8-byte state access) and X % 16 == 0 (T = uint16_t: 16 voxels, 16-byte
+// state access).
+template <typename T>
+__global__ __launch_bounds__(256) void flood_apply_wide_kernel(uint8_t *__restrict__ state,
+                                                               const FloodParams p) {
+    constexpr int kV = 8 * (int)sizeof(T);  // voxels per thread
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int rowBytes = p.XW * 8, gmax = p.X / 8;
+    const int rowUnits = p.XW * 64 / kV, gmax = p.X / kV;
     const size_t nrows = (size_t)p.Y * p.Z;
     if (t >= nrows * gmax) return;
     const size_t row = t / gmax;
     const int g = (int)(t % gmax);
     const int y = (int)(row % p.Y), z = (int)(row / p.Y);
-    const uint8_t *rb = (const uint8_t *)p.reach + row * rowBytes + g;
+    const T *rb = (const T *)p.reach + row * rowUnits + g;
+    const unsigned top = kV - 1, mask = (kV == 8) ? 0xFFu : 0xFFFFu;
     const unsigned e = rb[0];
-    unsigned nb = ((e << 1) | (e >> 1)) & 0xFFu;
-    if (g > 0) nb |= rb[-1] >> 7;
-    if (g + 1 < gmax) nb |= (rb[1] & 1u) << 7;
-    if (y > 0) nb |= rb[-(ptrdiff_t)rowBytes];
-    if (y + 1 < p.Y) nb |= rb[rowBytes];
-    if (z > 0) nb |= rb[-(ptrdiff_t)rowBytes * p.Y];
-    if (z + 1 < p.Z) nb |= rb[(ptrdiff_t)rowBytes * p.Y];
+    unsigned nb = ((e << 1) | (e >> 1)) & mask;
+    if (g > 0) nb |= (unsigned)rb[-1] >> top;
+    if (g + 1 < gmax) nb |= ((unsigned)rb[1] & 1u) << top;
+    if (y > 0) nb |= rb[-(ptrdiff_t)rowUnits];
+    if (y + 1 < p.Y) nb |= rb[rowUnits];
+    if (z > 0) nb |= rb[-(ptrdiff_t)rowUnits * p.Y];
+    if (z + 1 < p.Z) nb |= rb[(ptrdiff_t)rowUnits * p.Y];
     if (t == 0) nb |= 1u;  // the seed is visited whatever happens (:100)
     if ((e | nb) == 0u) return;
     // bit j -> 0x01 in byte j
     auto spread = [](unsigned b) -> unsigned long long {
-        const unsigned long long v = (b * 0x0101010101010101ull) & 0x8040201008040201ull;
+        const unsigned long long v = ((b & 0xFFu) * 0x0101010101010101ull) & 0x8040201008040201ull;
         return ((v + 0x7F7F7F7F7F7F7F7Full) >> 7) & 0x0101010101010101ull;
     };
-    unsigned long long *sp = (unsigned long long *)(state + row * p.X + (size_t)g * 8);
-    const unsigned long long s = *sp;
-    const unsigned long long E = spread(e), N = spread(nb);
     // carved: clear bit0, set bit1; pushed by a carved neighbour: set bit1
-    const unsigned long long ns = (s & ~E) | ((E | N) << 1);
-    if (ns != s) *sp = ns;
+    unsigned long long *sp = (unsigned long long *)(state + row * p.X + (size_t)g * kV);
+    if (kV == 8) {
+        const unsigned long long s = sp[0];
+        const unsigned long long E = spread(e), N = spread(nb);
+        const unsigned long long ns = (s & ~E) | ((E | N) << 1);
+        if (ns != s) sp[0] = ns;
+    } else {
+        const ulonglong2 s = *(const ulonglong2 *)sp;
+        const unsigned long long E0 = spread(e), N0 = spread(nb);
+        const unsigned long long E1 = spread(e >> 8), N1 = spread(nb >> 8);
+        ulonglong2 ns;
+        ns.x = (s.x & ~E0) | ((E0 | N0) << 1);
+        ns.y = (s.y & ~E1) | ((E1 | N1) << 1);
+        if (ns.x != s.x || ns.y != s.y) *(ulonglong2 *)sp = ns;
+    }
 }
 
 }  // namespace arvx
