@@ -126,6 +126,7 @@ class Model {
     void handleUnseen() {  // src/Model.cpp:36-47
         std::cout << "LOG - PP: marking unseen voxels from model." << std::endl;
         pristine_ = false;
+        painted_ = true;
         for (size_t i = 0; i < state_.size(); ++i)
             if (!(state_[i] & kSeen)) {
                 state_[i] = (uint8_t)(kOcc | kUnseenPaint);
@@ -154,6 +155,9 @@ class Model {
     // still exactly as constructed (every voxel MODEL_COLOR, nothing seen): the GPU
     // side can start from arvx_state_reset instead of an N-byte upload
     bool pristine() const { return pristine_; }
+    // no explicit colours and no UNSEEN paint: the state bytes are the whole model, so
+    // a device plane can be downloaded straight into state_data()
+    bool plain() const { return !painted_ && colors_.empty(); }
     uint8_t *state_data() {
         pristine_ = false;  // the caller may write through the pointer
         return state_.data();
@@ -206,6 +210,7 @@ class Model {
     const float voxel_size;
     std::vector<uint8_t> state_;
     bool pristine_ = true;
+    bool painted_ = false;  // handleUnseen() ran: some bytes may carry kUnseenPaint
     std::unordered_map<int, Vec4f> colors_;
     std::unordered_map<int, std::vector<DCLR>> color_lists_;
 

@@ -127,6 +127,10 @@ class Session {
     }
 
     void pull_state() {
+        if (model_.plain()) {  // nothing but occupied/seen bits on either side
+            check(arvx_state_download(ctx_, model_.state_data()), "arvx_state_download");
+            return;
+        }
         std::vector<uint8_t> st(model_.voxels());
         check(arvx_state_download(ctx_, st.data()), "arvx_state_download");
         model_.absorb_state(st.data());

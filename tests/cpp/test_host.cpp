@@ -112,6 +112,13 @@ static int run_carve(const char *scene, const char *out, const char *mode) {
         else if (!std::strcmp(mode, "closest")) {
             arvx::carve(intr, model, views);
             arvx::reconstructClosestColor(intr, model, views);
+        } else if (!std::strcmp(mode, "recarve_colored")) {
+            // a coloured, painted model goes through the carve again: state comes back
+            // through Model::absorb_state, colours and paint stay where voxels survive
+            arvx::carve(intr, model, views);
+            arvx::reconstructClosestColor(intr, model, views);
+            model.handleUnseen();
+            arvx::carve(intr, model, views);
         } else if (!std::strcmp(mode, "average_unseen")) {
             arvx::carve(intr, model, views);
             arvx::reconstructAvgColor(intr, model, views);

@@ -57,7 +57,7 @@ def read_result(path, n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["carve", "carve_steps", "closest", "average_unseen", "fast",
-                                  "closure", "closure_mc"])
+                                  "closure", "closure_mc", "recarve_colored"])
 def test_cpp_entry_points_match_oracle(host_bin, oracle, tmp_path, mode):
     X, Y, Z, V = 30, 20, 12, 5
     sc = scenes.syn.sphere_scene(32, V, W=96, H=72, with_images=True)
@@ -77,9 +77,13 @@ def test_cpp_entry_points_match_oracle(host_bin, oracle, tmp_path, mode):
         assert "LOG - VC: starting carving process (version 1)." in r.stdout
         st = oracle.carve(X, Y, Z, s, M, sc.masks, state=st0)
     want = oracle.model_from_state(st)
-    if mode == "closest":
+    if mode in ("closest", "recarve_colored"):
         want = oracle.color(X, Y, Z, s, M, sc.campos, sc.images, 0, want)
         assert "LOG - CR: starting color reconstruction (closest color)." in r.stdout
+    if mode == "recarve_colored":
+        # handleUnseen paints never-seen voxels; the second carve changes nothing the
+        # first did not (it is idempotent) -- but a never-seen voxel stays unseen too
+        want = oracle.handle_unseen(st, want)
     if mode in ("average_unseen", "closure", "closure_mc"):
         want = oracle.color(X, Y, Z, s, M, sc.campos, sc.images, 1, want)
         want = oracle.handle_unseen(st, want)
