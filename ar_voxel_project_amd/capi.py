@@ -366,4 +366,7 @@ class Context:
         out = {k: int(getattr(s, k)) for k, _ in Stats._fields_ if k != "reserved"}
         out["slices_evaluated"] = int(s.reserved[0])  # 256-voxel slices projected exactly
         out["open_voxels_in_slices"] = int(s.reserved[1])  # of those voxels, not yet finished
+        # (sub-tile, view) pairs that went to the exact kernel although every open voxel
+        # got the same answer there: what a perfect classifier would have decided
+        out["mixed_pairs_uniform"] = int(s.reserved[2])
         return out

@@ -612,6 +612,7 @@ int arvx_get_stats(arvx_ctx *ctx, arvx_stats *out) {
     out->surface_voxels = h[4];
     out->reserved[0] = h[5];  // 256-voxel slices evaluated exactly
     out->reserved[1] = h[6];  // voxels among them that were not yet carved+seen
+    out->reserved[2] = h[7];  // mixed pairs whose open voxels all got the same answer
     return ARVX_OK;
 }
 

@@ -626,6 +626,7 @@ __device__ __forceinline__ bool exact_view(const CarveParams &p, const int view,
         for (int j = 0; j < 4; ++j) p01[r][j] = p0 + m1 * dwx[j];
     }
     const float wlim = (float)p.W - 0.5f, hlim = (float)p.H - 0.5f;
+    bool saw_bg = false, saw_other = false;  // ARVX_CARVE_STATS only
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (!__any(st[k] != kDone4)) continue;  // these 256 voxels are finished
@@ -667,8 +668,17 @@ __device__ __forceinline__ bool exact_view(const CarveParams &p, const int view,
             const uint32_t isbg = in[j] ? ((word[j] >> (pix[j] & 31)) & 1u) : 0u;
             const uint32_t seen = in[j] ? (2u << (8 * j)) : 0u;
             w = (w | seen) & ~(isbg << (8 * j));
+            if (p.flags & 2u) {
+                const bool open = ((st[k] >> (8 * j)) & 0xffu) != 2u;  // not carved-and-seen yet
+                saw_bg = saw_bg || (open && isbg);
+                saw_other = saw_other || (open && !isbg);
+            }
         }
         st[k] = w;
+    }
+    if (p.flags & 2u) {  // pairs whose evaluated voxels all got the same answer
+        const bool uniform = !(__any(saw_bg) && __any(saw_other));
+        if (lane == 0 && uniform) atomicAdd(&p.stats[7], 1ull);
     }
     return __all(st[0] == kDone4 && st[1] == kDone4 && st[2] == kDone4 && st[3] == kDone4);
 }
