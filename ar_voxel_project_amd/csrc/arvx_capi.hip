@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -537,12 +538,21 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
 #ifdef ARVX_TIMELINE
         if (ctx->d_timeline) (void)hipFree(ctx->d_timeline);
         ctx->d_timeline = nullptr;
-        ctx->timeline_n = pgrid;
-        ARVX_HIP(hipMalloc(&ctx->d_timeline, (size_t)pgrid * 32));
-        ARVX_HIP(hipMemsetAsync(ctx->d_timeline, 0, (size_t)pgrid * 32, ctx->stream));
+        ctx->timeline_n = (int64_t)pgrid * 4;  // one record per WAVE of the persistent kernel
+        ARVX_HIP(hipMalloc(&ctx->d_timeline, (size_t)pgrid * 4 * 32));
+        ARVX_HIP(hipMemsetAsync(ctx->d_timeline, 0, (size_t)pgrid * 4 * 32, ctx->stream));
         p.timeline = (unsigned long long *)ctx->d_timeline;
 #endif
-        if (aligned)
+        // the statistics counters live in the row-mapped variant
+        static const bool row_map = getenv("ARVX_EXACT_ROWS") != nullptr;
+        const bool blocks = !row_map && !(flags & ARVX_CARVE_STATS);
+        if (blocks && aligned)
+            hipLaunchKernelGGL(arvx::carve_exact_blocks_kernel<true>, dim3(pgrid), dim3(256), 0,
+                               ctx->stream, p);
+        else if (blocks)
+            hipLaunchKernelGGL(arvx::carve_exact_blocks_kernel<false>, dim3(pgrid), dim3(256), 0,
+                               ctx->stream, p);
+        else if (aligned)
             hipLaunchKernelGGL(arvx::carve_exact_kernel<true>, dim3(pgrid), dim3(256), 0,
                                ctx->stream, p);
         else
