@@ -73,11 +73,13 @@ __device__ __forceinline__ int global_z(const CarveParams &p, int lz) {
 // rint may return k: u - rint(u) is exact, so the tie is detected and fixed.
 __device__ __forceinline__ bool pixel_from_quotients(float u, float v, int W, float wlim,
                                                      float hlim, int &pix) {
-    const bool in = (u > -0.5f) && (u < wlim) && (v > -0.5f) && (v < hlim);
+    // (bitwise &: with && the compiler builds a chain of exec-masked branches per voxel)
+    const bool in = (u > -0.5f) & (u < wlim) & (v > -0.5f) & (v < hlim);
     float ru = rintf(u), rv = rintf(v);
     ru += (u - ru == 0.5f) ? 1.f : 0.f;
     rv += (v - rv == 0.5f) ? 1.f : 0.f;
-    pix = in ? (int)rv * W + (int)ru : 0;  // 0 keeps the unconditional table read in bounds
+    const int at = (int)rv * W + (int)ru;
+    pix = in ? at : 0;  // 0 keeps the unconditional table read in bounds
     return in;
 }
 

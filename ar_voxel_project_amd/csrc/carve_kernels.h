@@ -809,19 +809,26 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
                                                   const bool fast, const float (&wy)[2],
                                                   const float (&wx)[4], const float (&wz)[2],
                                                   uint32_t (&st)[4]) {
-    const float *__restrict__ Mv = p.M + 12 * view;
     const uint32_t *__restrict__ bgv = p.bg + (size_t)view * p.bgWords;
-    // the matrix stays in scalar registers as floats and is widened where it is used:
-    // twelve doubles per lane would not fit next to the hoisted row sums
-    float mf[3][3];
-    double p3[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        mf[r][0] = Mv[4 * r];
-        mf[r][1] = Mv[4 * r + 1];
-        mf[r][2] = Mv[4 * r + 2];
-        p3[r] = (double)Mv[4 * r + 3];
-    }
+    // The matrix of a view is the same for every lane and never written by a kernel:
+    // it is fetched through the scalar cache into scalar registers (the compiler itself
+    // issues vector loads here, a full memory round trip at the head of every view), stays
+    // there as floats and is widened where it is used -- twelve doubles per lane would not
+    // fit next to the hoisted row sums.
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 row0, row1, row2;
+    const float *Mv = p.M + 12 * view;
+    asm volatile(
+        "s_load_dwordx4 %0, %3, 0x0\n\t"
+        "s_load_dwordx4 %1, %3, 0x10\n\t"
+        "s_load_dwordx4 %2, %3, 0x20\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(row0), "=&s"(row1), "=&s"(row2)
+        : "s"(Mv)
+        : "memory");
+    const float mf[3][3] = {{row0.x, row0.y, row0.z}, {row1.x, row1.y, row1.z},
+                            {row2.x, row2.y, row2.z}};
+    const double p3[3] = {(double)row0.w, (double)row1.w, (double)row2.w};
     const float wlim = (float)p.W - 0.5f, hlim = (float)p.H - 0.5f;
 #pragma unroll
     for (int byi = 0; byi < 2; ++byi) {
@@ -939,8 +946,8 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
                 while (mixed && !done) {
                     const int b = __ffsll((long long)mixed) - 1;
                     mixed &= mixed - 1;
-                    done = exact_view_blocks(p, p.v0 + 64 * c + b, (fastdiv >> b) & 1ull, wy, wx,
-                                             wz, st);
+                    done = exact_view_blocks(p, __builtin_amdgcn_readfirstlane(p.v0 + 64 * c + b),
+                                             (fastdiv >> b) & 1ull, wy, wx, wz, st);
 #ifdef ARVX_TIMELINE
                     wave_timeline.views++;
                     wave_timeline.cur++;
