@@ -481,8 +481,9 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
     p.nchunks = (count + 63) / 64;
     p.coarseMixed = p.coarseFg = nullptr;
     p.coarseCarved = nullptr;
-    p.workCount = p.workNext = nullptr;
+    p.workCount = p.poolNext = nullptr;
     p.workCap = 0;
+    p.nwaves = 0;
     p.itemInfo = p.itemMasks = nullptr;
     if (flags & ARVX_CARVE_STATS) ARVX_HIP(hipMemsetAsync(ctx->d_stats, 0, 64, ctx->stream));
     // rows of tiles (along x) are dealt to the XCDs cyclically: see carve_fused_kernel
@@ -495,10 +496,20 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
         const size_t words = ncoarse * p.nchunks;
         const size_t off_work = (2 * words * sizeof(unsigned long long) + ncoarse + 255) / 256 * 256;
         const size_t nctr = (size_t)arvx::kWorkLists * arvx::kCounterStride;
-        const size_t cap = ((size_t)grid + arvx::kWorkLists - 1) / arvx::kWorkLists * 4;
+        // sub-tile i (of 4 per tile) goes to list i % 32 of one of the two halves: a list
+        // never gets more than every 32nd sub-tile
+        const size_t cap = ((size_t)p.tilesX * p.tilesY * p.tilesZ * 4 + 31) / 32;
         const size_t nitems = cap * arvx::kWorkLists;
-        const size_t need = off_work + 2 * nctr * sizeof(int) +
-                            nitems * (1 + 2 * (size_t)p.nchunks) * sizeof(unsigned long long) + 64;
+        // one persistent workgroup per workgroup slot of the chip (4 per CU at 128 VGPRs)
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        const unsigned pgrid = (unsigned)(ncu > 0 ? ncu : 256) * 4u;
+        const size_t nwaves = (size_t)pgrid * 4;
+        const size_t nctr_pool = (size_t)arvx::kPoolCounters * arvx::kCounterStride;
+        const size_t ints = nctr + nctr_pool;  // list fill counters, pool ticket counters
+        const size_t off_items = off_work + (ints * sizeof(int) + 255) / 256 * 256;
+        const size_t need =
+            off_items + nitems * (1 + 2 * (size_t)p.nchunks) * sizeof(unsigned long long) + 64;
         if (ctx->coarse_bytes < need) {
             if (ctx->d_coarse) (void)hipFree(ctx->d_coarse);
             ctx->d_coarse = nullptr;
@@ -512,11 +523,12 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
         if (split) {
             int *base = (int *)((uint8_t *)ctx->d_coarse + off_work);
             p.workCount = base;
-            p.workNext = base + nctr;
+            p.poolNext = base + nctr;
+            p.nwaves = (int)nwaves;
             p.workCap = (int)cap;
-            p.itemInfo = (unsigned long long *)(base + 2 * nctr);
+            p.itemInfo = (unsigned long long *)((uint8_t *)ctx->d_coarse + off_items);
             p.itemMasks = p.itemInfo + nitems;
-            ARVX_HIP(hipMemsetAsync(base, 0, 2 * nctr * sizeof(int), ctx->stream));
+            ARVX_HIP(hipMemsetAsync(base, 0, ints * sizeof(int), ctx->stream));
         }
         hipLaunchKernelGGL(arvx::carve_coarse_kernel, dim3((unsigned)((ncoarse + 3) / 4)),
                            dim3(256), 0, ctx->stream, p);
@@ -531,16 +543,14 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
             hipLaunchKernelGGL(arvx::carve_classify_kernel<false>, dim3(grid), dim3(256), 0,
                                ctx->stream, p);
         ARVX_HIP(hipGetLastError());
-        // one workgroup per workgroup slot of the chip (4 per CU at 128 VGPRs)
-        int ncu = 256;
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        const unsigned pgrid = (unsigned)(ncu > 0 ? ncu : 256) * 4u;
+        const unsigned pgrid = (unsigned)(p.nwaves / 4);
 #ifdef ARVX_TIMELINE
         if (ctx->d_timeline) (void)hipFree(ctx->d_timeline);
         ctx->d_timeline = nullptr;
         ctx->timeline_n = (int64_t)pgrid * 4;  // one record per WAVE of the persistent kernel
-        ARVX_HIP(hipMalloc(&ctx->d_timeline, (size_t)pgrid * 4 * 32));
-        ARVX_HIP(hipMemsetAsync(ctx->d_timeline, 0, (size_t)pgrid * 4 * 32, ctx->stream));
+        ctx->timeline_rec = 64;
+        ARVX_HIP(hipMalloc(&ctx->d_timeline, (size_t)pgrid * 4 * 64));
+        ARVX_HIP(hipMemsetAsync(ctx->d_timeline, 0, (size_t)pgrid * 4 * 64, ctx->stream));
         p.timeline = (unsigned long long *)ctx->d_timeline;
 #endif
         // the statistics counters live in the row-mapped variant
@@ -565,6 +575,7 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
     if (ctx->d_timeline) (void)hipFree(ctx->d_timeline);
     ctx->d_timeline = nullptr;
     ctx->timeline_n = grid;
+    ctx->timeline_rec = 32;
     ARVX_HIP(hipMalloc(&ctx->d_timeline, (size_t)grid * 32));
     ARVX_HIP(hipMemsetAsync(ctx->d_timeline, 0, (size_t)grid * 32, ctx->stream));
     p.timeline = (unsigned long long *)ctx->d_timeline;
@@ -870,7 +881,7 @@ extern "C" int arvx_debug_timeline(arvx_ctx *ctx, unsigned long long *out, int64
     *n = ctx->timeline_n;
     if (out && ctx->d_timeline) {
         ARVX_HIP(hipStreamSynchronize(ctx->stream));
-        ARVX_HIP(hipMemcpy(out, ctx->d_timeline, (size_t)ctx->timeline_n * 32,
+        ARVX_HIP(hipMemcpy(out, ctx->d_timeline, (size_t)ctx->timeline_n * ctx->timeline_rec,
                            hipMemcpyDeviceToHost));
     }
     return ARVX_OK;

@@ -57,6 +57,7 @@ struct Ctx {
     uint8_t *owned() const { return d_state + (size_t)(z0 - ze0) * X * Y; }
     void *d_timeline = nullptr;  // ARVX_TIMELINE diagnostic builds only
     int64_t timeline_n = 0;
+    int timeline_rec = 32;  // bytes per record
     bool fresh_pending = false;  // arvx_state_reset is lazy (arvx_capi.hip: materialize)
     void *d_coarse = nullptr;    // coarse pre-pass masks of the carve kernel
     size_t coarse_bytes = 0;

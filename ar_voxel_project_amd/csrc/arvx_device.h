@@ -20,7 +20,9 @@ constexpr int kSubX = 16;                           // x extent of one wave's su
 constexpr int kCoarseX = 64;  // pre-pass tile: 64 x (8 << cyShift) x (8 << czShift) voxels
 constexpr uint32_t kDone4 = 0x02020202u;            // 4 voxels carved+seen
 constexpr int kMaxImageDim = 16384;
-constexpr int kWorkLists = 32;      // work lists / pull counters of carve_exact_kernel
+constexpr int kWorkLists = 64;      // work lists carve_classify_kernel appends to: 32 for the
+                                    // sub-tiles with many views to evaluate, then 32 for the rest
+constexpr int kPoolCounters = 8;    // ticket counters of the shared part of the work
 constexpr int kCounterStride = 64;  // ints between counters: one 256-byte block each
 constexpr int kMaxChunks = 4;       // split launch handles up to 256 views (else: fused kernel)
 
@@ -51,7 +53,8 @@ struct CarveParams {
     uint8_t *coarseCarved;            // [ncoarse] 0 undecided, 1 carved, 2 all seen, 3 none seen
     // work lists of the split launch (carve_classify_kernel -> carve_exact_kernel)
     int *workCount;                 // [kWorkLists * kCounterStride] items per list
-    int *workNext;                  // [kWorkLists * kCounterStride] next item to pull
+    int *poolNext;                  // [kPoolCounters * kCounterStride] tickets of the shared pool
+    int nwaves;                     // waves of the persistent exact kernel
     int workCap;                    // capacity of one list
     unsigned long long *itemInfo;   // [kWorkLists * workCap] tx | ty<<16 | tz<<32 | wave<<48 | fg<<50
     unsigned long long *itemMasks;  // [..][nchunks][2] mixed views, shared-rcp division ok

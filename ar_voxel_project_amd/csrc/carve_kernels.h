@@ -192,22 +192,38 @@ struct TimelineScope {
     }
 };
 
-// persistent kernels: one record per wave {start, end, items pulled, views evaluated}
+// persistent kernels: one record per wave {start, end, items | ticks to the end of the
+// first item << 32, views | ticks to the end of the first view << 32}
 struct WaveTimeline {
     unsigned long long *slot;
-    unsigned long long items, views, cur, longest;  // longest = most views spent on one item
+    unsigned long long t0, items, views, first_item, first_view;
+    unsigned long long snaps = 0, looks = 0, failed = 0, last_pull = 0, snap_ticks = 0, tmp = 0;
+    unsigned long long snap_at[6] = {0, 0, 0, 0, 0, 0};
     __device__ explicit WaveTimeline(unsigned long long *base)
-        : slot(nullptr), items(0), views(0), cur(0), longest(0) {
+        : slot(nullptr), t0(0), items(0), views(0), first_item(0), first_view(0) {
         if ((threadIdx.x & 63) == 0 && base) {
-            slot = base + 4ull * (blockIdx.x * 4 + (threadIdx.x >> 6));
-            slot[0] = __builtin_amdgcn_s_memrealtime();
+            slot = base + 8ull * (blockIdx.x * 4 + (threadIdx.x >> 6));
+            t0 = __builtin_amdgcn_s_memrealtime();
+            slot[0] = t0;
         }
+    }
+    __device__ void view_done() {
+        if (slot && views++ == 0) first_view = __builtin_amdgcn_s_memrealtime() - t0;
+    }
+    __device__ void item_done() {
+        if (slot && items++ == 0) first_item = __builtin_amdgcn_s_memrealtime() - t0;
     }
     __device__ ~WaveTimeline() {
         if (slot) {
             slot[1] = __builtin_amdgcn_s_memrealtime();
-            slot[2] = items | (longest << 32);
-            slot[3] = views;
+            slot[2] = items | (first_item << 32);
+            slot[3] = views | (first_view << 32);
+            slot[4] = snaps | (looks << 32);
+            slot[5] = failed | (last_pull << 32);
+            slot[6] = snap_ticks;  // total ticks spent in the counter snapshots
+            slot[7] = (snap_at[0] & 0x3ff) | ((snap_at[1] >> 4 & 0x3ff) << 10) |
+                      ((snap_at[2] >> 4 & 0x3ff) << 20) | ((snap_at[3] >> 4 & 0x3ff) << 30) |
+                      ((snap_at[4] >> 4 & 0x3ff) << 40) | ((snap_at[5] >> 4 & 0x3ff) << 50);
         }
     }
 };
@@ -612,7 +628,20 @@ __global__ __launch_bounds__(256, 8) void carve_classify_kernel(const CarveParam
     } else if (lane == 0) {
         // hand the sub-tile to carve_exact_kernel: where it is, whether some view sees
         // all of it, and per chunk of 64 views which ones to evaluate (and how to divide)
-        const int cls = blockIdx.x & (kWorkLists - 1);
+        // spread the sub-tiles evenly: with the list taken from the block index the lists
+        // of some tile rows hold most of the surface and the others are empty from the start
+        // (consecutive sub-tiles go to consecutive lists: no list can get more than its
+        // share of all sub-tiles, which is what the host sizes the lists for)
+        // The long items (most of the views to evaluate) go to the first half of the
+        // lists, which the waves take as their fixed share at the start; the short ones
+        // are what the kernel ends on.
+        int nmixed = 0;
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; ++c)
+            if (c < p.nchunks) nmixed += __popcll(mixed_c[c]);
+        const int heavy = (nmixed * 5 >= (p.v1 - p.v0) * 3) ? 0 : kWorkLists / 2;
+        const int cls =
+            heavy + (((((tz * p.tilesY + ty) * p.tilesX + tx) << 2) + wave) & (kWorkLists / 2 - 1));
         const int pos = atomicAdd(&p.workCount[cls * kCounterStride], 1);
         const size_t it = (size_t)cls * p.workCap + pos;
         p.itemInfo[it] = (unsigned long long)tx | ((unsigned long long)ty << 16) |
@@ -703,29 +732,55 @@ __device__ __forceinline__ bool exact_view(const CarveParams &p, const int view,
     return __all(st[0] == kDone4 && st[1] == kDone4 && st[2] == kDone4 && st[3] == kDone4);
 }
 
-// Persistent waves pull sub-tiles from kWorkLists lists (one padded counter each: a
-// single atomic word sustains only ~90 pulls per microsecond, and counters sharing a
-// line serialise).  A wave starts on its own list and moves on when it is empty, so
-// every wave ends once all lists are drained.
-// (Tried and dropped: weight classes with the heavy items first -- every wave then sits
-// in long items at the same time and the whole kernel gets slower; a per-pull snapshot
-// of all counters instead of the walk -- 32 cache lines per pull instead of one.)
-template <class Body>
+// Work distribution of the persistent exact kernels.  carve_classify_kernel appends the
+// sub-tiles that need exact work to kWorkLists lists (one padded counter each: a single
+// atomic word sustains only ~90 appends per microsecond, and counters sharing a line
+// serialise; sub-tile i goes to list i % 32 of its half -- long items first, short items
+// second -- so the lists of a half are equally long and neighbouring sub-tiles are far
+// apart in the concatenation).  Every wave first takes ONE item of that concatenation by
+// its own index -- the start of the kernel needs no atomic at all -- and then draws the
+// rest one by one from a shared pool (ticket counters): the waves come back at different
+// times, so the counters are not crowded; when its counters run past the end it leaves.
+// (Measured before this, with waves pulling EVERY item with atomics from shared lists, in
+// several arrangements -- a walk over the lists, snapshots of all counters, weight
+// classes: all 4096 waves queue on the same few lines for ~20 us at the start, and spend
+// tens of microseconds at the end finding out that nothing is left; a failed pull costs
+// ~10 us when a thousand waves go for the same list.  A fully static split by the
+// number of views per item removed that but left the waves unevenly loaded: the cost of
+// an item is not known before it has run.)
+// kParts: every item is handed out as kParts units (body gets the part index).
+template <int kParts, class Body>
 __device__ __forceinline__ void for_each_work_item(const CarveParams &p, const int lane,
                                                    Body body) {
-    const int first = (blockIdx.x * 4 + (threadIdx.x >> 6)) & (kWorkLists - 1);
-    for (int r = 0; r < kWorkLists; ++r) {
-        const int cls = (first + r) & (kWorkLists - 1);
-        const int n = p.workCount[cls * kCounterStride];
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // inclusive prefix of the list fill counts, list l in lane l
+    int incl = (lane < kWorkLists) ? p.workCount[lane * kCounterStride] : 0;
+#pragma unroll
+    for (int d = 1; d < kWorkLists; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    const int T = __builtin_amdgcn_readlane(incl, kWorkLists - 1) * kParts;  // units
+    auto run = [&](int u) {  // flat unit u -> item f = u / kParts -> its place in the lists
+        const int f = u / kParts;
+        const int l = __popcll(__ballot(lane < kWorkLists && incl <= f));
+        const int start = l ? __builtin_amdgcn_readlane(incl, l - 1) : 0;
+        body((size_t)l * p.workCap + (f - start), u % kParts);
+    };
+    const int share = 1;  // (a larger fixed share balanced worse at 1024^3)
+    const int b0 = min(T, w * share), b1 = min(T, b0 + share);
+    for (int f = b0; f < b1; ++f) run(f);
+    // the pool: flat items pool0 + k + kPoolCounters * ticket, counter k
+    const int pool0 = (int)min((long long)T, (long long)p.nwaves * share);
+    for (int r = 0; r < kPoolCounters; ++r) {
+        const int k = (w + r) & (kPoolCounters - 1);
         for (;;) {
-            if (__hip_atomic_load(&p.workNext[cls * kCounterStride], __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_AGENT) >= n)
-                break;  // (a relaxed look first: drained lists are not hammered)
-            int item = 0;
-            if (lane == 0) item = atomicAdd(&p.workNext[cls * kCounterStride], 1);
-            item = __builtin_amdgcn_readfirstlane(item);
-            if (item >= n) break;
-            body((size_t)cls * p.workCap + item);
+            int ticket = 0;
+            if (lane == 0) ticket = atomicAdd(&p.poolNext[k * kCounterStride], 1);
+            ticket = __builtin_amdgcn_readfirstlane(ticket);
+            const long long f = (long long)pool0 + k + (long long)kPoolCounters * ticket;
+            if (f >= T) break;
+            run((int)f);
         }
     }
 }
@@ -736,7 +791,7 @@ __global__ __launch_bounds__(256, 4) void carve_exact_kernel(const CarveParams p
     WaveTimeline wave_timeline(p.timeline);
 #endif
     const int lane = threadIdx.x & 63;
-    for_each_work_item(p, lane, [&](const size_t it) {
+    for_each_work_item<1>(p, lane, [&](const size_t it, const int) {
             const unsigned long long info = p.itemInfo[it];
             const int tx = (int)(info & 0xffffu), ty = (int)((info >> 16) & 0xffffu);
             const int tz = (int)((info >> 32) & 0xffffu), wave = (int)((info >> 48) & 3u);
@@ -764,15 +819,12 @@ __global__ __launch_bounds__(256, 4) void carve_exact_kernel(const CarveParams p
                     done = exact_view(p, p.v0 + 64 * c + b, (fastdiv >> b) & 1ull, dwy, dwx, dwz,
                                       st, lane);
 #ifdef ARVX_TIMELINE
-                    wave_timeline.views++;
-                    wave_timeline.cur++;
+                    wave_timeline.view_done();
 #endif
                 }
             }
 #ifdef ARVX_TIMELINE
-            wave_timeline.items++;
-            if (wave_timeline.cur > wave_timeline.longest) wave_timeline.longest = wave_timeline.cur;
-            wave_timeline.cur = 0;
+            wave_timeline.item_done();
 #endif
             subtile_store<kAligned4>(p, t, st);
     });
@@ -804,7 +856,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 // view `view` on the blocks of one sub-tile.  st[byi * 2 + bzi] byte bxi = state of
 // voxel (4 bxi + lx, 4 byi + ly, 4 bzi + lz) of the sub-tile.
 // (Tried and dropped: consuming the table reads of one group only after the next group
-// has been projected -- no faster, and the extra live registers spill inside the loop.)
+// has been projected -- no faster, and the extra live registers spill inside the loop;
+// handing out half sub-tiles (eight blocks) as the unit of work -- the tail gets shorter
+// but the per-view set-up is paid twice: 27 % more view evaluations, 4 % slower.)
 __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const int view,
                                                   const bool fast, const float (&wy)[2],
                                                   const float (&wx)[4], const float (&wz)[2],
@@ -901,7 +955,7 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
     const int rowSlot = ((4 * (lane >> 5)) * 8 + ((lane >> 2) & 7)) * 4 + (lane & 3);  // + 32 k
     // block map: one voxel per block
     const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
-    for_each_work_item(p, lane, [&](const size_t it) {
+    for_each_work_item<1>(p, lane, [&](const size_t it, const int) {
             const unsigned long long info = p.itemInfo[it];
             const int tx = (int)(info & 0xffffu), ty = (int)((info >> 16) & 0xffffu);
             const int tz = (int)((info >> 32) & 0xffffu), wave = (int)((info >> 48) & 3u);

@@ -25,24 +25,43 @@ with capi.Context(N, N, N, sc.voxel_size) as ctx:
     n = C.c_int64()
     lib.arvx_debug_timeline.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     lib.arvx_debug_timeline(ctx._h, None, C.byref(n))
-    buf = np.zeros((n.value, 4), np.uint64)
+    buf = np.zeros((n.value, 8), np.uint64)
     lib.arvx_debug_timeline(ctx._h, buf.ctypes.data_as(C.c_void_p), C.byref(n))
 ok = buf[:, 0] > 0
 t0 = buf[ok, 0].min()
 start = (buf[ok, 0] - t0).astype(np.float64) / 100.0
 end = (buf[ok, 1] - t0).astype(np.float64) / 100.0
 items, views = (buf[ok, 2] & np.uint64(0xffffffff)).astype(int), buf[ok, 3].astype(int)
-longest = (buf[ok, 2] >> np.uint64(32)).astype(int)
+first_item_us = (buf[ok, 2] >> np.uint64(32)).astype(np.float64) / 100.0
+first_view_us = (buf[ok, 3] >> np.uint64(32)).astype(np.float64) / 100.0
+views = (buf[ok, 3] & np.uint64(0xffffffff)).astype(int)
 late = end > np.percentile(end, 90)
 total = end.max()
+snaps = (buf[ok, 4] & np.uint64(0xffffffff)).astype(int)
+looks = (buf[ok, 4] >> np.uint64(32)).astype(int)
+failed = (buf[ok, 5] & np.uint64(0xffffffff)).astype(int)
+last_pull_us = (buf[ok, 5] >> np.uint64(32)).astype(np.float64) / 100.0
+snap_us = (buf[ok, 6] & np.uint64(0xffffffff)).astype(np.float64) / 100.0
+store_us = (buf[ok, 6] >> np.uint64(32)).astype(np.float64) / 100.0
+few = np.nonzero(views <= 3)[0][:12]
+many = np.nonzero(views >= 30)[0][:6]
+sample = [{"views": int(views[i]), "items": int(items[i]), "start": float(start[i]),
+           "first_view": float(first_view_us[i]), "first_item": float(first_item_us[i]),
+           "end": float(end[i]), "snaps": int(snaps[i]), "looks": int(looks[i]),
+           "failed": int(failed[i]), "last_pull": float(last_pull_us[i]), "snap_us": float(snap_us[i]), "snap_at_us": [round(((int(buf[ok][i, 7]) >> (10 * k)) & 0x3ff) * (0.01 if k == 0 else 0.16), 2) for k in range(6)], "store_us": float(store_us[i])} for i in list(few) + list(many)]
 pct = lambda a: {k: float(np.percentile(a, q)) for k, q in (("p1", 1), ("p10", 10), ("p50", 50), ("p90", 90), ("p99", 99), ("max", 100))}
 print(json.dumps({
     "grid": N, "waves": int(ok.sum()), "kernel_us": float(total),
     "wave_start_us": pct(start), "wave_end_us": pct(end),
     "busy_fraction": float((end - start).sum() / (total * ok.sum())),
     "items_per_wave": pct(items), "views_per_wave": pct(views),
-    "longest_item_views_per_wave": pct(longest),
-    "late_waves(end>p90)": {"items": pct(items[late]), "views": pct(views[late]), "longest": pct(longest[late])},
+    "first_view_end_us": pct(first_view_us), "first_item_end_us": pct(first_item_us),
+    "late_waves(end>p90)": {"items": pct(items[late]), "views": pct(views[late])},
     "corr_end_views": float(np.corrcoef(end, views)[0, 1]),
+    "end_us_by_views": {str(lo): [int(((views >= lo) & (views < hi)).sum()),
+                                  float(np.median(end[(views >= lo) & (views < hi)]))
+                                  if ((views >= lo) & (views < hi)).any() else None]
+                        for lo, hi in ((0, 1), (1, 4), (4, 8), (8, 12), (12, 16), (16, 24), (24, 32), (32, 99))},
+    "sample": sample,
     "items": int(items.sum()), "views": int(views.sum()),
     "us_per_view_mean": float((end - start).sum() / max(1, views.sum()))}))
