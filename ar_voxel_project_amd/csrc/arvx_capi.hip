@@ -496,9 +496,9 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
         const size_t words = ncoarse * p.nchunks;
         const size_t off_work = (2 * words * sizeof(unsigned long long) + ncoarse + 255) / 256 * 256;
         const size_t nctr = (size_t)arvx::kWorkLists * arvx::kCounterStride;
-        // sub-tile i (of 4 per tile) goes to list i % 32 of one of the two halves: a list
-        // never gets more than every 32nd sub-tile
-        const size_t cap = ((size_t)p.tilesX * p.tilesY * p.tilesZ * 4 + 31) / 32;
+        // sub-tile i (of 4 per tile) goes to list i % 8 of one of eight weight classes: a
+        // list never gets more than every 8th sub-tile
+        const size_t cap = ((size_t)p.tilesX * p.tilesY * p.tilesZ * 4 + 7) / 8;
         const size_t nitems = cap * arvx::kWorkLists;
         // one persistent workgroup per workgroup slot of the chip (4 per CU at 128 VGPRs)
         int ncu = 256;
@@ -535,6 +535,9 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
         ARVX_HIP(hipGetLastError());
     }
     const bool aligned = (p.X % 4 == 0) && (((uintptr_t)p.state & 3u) == 0);
+    // the statistics counters live in the row-mapped variant
+    static const bool row_map = getenv("ARVX_EXACT_ROWS") != nullptr;
+    const bool blocks = split && !row_map && !(flags & ARVX_CARVE_STATS);
     if (split) {
         if (aligned)
             hipLaunchKernelGGL(arvx::carve_classify_kernel<true>, dim3(grid), dim3(256), 0,
@@ -553,9 +556,6 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
         ARVX_HIP(hipMemsetAsync(ctx->d_timeline, 0, (size_t)pgrid * 4 * 64, ctx->stream));
         p.timeline = (unsigned long long *)ctx->d_timeline;
 #endif
-        // the statistics counters live in the row-mapped variant
-        static const bool row_map = getenv("ARVX_EXACT_ROWS") != nullptr;
-        const bool blocks = !row_map && !(flags & ARVX_CARVE_STATS);
         if (blocks && aligned)
             hipLaunchKernelGGL(arvx::carve_exact_blocks_kernel<true>, dim3(pgrid), dim3(256), 0,
                                ctx->stream, p);

@@ -20,8 +20,8 @@ constexpr int kSubX = 16;                           // x extent of one wave's su
 constexpr int kCoarseX = 64;  // pre-pass tile: 64 x (8 << cyShift) x (8 << czShift) voxels
 constexpr uint32_t kDone4 = 0x02020202u;            // 4 voxels carved+seen
 constexpr int kMaxImageDim = 16384;
-constexpr int kWorkLists = 64;      // work lists carve_classify_kernel appends to: 32 for the
-                                    // sub-tiles with many views to evaluate, then 32 for the rest
+constexpr int kWorkLists = 64;      // work lists carve_classify_kernel appends to: 8 weight
+                                    // classes (most views to evaluate first) of 8 lists
 constexpr int kPoolCounters = 8;    // ticket counters of the shared part of the work
 constexpr int kCounterStride = 64;  // ints between counters: one 256-byte block each
 constexpr int kMaxChunks = 4;       // split launch handles up to 256 views (else: fused kernel)

@@ -197,8 +197,6 @@ struct TimelineScope {
 struct WaveTimeline {
     unsigned long long *slot;
     unsigned long long t0, items, views, first_item, first_view;
-    unsigned long long snaps = 0, looks = 0, failed = 0, last_pull = 0, snap_ticks = 0, tmp = 0;
-    unsigned long long snap_at[6] = {0, 0, 0, 0, 0, 0};
     __device__ explicit WaveTimeline(unsigned long long *base)
         : slot(nullptr), t0(0), items(0), views(0), first_item(0), first_view(0) {
         if ((threadIdx.x & 63) == 0 && base) {
@@ -218,12 +216,6 @@ struct WaveTimeline {
             slot[1] = __builtin_amdgcn_s_memrealtime();
             slot[2] = items | (first_item << 32);
             slot[3] = views | (first_view << 32);
-            slot[4] = snaps | (looks << 32);
-            slot[5] = failed | (last_pull << 32);
-            slot[6] = snap_ticks;  // total ticks spent in the counter snapshots
-            slot[7] = (snap_at[0] & 0x3ff) | ((snap_at[1] >> 4 & 0x3ff) << 10) |
-                      ((snap_at[2] >> 4 & 0x3ff) << 20) | ((snap_at[3] >> 4 & 0x3ff) << 30) |
-                      ((snap_at[4] >> 4 & 0x3ff) << 40) | ((snap_at[5] >> 4 & 0x3ff) << 50);
         }
     }
 };
@@ -632,16 +624,14 @@ __global__ __launch_bounds__(256, 8) void carve_classify_kernel(const CarveParam
         // of some tile rows hold most of the surface and the others are empty from the start
         // (consecutive sub-tiles go to consecutive lists: no list can get more than its
         // share of all sub-tiles, which is what the host sizes the lists for)
-        // The long items (most of the views to evaluate) go to the first half of the
-        // lists, which the waves take as their fixed share at the start; the short ones
-        // are what the kernel ends on.
+        // Eight weight classes of eight lists, the longest items (most views to evaluate)
+        // first: the waves start on those, and what the kernel ends on are the short ones.
         int nmixed = 0;
 #pragma unroll
         for (int c = 0; c < kMaxChunks; ++c)
             if (c < p.nchunks) nmixed += __popcll(mixed_c[c]);
-        const int heavy = (nmixed * 5 >= (p.v1 - p.v0) * 3) ? 0 : kWorkLists / 2;
-        const int cls =
-            heavy + (((((tz * p.tilesY + ty) * p.tilesX + tx) << 2) + wave) & (kWorkLists / 2 - 1));
+        const int wclass = 7 - min(7, nmixed * 8 / (p.v1 - p.v0 + 1));
+        const int cls = wclass * 8 + (((((tz * p.tilesY + ty) * p.tilesX + tx) << 2) + wave) & 7);
         const int pos = atomicAdd(&p.workCount[cls * kCounterStride], 1);
         const size_t it = (size_t)cls * p.workCap + pos;
         p.itemInfo[it] = (unsigned long long)tx | ((unsigned long long)ty << 16) |
@@ -735,9 +725,8 @@ __device__ __forceinline__ bool exact_view(const CarveParams &p, const int view,
 // Work distribution of the persistent exact kernels.  carve_classify_kernel appends the
 // sub-tiles that need exact work to kWorkLists lists (one padded counter each: a single
 // atomic word sustains only ~90 appends per microsecond, and counters sharing a line
-// serialise; sub-tile i goes to list i % 32 of its half -- long items first, short items
-// second -- so the lists of a half are equally long and neighbouring sub-tiles are far
-// apart in the concatenation).  Every wave first takes ONE item of that concatenation by
+// serialise; the lists form eight weight classes, long items first, and sub-tile i goes
+// to list i % 8 of its class).  Every wave first takes ONE item of that concatenation by
 // its own index -- the start of the kernel needs no atomic at all -- and then draws the
 // rest one by one from a shared pool (ticket counters): the waves come back at different
 // times, so the counters are not crowded; when its counters run past the end it leaves.
@@ -749,8 +738,11 @@ __device__ __forceinline__ bool exact_view(const CarveParams &p, const int view,
 // number of views per item removed that but left the waves unevenly loaded: the cost of
 // an item is not known before it has run.)
 // kParts: every item is handed out as kParts units (body gets the part index).
+// srank / nstatic: this wave's rank among the nstatic waves that take an item by index
+// (srank < 0: none for this wave).
 template <int kParts, class Body>
 __device__ __forceinline__ void for_each_work_item(const CarveParams &p, const int lane,
+                                                   const int srank, const int nstatic,
                                                    Body body) {
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     // inclusive prefix of the list fill counts, list l in lane l
@@ -768,10 +760,12 @@ __device__ __forceinline__ void for_each_work_item(const CarveParams &p, const i
         body((size_t)l * p.workCap + (f - start), u % kParts);
     };
     const int share = 1;  // (a larger fixed share balanced worse at 1024^3)
-    const int b0 = min(T, w * share), b1 = min(T, b0 + share);
-    for (int f = b0; f < b1; ++f) run(f);
+    if (srank >= 0) {
+        const int b0 = min(T, srank * share), b1 = min(T, b0 + share);
+        for (int f = b0; f < b1; ++f) run(f);
+    }
     // the pool: flat items pool0 + k + kPoolCounters * ticket, counter k
-    const int pool0 = (int)min((long long)T, (long long)p.nwaves * share);
+    const int pool0 = (int)min((long long)T, (long long)nstatic * share);
     for (int r = 0; r < kPoolCounters; ++r) {
         const int k = (w + r) & (kPoolCounters - 1);
         for (;;) {
@@ -791,7 +785,8 @@ __global__ __launch_bounds__(256, 4) void carve_exact_kernel(const CarveParams p
     WaveTimeline wave_timeline(p.timeline);
 #endif
     const int lane = threadIdx.x & 63;
-    for_each_work_item<1>(p, lane, [&](const size_t it, const int) {
+    for_each_work_item<1>(p, lane, blockIdx.x * 4 + (threadIdx.x >> 6), p.nwaves,
+                          [&](const size_t it, const int) {
             const unsigned long long info = p.itemInfo[it];
             const int tx = (int)(info & 0xffffu), ty = (int)((info >> 16) & 0xffffu);
             const int tz = (int)((info >> 32) & 0xffffu), wave = (int)((info >> 48) & 3u);
@@ -955,7 +950,13 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
     const int rowSlot = ((4 * (lane >> 5)) * 8 + ((lane >> 2) & 7)) * 4 + (lane & 3);  // + 32 k
     // block map: one voxel per block
     const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
-    for_each_work_item<1>(p, lane, [&](const size_t it, const int) {
+    // every fourth workgroup starts with the fill and joins the exact work afterwards;
+    // the others end with whatever is left of the fill
+    // (Tried and dropped: leaving the pure fill of the decided tiles to a quarter of these
+    // workgroups so that it overlaps the exact work -- the fill saturates HBM and the
+    // exact waves, which live on memory latency, slow down by more than the fill costs.)
+    for_each_work_item<1>(p, lane, blockIdx.x * 4 + (threadIdx.x >> 6), p.nwaves,
+                          [&](const size_t it, const int) {
             const unsigned long long info = p.itemInfo[it];
             const int tx = (int)(info & 0xffffu), ty = (int)((info >> 16) & 0xffffu);
             const int tz = (int)((info >> 32) & 0xffffu), wave = (int)((info >> 48) & 3u);
@@ -1003,15 +1004,12 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
                     done = exact_view_blocks(p, __builtin_amdgcn_readfirstlane(p.v0 + 64 * c + b),
                                              (fastdiv >> b) & 1ull, wy, wx, wz, st);
 #ifdef ARVX_TIMELINE
-                    wave_timeline.views++;
-                    wave_timeline.cur++;
+                    wave_timeline.view_done();
 #endif
                 }
             }
 #ifdef ARVX_TIMELINE
-            wave_timeline.items++;
-            if (wave_timeline.cur > wave_timeline.longest) wave_timeline.longest = wave_timeline.cur;
-            wave_timeline.cur = 0;
+            wave_timeline.item_done();
 #endif
             // blocks -> rows
             wave_lds_sync();

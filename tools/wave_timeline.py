@@ -37,18 +37,11 @@ first_view_us = (buf[ok, 3] >> np.uint64(32)).astype(np.float64) / 100.0
 views = (buf[ok, 3] & np.uint64(0xffffffff)).astype(int)
 late = end > np.percentile(end, 90)
 total = end.max()
-snaps = (buf[ok, 4] & np.uint64(0xffffffff)).astype(int)
-looks = (buf[ok, 4] >> np.uint64(32)).astype(int)
-failed = (buf[ok, 5] & np.uint64(0xffffffff)).astype(int)
-last_pull_us = (buf[ok, 5] >> np.uint64(32)).astype(np.float64) / 100.0
-snap_us = (buf[ok, 6] & np.uint64(0xffffffff)).astype(np.float64) / 100.0
-store_us = (buf[ok, 6] >> np.uint64(32)).astype(np.float64) / 100.0
 few = np.nonzero(views <= 3)[0][:12]
 many = np.nonzero(views >= 30)[0][:6]
 sample = [{"views": int(views[i]), "items": int(items[i]), "start": float(start[i]),
            "first_view": float(first_view_us[i]), "first_item": float(first_item_us[i]),
-           "end": float(end[i]), "snaps": int(snaps[i]), "looks": int(looks[i]),
-           "failed": int(failed[i]), "last_pull": float(last_pull_us[i]), "snap_us": float(snap_us[i]), "snap_at_us": [round(((int(buf[ok][i, 7]) >> (10 * k)) & 0x3ff) * (0.01 if k == 0 else 0.16), 2) for k in range(6)], "store_us": float(store_us[i])} for i in list(few) + list(many)]
+           "end": float(end[i])} for i in list(few) + list(many)]
 pct = lambda a: {k: float(np.percentile(a, q)) for k, q in (("p1", 1), ("p10", 10), ("p50", 50), ("p90", 90), ("p99", 99), ("max", 100))}
 print(json.dumps({
     "grid": N, "waves": int(ok.sum()), "kernel_us": float(total),
