@@ -543,7 +543,10 @@ __device__ __forceinline__ void subtile_store(const CarveParams &p, const SubTil
 // workgroups -- alone it reaches twice the write rate of the fill branch below, but after
 // it the classification still takes 190 us by itself (it is bound by arithmetic, and the
 // branch's stores hide under it: 311 us together); run beside the classification on a
-// second stream, both slow down (388 us): the classification lives on memory latency too.)
+// second stream, both slow down (388 us): the classification lives on memory latency too.
+// A fixed grid walking a compacted list of the undecided tiles classifies them in 127 us,
+// but fill (227 us as a row-walking kernel) + list + classification is still more than
+// the 311 us of this kernel, in which the stores hide under the classification.)
 template <bool kAligned4>
 __global__ __launch_bounds__(256, 8) void carve_classify_kernel(const CarveParams p) {
     // same block -> tile map as carve_fused_kernel (rows of tiles dealt to the XCDs)
