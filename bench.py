@@ -246,7 +246,7 @@ def main():
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "physical_GBps": (traffic / (r["kern_ms"] * 1e-3) / 1e9) if traffic else None,
-                "kernel": "carve_coarse_kernel + carve_classify_kernel + carve_exact_kernel "
+                "kernel": "carve_coarse_kernel + carve_classify_kernel + carve_exact_blocks_kernel "
                           "(one arvx_carve call)",
                 "kernel_ms": r["kern_ms"],
                 "algorithmic_bytes": alg_bytes,
