@@ -546,7 +546,10 @@ __device__ __forceinline__ void subtile_store(const CarveParams &p, const SubTil
 // second stream, both slow down (388 us): the classification lives on memory latency too.
 // A fixed grid walking a compacted list of the undecided tiles classifies them in 127 us,
 // but fill (227 us as a row-walking kernel) + list + classification is still more than
-// the 311 us of this kernel, in which the stores hide under the classification.)
+// the 311 us of this kernel, in which the stores hide under the classification.  Four tiles
+// along x per workgroup (a quarter of the launches, whole 256-byte lines per fill store):
+// 399 us -- the kernel is not bound by its launches but by the ~5 us chain of dependent reads
+// of every undecided sub-tile at 8 waves per SIMD, and fatter workgroups lengthen that chain.)
 template <bool kAligned4>
 __global__ __launch_bounds__(256, 8) void carve_classify_kernel(const CarveParams p) {
     // same block -> tile map as carve_fused_kernel (rows of tiles dealt to the XCDs)
