@@ -595,11 +595,21 @@ __global__ __launch_bounds__(256, 8) void carve_classify_kernel(const CarveParam
         if (myv < p.v1) {
             const unsigned long long cm = p.coarseMixed[(size_t)ct * p.nchunks + chunk];
             const unsigned long long cf = p.coarseFg[(size_t)ct * p.nchunks + chunk];
-            if ((cf >> lane) & 1ull)
+            // (one value from both words: their loads go out together, not one per branch)
+            unsigned sel = (unsigned)((cf >> lane) & 1ull) | ((unsigned)((cm >> lane) & 1ull) << 1);
+            // the lane's matrix is requested together with the masks, not after them
+            float Mr[12];
+            const float4 *Mp = reinterpret_cast<const float4 *>(p.M + 12 * myv);
+            float4 m0 = Mp[0], m1 = Mp[1], m2 = Mp[2];
+            // (or the compiler moves every load back behind the branch that needs it)
+            asm volatile("" : "+v"(sel), "+v"(m0.x), "+v"(m1.x), "+v"(m2.x));
+            Mr[0] = m0.x; Mr[1] = m0.y; Mr[2] = m0.z; Mr[3] = m0.w;
+            Mr[4] = m1.x; Mr[5] = m1.y; Mr[6] = m1.z; Mr[7] = m1.w;
+            Mr[8] = m2.x; Mr[9] = m2.y; Mr[10] = m2.z; Mr[11] = m2.w;
+            if (sel & 1u)
                 cls = kClsFg;  // inherited: the coarse rectangle contains this one
-            else if ((cm >> lane) & 1ull)
-                cls = classify_box(p.M + 12 * myv, box, p.W, p.H,
-                                   p.sat + (size_t)myv * p.satStride);
+            else if (sel & 2u)
+                cls = classify_box(Mr, box, p.W, p.H, p.sat + (size_t)myv * p.satStride);
         }
         fast_c[chunk] = __ballot((cls & kFastDiv) != 0);
         cls &= 3;
