@@ -528,7 +528,7 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
             p.workCap = (int)cap;
             p.itemInfo = (unsigned long long *)((uint8_t *)ctx->d_coarse + off_items);
             p.itemMasks = p.itemInfo + nitems;
-            ARVX_HIP(hipMemsetAsync(base, 0, ints * sizeof(int), ctx->stream));
+            // (carve_coarse_kernel zeroes the `ints` counters at base)
         }
         hipLaunchKernelGGL(arvx::carve_coarse_kernel, dim3((unsigned)((ncoarse + 3) / 4)),
                            dim3(256), 0, ctx->stream, p);

@@ -137,6 +137,11 @@ __device__ inline int classify_box(const float *__restrict__ M, const BoxW b, in
 // foreground" for the coarse box are that for every sub-tile too, so the main
 // kernel re-classifies only the views left in the coarse "mixed" mask.
 __global__ __launch_bounds__(256) void carve_coarse_kernel(const CarveParams p) {
+    // the work-list and pool counters of the kernels that follow start at zero (this
+    // saves a memset launch in front of every carve)
+    if (blockIdx.x == 0 && p.workCount)
+        for (int i = threadIdx.x; i < (kWorkLists + kPoolCounters) * kCounterStride; i += 256)
+            p.workCount[i] = 0;  // poolNext follows workCount in the same allocation
     const int ct = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int ncoarse = p.coarseX * p.coarseY * p.coarseZ;
