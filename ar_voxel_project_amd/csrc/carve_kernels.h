@@ -876,8 +876,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // view `view` on the blocks of one sub-tile.  st[byi * 2 + bzi] byte bxi = state of
 // voxel (4 bxi + lx, 4 byi + ly, 4 bzi + lz) of the sub-tile.
-// (Tried and dropped: consuming the table reads of one group only after the next group
-// has been projected -- no faster, and the extra live registers spill inside the loop;
+// (Tried and dropped: consuming the table reads of one group while the next group is
+// projected -- no faster, and the extra live registers spill inside the loop;
 // handing out half sub-tiles (eight blocks) as the unit of work -- the tail gets shorter
 // but the per-view set-up is paid twice: 27 % more view evaluations, 4 % slower.)
 __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const int view,
@@ -905,8 +905,20 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
                             {row2.x, row2.y, row2.z}};
     const double p3[3] = {(double)row0.w, (double)row1.w, (double)row2.w};
     const float wlim = (float)p.W - 0.5f, hlim = (float)p.H - 0.5f;
+    // All sixteen blocks are projected before the table is read: ONE wait per view.  (The
+    // sub-tiles that stay fully occupied pay every wait in every view, and they are what
+    // the kernel ends on.)
+    int pix[4][4];
+    bool in[4][4];
 #pragma unroll
     for (int byi = 0; byi < 2; ++byi) {
+#pragma unroll
+        for (int bzi = 0; bzi < 2; ++bzi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                in[2 * byi + bzi][j] = false;
+                pix[2 * byi + bzi][j] = 0;
+            }
         if (!__any(st[2 * byi] != kDone4 || st[2 * byi + 1] != kDone4)) continue;
         double p01[3][4];
         {
@@ -924,17 +936,14 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
         }
 #pragma unroll
         for (int bzi = 0; bzi < 2; ++bzi) {
-            uint32_t w = st[2 * byi + bzi];
+            const int m = 2 * byi + bzi;
+            const uint32_t w = st[m];
             if (!__any(w != kDone4)) continue;  // these four blocks are finished
             const double dwz = (double)wz[bzi];
             const double p20 = (double)mf[0][2] * dwz, p21 = (double)mf[1][2] * dwz,
                          p22 = (double)mf[2][2] * dwz;
-            int pix[4];
-            bool in[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                in[j] = false;
-                pix[j] = 0;
                 if (!__any(((w >> (8 * j)) & 0xffu) != 2u)) continue;  // block j is finished
                 const float a0 = row_sum(p01[0][j], p20, p3[0]);
                 const float a1 = row_sum(p01[1][j], p21, p3[1]);
@@ -946,19 +955,25 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
                     u = a0 / a2;
                     v = a1 / a2;
                 }
-                in[j] = pixel_from_quotients(u, v, p.W, wlim, hlim, pix[j]);
+                in[m][j] = pixel_from_quotients(u, v, p.W, wlim, hlim, pix[m][j]);
             }
-            uint32_t word[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) word[j] = bgv[(unsigned)pix[j] >> 5];  // pix = 0 if skipped
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t isbg = in[j] ? ((word[j] >> (pix[j] & 31)) & 1u) : 0u;
-                const uint32_t seen = in[j] ? (2u << (8 * j)) : 0u;
-                w = (w | seen) & ~(isbg << (8 * j));
-            }
-            st[2 * byi + bzi] = w;
         }
+    }
+    uint32_t word[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) word[m][j] = bgv[(unsigned)pix[m][j] >> 5];  // pix = 0 if skipped
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        uint32_t w = st[m];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t isbg = in[m][j] ? ((word[m][j] >> (pix[m][j] & 31)) & 1u) : 0u;
+            const uint32_t seen = in[m][j] ? (2u << (8 * j)) : 0u;
+            w = (w | seen) & ~(isbg << (8 * j));
+        }
+        st[m] = w;
     }
     return __all(st[0] == kDone4 && st[1] == kDone4 && st[2] == kDone4 && st[3] == kDone4);
 }
