@@ -71,17 +71,16 @@ __device__ __forceinline__ int global_z(const CarveParams &p, int lz) {
 //   round(u) >= 0    <=>  u > -0.5        (round(-0.5) = -1, round(-0.4999) = -0)
 //   round(u) <= W-1  <=>  u < W - 0.5     (round(W-0.5) = W)
 // both bounds are exact floats for W <= 16384; NaN/Inf fail them, which is the
-// "outside" x86's cvttss2si gives the reference there.  For u in that range
-// round-half-away equals rint (half-to-even) except at an exact tie k+0.5, where
-// rint may return k: u - rint(u) is exact, so the tie is detected and fixed.
+// "outside" x86's cvttss2si gives the reference there.
 __device__ __forceinline__ bool pixel_from_quotients(float u, float v, int W, float wlim,
                                                      float hlim, int &pix) {
     // (bitwise &: with && the compiler builds a chain of exec-masked branches per voxel)
     const bool in = (u > -0.5f) & (u < wlim) & (v > -0.5f) & (v < hlim);
-    float ru = rintf(u), rv = rintf(v);
-    ru += (u - ru == 0.5f) ? 1.f : 0.f;
-    rv += (v - rv == 0.5f) ? 1.f : 0.f;
-    const int at = (int)rv * W + (int)ru;
+    // inside that range round-half-away is floor(u) + (frac(u) >= 0.5): u - floor(u) is
+    // exact, and for u in (-0.5, 0) it gives -1 + 1 = 0 like roundf's -0
+    const int px = (int)floorf(u) + (__builtin_amdgcn_fractf(u) >= 0.5f ? 1 : 0);
+    const int py = (int)floorf(v) + (__builtin_amdgcn_fractf(v) >= 0.5f ? 1 : 0);
+    const int at = py * W + px;
     pix = in ? at : 0;  // 0 keeps the unconditional table read in bounds
     return in;
 }
