@@ -80,7 +80,7 @@ __device__ __forceinline__ bool pixel_from_quotients(float u, float v, int W, fl
     // exact, and for u in (-0.5, 0) it gives -1 + 1 = 0 like roundf's -0
     const int px = (int)floorf(u) + (__builtin_amdgcn_fractf(u) >= 0.5f ? 1 : 0);
     const int py = (int)floorf(v) + (__builtin_amdgcn_fractf(v) >= 0.5f ? 1 : 0);
-    const int at = py * W + px;
+    const int at = __mul24(py, W) + px;  // (24-bit multiply: full rate; in range where it counts)
     pix = in ? at : 0;  // 0 keeps the unconditional table read in bounds
     return in;
 }
