@@ -202,11 +202,24 @@ struct TimelineScope {
 struct WaveTimeline {
     unsigned long long *slot;
     unsigned long long t0, items, views, first_item, first_view;
+    // ticks: waiting for / reading the item, set-up until the first view, the views,
+    // write-back after the last view
+    unsigned long long ph[4] = {0, 0, 0, 0};
+    unsigned long long mark = 0;
+    __device__ void tick(int k) {
+        if (slot) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (k >= 0) ph[k] += now - mark;
+            mark = now;
+        }
+    }
     __device__ explicit WaveTimeline(unsigned long long *base)
         : slot(nullptr), t0(0), items(0), views(0), first_item(0), first_view(0) {
         if ((threadIdx.x & 63) == 0 && base) {
             slot = base + 8ull * (blockIdx.x * 4 + (threadIdx.x >> 6));
             t0 = __builtin_amdgcn_s_memrealtime();
+            mark = t0;
             slot[0] = t0;
         }
     }
@@ -221,6 +234,8 @@ struct WaveTimeline {
             slot[1] = __builtin_amdgcn_s_memrealtime();
             slot[2] = items | (first_item << 32);
             slot[3] = views | (first_view << 32);
+            slot[4] = ph[0] | (ph[1] << 32);
+            slot[5] = ph[2] | (ph[3] << 32);
         }
     }
 };
@@ -999,6 +1014,10 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
     for_each_work_item<1>(p, lane, blockIdx.x * 4 + (threadIdx.x >> 6), p.nwaves,
                           [&](const size_t it, const int) {
             const unsigned long long info = p.itemInfo[it];
+#ifdef ARVX_TIMELINE
+            { volatile unsigned long long sink = info; (void)sink; }
+            wave_timeline.tick(0);  // since the end of the previous item: the pull + this read
+#endif
             const int tx = (int)(info & 0xffffu), ty = (int)((info >> 16) & 0xffffu);
             const int tz = (int)((info >> 32) & 0xffffu), wave = (int)((info >> 48) & 3u);
             const SubTile t = subtile_of(p, tx, ty, tz, wave, lane);
@@ -1034,6 +1053,9 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
                 wz[b] = (float)(-global_z(p, t.sz0 + 4 * b + lz)) * p.s;
             }
             bool done = false;
+#ifdef ARVX_TIMELINE
+            wave_timeline.tick(1);
+#endif
             for (int c = 0; c < p.nchunks && !done; ++c) {
                 // the same words in every lane: keep them, and the view loop, scalar
                 unsigned long long mixed = uniform64(p.itemMasks[(it * p.nchunks + c) * 2]);
@@ -1051,6 +1073,7 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
             }
 #ifdef ARVX_TIMELINE
             wave_timeline.item_done();
+            wave_timeline.tick(2);
 #endif
             // blocks -> rows
             wave_lds_sync();
@@ -1067,6 +1090,9 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
             for (int k = 0; k < 4; ++k) st[k] = buf[rowSlot + 32 * k];
             wave_lds_sync();
             subtile_store<kAligned4>(p, t, st);
+#ifdef ARVX_TIMELINE
+            wave_timeline.tick(3);
+#endif
     });
 }
 

@@ -42,6 +42,8 @@ many = np.nonzero(views >= 30)[0][:6]
 sample = [{"views": int(views[i]), "items": int(items[i]), "start": float(start[i]),
            "first_view": float(first_view_us[i]), "first_item": float(first_item_us[i]),
            "end": float(end[i])} for i in list(few) + list(many)]
+ph = np.stack([(buf[ok, 4] & np.uint64(0xffffffff)), (buf[ok, 4] >> np.uint64(32)),
+               (buf[ok, 5] & np.uint64(0xffffffff)), (buf[ok, 5] >> np.uint64(32))], 1).astype(np.float64) / 100.0
 pct = lambda a: {k: float(np.percentile(a, q)) for k, q in (("p1", 1), ("p10", 10), ("p50", 50), ("p90", 90), ("p99", 99), ("max", 100))}
 print(json.dumps({
     "grid": N, "waves": int(ok.sum()), "kernel_us": float(total),
@@ -55,6 +57,7 @@ print(json.dumps({
                                   float(np.median(end[(views >= lo) & (views < hi)]))
                                   if ((views >= lo) & (views < hi)).any() else None]
                         for lo, hi in ((0, 1), (1, 4), (4, 8), (8, 12), (12, 16), (16, 24), (24, 32), (32, 99))},
+    "phase_us_per_item(pull+read, set-up, views, write-back)": [float(ph[:, k].sum() / max(1, items.sum())) for k in range(4)],
     "sample": sample,
     "items": int(items.sum()), "views": int(views.sum()),
     "us_per_view_mean": float((end - start).sum() / max(1, views.sum()))}))
