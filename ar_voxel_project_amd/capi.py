@@ -37,6 +37,7 @@ SYMBOLS = [
     "arvx_surface_depth_download",
     "arvx_colors_upload", "arvx_closure", "arvx_closure_count", "arvx_closure_download",
     "arvx_mc_cells", "arvx_mc_cells_download",
+    "arvx_occupancy_packet_words", "arvx_occupancy_compress", "arvx_occupancy_expand",
     "arvx_export_model", "arvx_get_stats", "arvx_selftest_divide",
 ]
 
@@ -124,14 +125,26 @@ def load_library() -> C.CDLL:
     if hasattr(lib, "arvx_mc_cells") or not ab_build:
         lib.arvx_mc_cells.argtypes = [p, C.POINTER(C.c_int64)]
         lib.arvx_mc_cells_download.argtypes = [p, C.POINTER(C.c_int32)]
+    if hasattr(lib, "arvx_occupancy_compress") or not ab_build:
+        lib.arvx_occupancy_packet_words.argtypes = [C.c_int64, C.c_int64]
+        lib.arvx_occupancy_compress.argtypes = [p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        lib.arvx_occupancy_expand.argtypes = [p, C.c_void_p, C.c_int, C.c_int, C.c_int64,
+                                              C.c_int64, C.c_void_p, C.c_void_p]
     for name in SYMBOLS:
         if ab_build and not hasattr(lib, name):
             continue
         fn = getattr(lib, name)
-        if name not in ("arvx_last_error",):
+        if name == "arvx_occupancy_packet_words":
+            fn.restype = C.c_int64
+        elif name not in ("arvx_last_error",):
             fn.restype = C.c_int
     _lib = lib
     return lib
+
+
+def occupancy_packet_words(n_words64: int, cap_words64: int) -> int:
+    """64-bit words of one compressed-occupancy packet (header + room for cap mixed words)."""
+    return int(load_library().arvx_occupancy_packet_words(n_words64, cap_words64))
 
 
 def _check(rc: int) -> None:
@@ -281,6 +294,19 @@ class Context:
 
     def pack_occupancy_global(self, dev_global_words_ptr: int) -> None:
         _check(self._lib.arvx_pack_occupancy_global(self._h, C.c_void_p(dev_global_words_ptr)))
+
+    # -- compressed occupancy exchange (device pointers; see include/arvx/arvx.h) --
+    def occupancy_compress(self, dev_words_ptr: int, n_words64: int, dev_packet_ptr: int,
+                           cap_words64: int) -> None:
+        _check(self._lib.arvx_occupancy_compress(self._h, C.c_void_p(dev_words_ptr), n_words64,
+                                                 C.c_void_p(dev_packet_ptr), cap_words64))
+
+    def occupancy_expand(self, dev_packets_ptr: int, world: int, self_rank: int, n_words64: int,
+                         cap_words64: int, dev_full_ptr: int, dev_overflow_ptr: int) -> None:
+        _check(self._lib.arvx_occupancy_expand(self._h, C.c_void_p(dev_packets_ptr), world,
+                                               self_rank, n_words64, cap_words64,
+                                               C.c_void_p(dev_full_ptr),
+                                               C.c_void_p(dev_overflow_ptr)))
 
     def set_stream(self, stream_ptr: int) -> None:
         _check(self._lib.arvx_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))

@@ -21,6 +21,7 @@
 #include "bitplane_kernels.h"
 #include "fast_carve_kernels.h"
 #include "mc_kernels.h"
+#include "exchange_kernels.h"
 #include <algorithm>
 
 namespace {
@@ -438,6 +439,62 @@ int arvx_pack_occupancy_global(arvx_ctx *ctx, void *dev_global_words) {
                        dim3(256), 0, ctx->stream, ctx->owned(), plane, ctx->z1 - ctx->z0,
                        ctx->stripe_world > 1 ? 0 : ctx->z0, ctx->stripe_world, ctx->stripe_rank,
                        (uint8_t *)dev_global_words);
+    ARVX_HIP(hipGetLastError());
+    return ARVX_OK;
+}
+
+// ---- compressed occupancy exchange -----------------------------------------------------
+
+int64_t arvx_occupancy_packet_words(int64_t n_words64, int64_t cap_words64) {
+    if (n_words64 < 0 || cap_words64 < 0) return -1;
+    return (int64_t)arvx::occ_packet_header(n_words64) + cap_words64;
+}
+
+int arvx_occupancy_compress(arvx_ctx *ctx, const void *dev_words, int64_t n_words64,
+                            void *dev_packet, int64_t cap_words64) {
+    ARVX_CHECK_CTX(ctx);
+    if (!dev_words || !dev_packet || n_words64 <= 0 || cap_words64 < 0)
+        return fail(ARVX_ERR_INVALID, "bad argument");
+    if (((uintptr_t)dev_words | (uintptr_t)dev_packet) & 7u)
+        return fail(ARVX_ERR_INVALID, "buffers must be 8-byte aligned");
+    const long long n = n_words64, nb = (n + 63) / 64;
+    const int nsb = (int)((nb + arvx::kScanBlock - 1) / arvx::kScanBlock);
+    if (int rc = ensure_scratch(ctx, (size_t)(nb + nsb + 1) * sizeof(long long) +
+                                         (size_t)(nb + nsb) * sizeof(int) + 64))
+        return rc;
+    long long *d_off = (long long *)ctx->d_scratch;  // nb group offsets
+    long long *d_boff = d_off + nb;                  // nsb + 1 block offsets, last = total
+    int *d_cnt = (int *)(d_boff + nsb + 1);
+    int *d_bsum = d_cnt + nb;
+    const unsigned gw = (unsigned)((nb + 3) / 4);
+    hipLaunchKernelGGL(arvx::occ_classify_kernel, dim3(gw), dim3(256), 0, ctx->stream,
+                       (const unsigned long long *)dev_words, n, (unsigned long long *)dev_packet,
+                       d_cnt);
+    hipLaunchKernelGGL(arvx::mc_block_sum_kernel, dim3(nsb), dim3(256), 0, ctx->stream, d_cnt,
+                       (int)nb, d_bsum);
+    hipLaunchKernelGGL(arvx::mc_scan_blocks_kernel, dim3(1), dim3(256), 0, ctx->stream, d_bsum, nsb,
+                       d_boff);
+    hipLaunchKernelGGL(arvx::mc_block_scan_kernel, dim3(nsb), dim3(256), 0, ctx->stream, d_cnt,
+                       (int)nb, d_boff, d_off);
+    hipLaunchKernelGGL(arvx::occ_write_kernel, dim3(gw), dim3(256), 0, ctx->stream,
+                       (const unsigned long long *)dev_words, n, (long long)cap_words64, d_off,
+                       d_boff + nsb, (unsigned long long *)dev_packet);
+    ARVX_HIP(hipGetLastError());
+    return ARVX_OK;
+}
+
+int arvx_occupancy_expand(arvx_ctx *ctx, const void *dev_packets, int world, int self_rank,
+                          int64_t n_words64, int64_t cap_words64, void *dev_full_words,
+                          int *dev_overflow) {
+    ARVX_CHECK_CTX(ctx);
+    if (!dev_packets || !dev_full_words || !dev_overflow || world < 1 || self_rank < 0 ||
+        self_rank >= world || n_words64 <= 0 || cap_words64 < 0)
+        return fail(ARVX_ERR_INVALID, "bad argument");
+    const long long n = n_words64, nb = (n + 63) / 64;
+    const long long S = arvx::occ_packet_header(n) + cap_words64;
+    hipLaunchKernelGGL(arvx::occ_expand_kernel, dim3((unsigned)((nb * world + 3) / 4)), dim3(256), 0,
+                       ctx->stream, (const unsigned long long *)dev_packets, S, world, self_rank, n,
+                       (long long)cap_words64, (unsigned long long *)dev_full_words, dev_overflow);
     ARVX_HIP(hipGetLastError());
     return ARVX_OK;
 }

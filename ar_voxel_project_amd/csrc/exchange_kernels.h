@@ -1,0 +1,100 @@
+// exchange_kernels.h -- the packed occupancy of a slab in a form that is cheap to ship.
+//
+// The end-of-carve collective moves the bit-packed occupancy of every slab to
+// every rank; over xGMI that, not the carve, sets the pace of a multi-GPU step.  Most
+// 64-bit words of the packed plane are all-zero (empty space) or all-one (inside the
+// object): a slab is shipped as
+//     [0]                  number of mixed words
+//     [1, 1+nb)            bitmap of the all-one words            (nb = ceil(n / 64))
+//     [1+nb, 1+2nb)        bitmap of the mixed words
+//     [1+2nb, H)           per group of 64 words: how many mixed words precede it (u32)
+//     [H, H+cap)           the mixed words, in order              (H = 1 + 2nb + ceil(nb/2))
+// A receiver rebuilds the plain words with one kernel and no scan of its own.  If a slab
+// has more than `cap` mixed words the packet says so in [0] and the receiver raises a
+// flag: the caller then falls back to the plain all-gather for that exchange.
+#pragma once
+
+#include "arvx_device.h"
+
+namespace arvx {
+
+__host__ __device__ inline long long occ_packet_header(long long n) {
+    const long long nb = (n + 63) / 64;
+    return 1 + 2 * nb + (nb + 1) / 2;
+}
+
+// one wave per group of 64 words: the two bitmaps and the group's number of mixed words
+__global__ __launch_bounds__(256) void occ_classify_kernel(const unsigned long long *__restrict__ words,
+                                                           long long n,
+                                                           unsigned long long *__restrict__ out,
+                                                           int *__restrict__ counts) {
+    const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nb = (n + 63) / 64;
+    if (g >= nb) return;
+    const int lane = threadIdx.x & 63;
+    const long long i = g * 64 + lane;
+    const unsigned long long w = i < n ? words[i] : 0ull;
+    const unsigned long long ones = __ballot(i < n && w == ~0ull);
+    const unsigned long long mixed = __ballot(w != 0ull && w != ~0ull);
+    if (lane == 0) {
+        out[1 + g] = ones;
+        out[1 + nb + g] = mixed;
+        counts[g] = __popcll(mixed);
+    }
+}
+
+// offsets[g] = mixed words before group g (from the block scan of counts)
+__global__ __launch_bounds__(256) void occ_write_kernel(const unsigned long long *__restrict__ words,
+                                                        long long n, long long cap,
+                                                        const long long *__restrict__ offsets,
+                                                        const long long *__restrict__ total,
+                                                        unsigned long long *__restrict__ out) {
+    const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nb = (n + 63) / 64;
+    if (g >= nb) return;
+    const int lane = threadIdx.x & 63;
+    const long long H = occ_packet_header(n);
+    const unsigned long long mixed = out[1 + nb + g];
+    const long long off = offsets[g];
+    if (lane == 0) {
+        reinterpret_cast<unsigned *>(out + 1 + 2 * nb)[g] = (unsigned)off;
+        if (g == 0) out[0] = (unsigned long long)*total;
+    }
+    if ((mixed >> lane) & 1ull) {
+        const long long at = off + __popcll(mixed & ((1ull << lane) - 1ull));
+        if (at < cap) out[H + at] = words[g * 64 + lane];
+    }
+}
+
+// all packets of one all-gather (world x S words) -> the plain words of every OTHER rank's
+// slab, at slab q's place q * n in `full`
+__global__ __launch_bounds__(256) void occ_expand_kernel(const unsigned long long *__restrict__ in,
+                                                         long long S, int world, int self,
+                                                         long long n, long long cap,
+                                                         unsigned long long *__restrict__ full,
+                                                         int *__restrict__ overflow) {
+    const long long nb = (n + 63) / 64;
+    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= nb * world) return;
+    const int q = (int)(wv / nb);
+    const long long g = wv % nb;
+    if (q == self) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long *pk = in + (long long)q * S;
+    if ((long long)pk[0] > cap) {
+        if (g == 0 && lane == 0) *overflow = 1;
+        return;
+    }
+    const long long i = g * 64 + lane;
+    if (i >= n) return;
+    const long long H = occ_packet_header(n);
+    const unsigned long long ones = pk[1 + g], mixed = pk[1 + nb + g];
+    unsigned long long w = ((ones >> lane) & 1ull) ? ~0ull : 0ull;
+    if ((mixed >> lane) & 1ull) {
+        const long long off = reinterpret_cast<const unsigned *>(pk + 1 + 2 * nb)[g];
+        w = pk[H + off + __popcll(mixed & ((1ull << lane) - 1ull))];
+    }
+    full[(long long)q * n + i] = w;
+}
+
+}  // namespace arvx

@@ -13,6 +13,13 @@ every rank holds the whole grid's occupancy.  Two interchangeable forms:
              bit is set, since the words travel as signed int32)
   allgather  the slabs are equal-sized, so the full plane is simply the
              concatenation of the ranks' slab words
+  compressed allgather of PACKETS instead of words: most 64-bit words of a packed slab
+             are all-zero or all-one, so a slab travels as two bitmaps plus its mixed
+             words (arvx_occupancy_compress / _expand, include/arvx/arvx.h).  The packet
+             size is fixed per exchange by `cap` (room for mixed words); it starts at the
+             worst case and retune() shrinks it to what the last exchange needed + 25 %.
+             A slab that outgrows cap raises a flag and wait() redoes that exchange as a
+             plain allgather.
 
 Two ways to cut the grid:
 
@@ -75,11 +82,16 @@ def words_of(nvox: int) -> int:
 
 class OccupancyExchange:
     """The end-of-carve collective on the bit-packed occupancy (1 bit per voxel,
-    voxel i -> bit i % 32 of int32 word i // 32, x fastest)."""
+    voxel i -> bit i % 32 of int32 word i // 32, x fastest).
+
+    mode "compressed" needs `codec`: an object with occupancy_compress /
+    occupancy_expand taking device pointers (capi.Context has them).  The codec must run
+    on torch's current stream (Context.set_stream(torch.cuda.current_stream().cuda_stream)):
+    the collective is ordered against that stream, and so must the kernels around it be."""
 
     def __init__(self, X: int, Y: int, Z: int, world: int, rank: int, device,
-                 mode: str = "allreduce", buffers: int = 2, layout: str = "slab"):
-        assert mode in ("allreduce", "allgather") and layout in ("slab", "striped")
+                 mode: str = "allreduce", buffers: int = 2, layout: str = "slab", codec=None):
+        assert mode in ("allreduce", "allgather", "compressed") and layout in ("slab", "striped")
         self.X, self.Y, self.Z, self.world, self.rank, self.mode = X, Y, Z, world, rank, mode
         self.layout = layout
         self.z0, self.z1 = slab_of(Z, world, rank)
@@ -91,23 +103,42 @@ class OccupancyExchange:
                 raise ValueError("striped slabs need Z % 8 == 0 and X*Y % 64 == 0")
         if (plane * self.z0) % 32 or (world > 1 and (plane * (self.z1 - self.z0)) % 32):
             raise ValueError("slab boundaries must fall on 32-voxel words of the packed plane")
-        if mode == "allgather" and Z % world:
-            raise ValueError("allgather needs equal slabs (world must divide Z)")
+        if mode != "allreduce" and Z % world:
+            raise ValueError(f"{mode} needs equal slabs (world must divide Z)")
         self.off_words = plane * self.z0 // 32
         self.my_words = words_of(plane * (self.z1 - self.z0))
         self.total_words = words_of(plane * Z)
         self.full = [torch.zeros(self.total_words, dtype=torch.int32, device=device)
                      for _ in range(buffers)]
         self.pending = [None] * buffers
+        if mode == "compressed":
+            if codec is None:
+                raise ValueError("compressed exchange needs a codec (a capi.Context)")
+            if (plane * (self.z1 - self.z0)) % 64:
+                raise ValueError("compressed exchange needs slabs of whole 64-bit words")
+            self.codec = codec
+            self.n64 = self.my_words // 2
+            self.header = packet_header_words(self.n64)
+            self.cap_max = self.n64  # every word mixed: cannot overflow
+            self.cap = self.cap_max
+            smax = self.header + self.cap_max
+            self.packet = [torch.zeros(smax, dtype=torch.int64, device=device)
+                           for _ in range(buffers)]
+            self.gathered = [torch.zeros(world * smax, dtype=torch.int64, device=device)
+                             for _ in range(buffers)]
+            self.cap_of = [self.cap] * buffers  # cap the exchange in flight on buffer b used
+            self.unexpanded = [False] * buffers
+            self.overflow = torch.zeros(1, dtype=torch.int32, device=device)  # sticky
+            self.fallbacks = 0
 
     def my_slice(self, b: int) -> torch.Tensor:
         """Where this rank's pack_occupancy output goes inside buffer b."""
         return self.full[b][self.off_words:self.off_words + self.my_words]
 
-    def prepare(self, b: int) -> None:
+    def prepare(self, b: int, verify: bool = True) -> None:
         """Make buffer b reusable: wait for its previous collective, and for
         allreduce re-zero the words owned by other ranks."""
-        self.wait(b)
+        self.wait(b, verify)
         if self.mode == "allreduce" and self.world > 1:
             if self.layout == "striped":
                 self.full[b].zero_()  # own stripes are rewritten by the pack that follows
@@ -122,16 +153,69 @@ class OccupancyExchange:
         t = self.full[b]
         if self.mode == "allreduce":
             w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
-        else:
+        elif self.mode == "allgather":
             w = dist.all_gather_into_tensor(t, self.my_slice(b), async_op=async_op)
+        else:
+            cap = self.cap
+            S = self.header + cap
+            self.codec.occupancy_compress(self.my_slice(b).data_ptr(), self.n64,
+                                          self.packet[b].data_ptr(), cap)
+            w = dist.all_gather_into_tensor(self.gathered[b][:self.world * S],
+                                            self.packet[b][:S], async_op=async_op)
+            self.cap_of[b] = cap
+            self.unexpanded[b] = True
+            if not async_op:
+                self._expand(b, True)
         self.pending[b] = w if async_op else None
 
-    def wait(self, b: int) -> None:
+    def _expand(self, b: int, verify: bool) -> None:
+        self.codec.occupancy_expand(self.gathered[b].data_ptr(), self.world, self.rank, self.n64,
+                                    self.cap_of[b], self.full[b].data_ptr(),
+                                    self.overflow.data_ptr())
+        self.unexpanded[b] = False
+        if verify and self.overflowed():
+            # some slab had more mixed words than cap: redo this exchange in plain words.
+            # Every rank sees the same packets, so every rank takes this branch.
+            self.overflow.zero_()
+            self.fallbacks += 1
+            self.cap = self.cap_max
+            dist.all_gather_into_tensor(self.full[b], self.my_slice(b))
+
+    def overflowed(self) -> bool:
+        """Has any expand since the last reset met a packet that outgrew its cap?
+        (Reads a device flag: synchronises.)"""
+        return self.mode == "compressed" and bool(self.overflow.item())
+
+    def wait(self, b: int, verify: bool = True) -> None:
+        """Buffer b's exchange is complete (in stream order).  compressed: verify=True reads
+        the overflow flag (a host sync) and repairs an overflowed exchange; a pipelined
+        caller passes False and checks overflowed() where it synchronises anyway."""
         w = self.pending[b]
         if w is not None:
             w.wait()
             self.pending[b] = None
+        if self.mode == "compressed" and self.unexpanded[b]:
+            self._expand(b, verify)
 
-    def wait_all(self) -> None:
+    def wait_all(self, verify: bool = True) -> None:
         for b in range(len(self.full)):
-            self.wait(b)
+            self.wait(b, verify)
+
+    def retune(self, b: int = 0) -> int:
+        """compressed: size the packets for what buffer b's last exchange needed (+25 %).
+        Call with no exchange in flight; reads the packets' counts (synchronises).  All
+        ranks hold the same packets, so all arrive at the same cap."""
+        assert self.mode == "compressed" and all(p is None for p in self.pending)
+        if self.world == 1:
+            return self.cap
+        S = self.header + self.cap_of[b]
+        counts = self.gathered[b][:self.world * S].view(self.world, S)[:, 0]
+        need = int(counts.max().item())
+        self.cap = min(self.cap_max, need + need // 4 + 16)
+        return self.cap
+
+
+def packet_header_words(n64: int) -> int:
+    """64-bit words before the mixed words of a packet (include/arvx/arvx.h)."""
+    nb = (n64 + 63) // 64
+    return 1 + 2 * nb + (nb + 1) // 2

@@ -12,8 +12,10 @@ metric  Mvoxel-views/s = voxels x views / carve time  (BASELINE.json)
 N = 1   512^3 grid x 36 views (the configuration the metric is quoted on)
 N > 1   one rank per GPU; rank r carves Z slab r of a grid that holds N x 512^3
         voxels (weak scaling), then ONE collective over RCCL merges the
-        bit-packed occupancy of all slabs: an in-place all-gather by default,
-        or the north star's all-reduce with --collective allreduce.
+        bit-packed occupancy of all slabs: by default an all-gather of compressed
+        packets (two bitmaps + the mixed 64-bit words of each slab, expanded by one
+        kernel on the receivers), --collective allgather for the plain in-place
+        all-gather, --collective allreduce for the north star's all-reduce.
 
 The JSON line also carries `roofline` (algorithmic HBM bytes of SURVEY 8d / the
 carve kernel's launch time measured with HIP events on its own stream) and
@@ -96,10 +98,13 @@ def main():
     ap.add_argument("--grid", type=int, default=512, help="base grid edge per GPU")
     ap.add_argument("--views", type=int, default=36)
     ap.add_argument("--no-cull", action="store_true", help="evaluate every voxel in every view")
-    ap.add_argument("--collective", default="allgather", choices=["allreduce", "allgather", "none"],
-                    help="end-of-carve merge of the packed occupancy: in-place all-gather of "
-                         "contiguous slabs (default: half the bytes), or the north star's "
-                         "all-reduce (SUM over zero-filled planes, striped slabs)")
+    ap.add_argument("--collective", default="compressed", choices=["allreduce", "allgather", "compressed", "none"],
+                    help="end-of-carve merge of the packed occupancy: all-gather of compressed "
+                         "packets (default: bitmaps + mixed words, ~1/7 of the bytes; checked "
+                         "by an untimed trial first and replaced by the plain all-gather if the "
+                         "trial fails or a packet overflows), in-place all-gather of contiguous "
+                         "slabs, or the north star's all-reduce (SUM over zero-filled planes, "
+                         "striped slabs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ablation", action="store_true",
                     help="skip the NO_CULL ablation leg (keeps a profile to one kernel variant)")
@@ -147,7 +152,7 @@ def main():
         nvox_global = X * Y * Z
         flags = capi.CARVE_NO_CULL if (args.no_cull or no_cull) else 0
         # allreduce: striped (load-balanced) slabs; allgather needs contiguous ones
-        layout = "striped" if (world > 1 and collective != "allgather") else "slab"
+        layout = "striped" if (world > 1 and collective in ("allreduce", "none")) else "slab"
         if layout == "striped":
             ctx = capi.Context(X, Y, Z, sc.voxel_size, device=local_rank, stripes=(world, rank))
         else:
@@ -162,7 +167,7 @@ def main():
         ex = None
         if world > 1 and collective != "none":
             ex = sharding.OccupancyExchange(X, Y, Z, world, rank, dev, mode=collective, buffers=2,
-                                            layout=layout)
+                                            layout=layout, codec=ctx)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
               for _ in range(steps)]
         nstep = [0]
@@ -180,19 +185,26 @@ def main():
                 ev[i][1].record(stream)
             if ex is not None:
                 b = nstep[0] % 2
-                ex.prepare(b)
+                ex.prepare(b, verify=False)  # compressed: overflow is checked after drain()
                 ctx.pack_occupancy_global(ex.full[b].data_ptr())
                 ex.launch(b, async_op=True)
             nstep[0] += 1
 
         def drain():
             if ex is not None:
-                ex.wait_all()
+                ex.wait_all(verify=False)
             torch.cuda.synchronize()
 
         for _ in range(warmup):
             step()
         drain()
+        packet_cap = None
+        if ex is not None and collective == "compressed":
+            if nstep[0] == 0:  # --warmup 0: one untimed job to size the packets
+                step()
+                drain()
+            # packets start at the worst-case size; size them to what this scene needs
+            packet_cap = ex.retune((nstep[0] - 1) % 2)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -208,22 +220,52 @@ def main():
         dt = float(tmax.item())
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         occ = None
+        overflowed = bool(ex is not None and ex.overflowed())
+        st = ctx.download_state() if (rank == 0 or ex is not None) else None
+        merged_count_ok = None
+        if ex is not None:  # the merged plane must hold as many voxels as the slabs together
+            cnt = torch.tensor([int((st & 1).sum())], dtype=torch.int64, device=dev)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                merged = ex.full[(nstep[0] - 1) % 2].cpu().numpy().view(np.uint64)
+                merged_count_ok = bool(int(np.bitwise_count(merged).sum()) == int(cnt.item()))
         if rank == 0:
-            st = ctx.download_state()
             occ = float((st & 1).mean())
             if ex is not None:  # the merged plane must hold this rank's planes
                 got = ex.full[(nstep[0] - 1) % 2].cpu().numpy().view(np.uint8)
                 got = got.reshape(Z, X * Y // 8)[ctx.planes]
                 mine = np.packbits((st.reshape(len(ctx.planes), -1) & 1).astype(np.uint8),
                                    axis=1, bitorder="little")
-                merge_ok[0] = bool(np.array_equal(got, mine))
+                merge_ok[0] = bool(np.array_equal(got, mine)) and merged_count_ok
         ctx.close()
         del d_masks
         nplanes = len(ctx.planes) if hasattr(ctx, "planes") else zhi - zlo
+        xbytes = None
+        if ex is not None:  # bytes each rank contributes to the collective
+            xbytes = ((ex.header + packet_cap) * 8 if collective == "compressed"
+                      else ex.total_words * 4 if collective == "allreduce" else ex.my_words * 4)
         return dict(X=X, Y=Y, Z=Z, V=V, dt=dt, kern_ms=kern_ms, sc=sc, occ=occ,
-                    nplanes=nplanes, layout=layout, nvox=nvox_global, merge_ok=merge_ok[0])
+                    nplanes=nplanes, layout=layout, nvox=nvox_global, merge_ok=merge_ok[0],
+                    overflowed=overflowed, exchange_bytes_per_rank=xbytes)
 
+    if world > 1 and args.collective == "compressed":
+        # untimed trial of the compressed exchange: every rank must see a merged plane
+        # that holds all slabs' voxels, else all ranks use the plain all-gather
+        try:
+            t = run_config(args.grid, args.views, 1, 1, "compressed")
+            good = (t["merge_ok"] is not False) and not t["overflowed"]
+        except Exception as e:  # noqa: BLE001 -- any failure means "do not use it"
+            print(f"[bench] rank {rank}: compressed exchange trial failed: {e}", file=sys.stderr)
+            good = False
+        flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not int(flag.item()):
+            args.collective = "allgather"
     r = run_config(args.grid, args.views, args.steps, args.warmup, args.collective)
+    if r["overflowed"]:
+        # a packet outgrew its size inside the timed region: that run does not count
+        args.collective = "allgather"
+        r = run_config(args.grid, args.views, args.steps, args.warmup, args.collective)
     vv = r["nvox"] * r["V"]
     value = vv * args.steps / r["dt"] / 1e6
     ms_per_step = r["dt"] / args.steps * 1e3
@@ -269,6 +311,7 @@ def main():
                    "parallelism": f"z-slab x{world} ({r['layout']})" if world > 1 else "single GPU",
                    "collective": args.collective if world > 1 else "none",
                    "merged_plane_holds_rank0_planes": r["merge_ok"],
+                   "exchange_bytes_per_rank": r["exchange_bytes_per_rank"],
                    "cull": not args.no_cull},
         "carve_kernel_ms": r["kern_ms"], "occupied_fraction": r["occ"],
         "roofline": roofline,

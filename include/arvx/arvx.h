@@ -147,6 +147,24 @@ int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words);
  * Works for contiguous and striped slabs; needs X*Y to be a multiple of 64. */
 int arvx_pack_occupancy_global(arvx_ctx *ctx, void *dev_global_words);
 
+/* Compressed form of a slab's packed occupancy for the end-of-carve exchange (SURVEY 8e:
+ * over xGMI the exchange, not the carve, sets the pace of a multi-GPU step).  Most 64-bit
+ * words of the packed plane are all-zero or all-one: a packet holds the number of mixed
+ * words, two bitmaps (all-one, mixed), per 64 words the number of mixed words before them,
+ * and the mixed words themselves -- arvx_occupancy_packet_words(n, cap) 64-bit words for a
+ * slab of n words with room for cap mixed ones.
+ *   arvx_occupancy_compress: device words of ONE slab -> one packet.
+ *   arvx_occupancy_expand: the `world` packets of an all-gather, back to back -> the plain
+ *   words of every other rank's slab at q * n in dev_full_words (equal slabs); a packet whose
+ *   slab had more than cap mixed words sets *dev_overflow = 1 and is skipped: fall back to
+ *   the plain all-gather of the packed words then. */
+int64_t arvx_occupancy_packet_words(int64_t n_words64, int64_t cap_words64);
+int arvx_occupancy_compress(arvx_ctx *ctx, const void *dev_words, int64_t n_words64,
+                            void *dev_packet, int64_t cap_words64);
+int arvx_occupancy_expand(arvx_ctx *ctx, const void *dev_packets, int world, int self_rank,
+                          int64_t n_words64, int64_t cap_words64, void *dev_full_words,
+                          int *dev_overflow);
+
 /* ---- hot path --------------------------------------------------------- */
 
 /* Dense carve over all views: reference carve(), src/VoxelCarving.cpp:60-72. */

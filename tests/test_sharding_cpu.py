@@ -44,7 +44,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mode, tmpdir, layout="slab"):
+def _worker(rank, world, port, mode, tmpdir, layout="slab", tight_cap=None):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
@@ -58,8 +58,12 @@ def _worker(rank, world, port, mode, tmpdir, layout="slab"):
         sc = scenes.small_sphere(32, V, W=96, H=72)
         s = np.float32(0.512 / 32)
         full = pyoracle.carve(X, Y, Z, s, sc.M, sc.masks, threads=1)
+        codec = None
+        if mode == "compressed":
+            from tests import occ_codec
+            codec = occ_codec.NumpyCodec()
         ex = sharding.OccupancyExchange(X, Y, Z, world, rank, "cpu", mode=mode, buffers=2,
-                                        layout=layout)
+                                        layout=layout, codec=codec)
         # the rank contributes ONLY the planes it owns
         if layout == "striped":
             planes = sharding.stripe_planes(Z, world, rank)
@@ -73,23 +77,67 @@ def _worker(rank, world, port, mode, tmpdir, layout="slab"):
             for z in planes:  # what arvx_pack_occupancy_global does on the device
                 buf[z * wpp:(z + 1) * wpp] = pack_bits(full[z])
             ex.launch(b, async_op=True)
+            if mode == "compressed" and step == 0:
+                # the first exchange ships worst-case packets; size the next ones to need
+                ex.wait_all()
+                assert ex.cap == ex.cap_max
+                cap = ex.retune(0)
+                assert 16 <= cap <= ex.cap_max
+                if tight_cap is not None:
+                    ex.cap = tight_cap  # too small for the sphere's mixed words: must fall back
         ex.wait_all()
         want = pack_bits(full)
         for b in range(2):
             got = ex.full[b].numpy()
             assert np.array_equal(got, want), f"rank {rank} buffer {b} mode {mode}"
+        if mode == "compressed":
+            assert ex.fallbacks == (2 if tight_cap is not None else 0)
+            assert not ex.overflowed()
         open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("mode,layout", [("allreduce", "slab"), ("allgather", "slab"),
-                                         ("allreduce", "striped")])
+                                         ("allreduce", "striped"), ("compressed", "slab")])
 def test_occupancy_exchange_world2_gloo(tmp_path, oracle, mode, layout):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path), layout), nprocs=world,
              join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_compressed_exchange_overflow_falls_back_gloo(tmp_path, oracle):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), "compressed", str(tmp_path), "slab", 1),
+             nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_occupancy_packet_restatement():
+    """The numpy packet codec round-trips and flags overflow (it is the GPU tests' checker)."""
+    from tests import occ_codec
+    rng = np.random.default_rng(5)
+    for n in (1, 63, 64, 65, 1000, 4096 + 7):
+        kind = rng.integers(0, 4, n)
+        w = rng.integers(1, 2 ** 63, n, dtype=np.uint64)
+        w[kind == 0] = 0
+        w[kind == 1] = occ_codec.ONES
+        nm = int(((w != 0) & (w != occ_codec.ONES)).sum())
+        world = 3
+        for cap, over in ((nm, False), (nm + 5, False), (max(nm - 1, 0), nm > 0)):
+            S = occ_codec.header_words(n) + cap
+            assert S == sharding.packet_header_words(n) + cap
+            pk = occ_codec.compress(w, cap)
+            assert len(pk) == S and int(pk[0]) == nm
+            full = np.full(world * n, 0x5A5A, np.uint64)
+            got_over = occ_codec.expand(np.tile(pk, world), world, 1, n, cap, full)
+            assert got_over == over
+            assert np.all(full[n:2 * n] == 0x5A5A)  # own slab untouched
+            if not over:
+                assert np.array_equal(full[:n], w) and np.array_equal(full[2 * n:], w)
+            else:
+                assert np.all(full[:n] == 0x5A5A)
 
 
 def test_stripe_planes():
