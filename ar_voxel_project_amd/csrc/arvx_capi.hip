@@ -490,9 +490,12 @@ int arvx_occupancy_expand(arvx_ctx *ctx, const void *dev_packets, int world, int
     if (!dev_packets || !dev_full_words || !dev_overflow || world < 1 || self_rank < 0 ||
         self_rank >= world || n_words64 <= 0 || cap_words64 < 0)
         return fail(ARVX_ERR_INVALID, "bad argument");
+    if (((uintptr_t)dev_packets & 7u) || ((uintptr_t)dev_full_words & 15u))
+        return fail(ARVX_ERR_INVALID, "packets must be 8-byte, the word plane 16-byte aligned");
     const long long n = n_words64, nb = (n + 63) / 64;
     const long long S = arvx::occ_packet_header(n) + cap_words64;
-    hipLaunchKernelGGL(arvx::occ_expand_kernel, dim3((unsigned)((nb * world + 3) / 4)), dim3(256), 0,
+    const long long per = (nb + 2 * arvx::kExpandChunks - 1) / (2 * arvx::kExpandChunks);
+    hipLaunchKernelGGL(arvx::occ_expand_kernel, dim3((unsigned)((per * world + 3) / 4)), dim3(256), 0,
                        ctx->stream, (const unsigned long long *)dev_packets, S, world, self_rank, n,
                        (long long)cap_words64, (unsigned long long *)dev_full_words, dev_overflow);
     ARVX_HIP(hipGetLastError());

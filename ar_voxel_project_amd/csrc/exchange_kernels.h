@@ -67,34 +67,60 @@ __global__ __launch_bounds__(256) void occ_write_kernel(const unsigned long long
 }
 
 // all packets of one all-gather (world x S words) -> the plain words of every OTHER rank's
-// slab, at slab q's place q * n in `full`
+// slab, at slab q's place q * n in `full`.  A wave rebuilds kExpandChunks x 128 words: lane l
+// owns words 2l, 2l+1 of a chunk (one 16-byte store), i.e. bits 2(l%32), 2(l%32)+1 of group
+// 2c + l/32.
+constexpr int kExpandChunks = 4;
+
 __global__ __launch_bounds__(256) void occ_expand_kernel(const unsigned long long *__restrict__ in,
                                                          long long S, int world, int self,
                                                          long long n, long long cap,
                                                          unsigned long long *__restrict__ full,
                                                          int *__restrict__ overflow) {
     const long long nb = (n + 63) / 64;
+    const long long per = (nb + 2 * kExpandChunks - 1) / (2 * kExpandChunks);  // waves per slab
     const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wv >= nb * world) return;
-    const int q = (int)(wv / nb);
-    const long long g = wv % nb;
+    if (wv >= per * world) return;
+    const int q = (int)(wv / per);
+    const long long c0 = (wv % per) * kExpandChunks;  // first 128-word chunk
     if (q == self) return;
     const int lane = threadIdx.x & 63;
     const unsigned long long *pk = in + (long long)q * S;
     if ((long long)pk[0] > cap) {
-        if (g == 0 && lane == 0) *overflow = 1;
+        if (c0 == 0 && lane == 0) *overflow = 1;
         return;
     }
-    const long long i = g * 64 + lane;
-    if (i >= n) return;
     const long long H = occ_packet_header(n);
-    const unsigned long long ones = pk[1 + g], mixed = pk[1 + nb + g];
-    unsigned long long w = ((ones >> lane) & 1ull) ? ~0ull : 0ull;
-    if ((mixed >> lane) & 1ull) {
-        const long long off = reinterpret_cast<const unsigned *>(pk + 1 + 2 * nb)[g];
-        w = pk[H + off + __popcll(mixed & ((1ull << lane) - 1ull))];
+    const unsigned *goff = reinterpret_cast<const unsigned *>(pk + 1 + 2 * nb);
+    unsigned long long *dst = full + (long long)q * n;
+    const bool pair_ok = (((long long)q * n) & 1) == 0;  // 16-byte aligned pairs
+    const int bit = 2 * (lane & 31);
+    unsigned long long ones[kExpandChunks], mixed[kExpandChunks];
+    long long off[kExpandChunks];
+#pragma unroll
+    for (int k = 0; k < kExpandChunks; ++k) {
+        const long long g = 2 * (c0 + k) + (lane >> 5);
+        const bool ok = g < nb;
+        ones[k] = ok ? pk[1 + g] : 0ull;
+        mixed[k] = ok ? pk[1 + nb + g] : 0ull;
+        off[k] = ok ? (long long)goff[g] : 0;
     }
-    full[(long long)q * n + i] = w;
+#pragma unroll
+    for (int k = 0; k < kExpandChunks; ++k) {
+        const long long i = (c0 + k) * 128 + 2 * lane;
+        if (i >= n) continue;
+        const unsigned m2 = (unsigned)(mixed[k] >> bit) & 3u, o2 = (unsigned)(ones[k] >> bit) & 3u;
+        const long long at = H + off[k] + __popcll(mixed[k] & ((1ull << bit) - 1ull));
+        unsigned long long w0 = (o2 & 1u) ? ~0ull : 0ull, w1 = (o2 & 2u) ? ~0ull : 0ull;
+        if (m2 & 1u) w0 = pk[at];
+        if (m2 & 2u) w1 = pk[at + (m2 & 1u)];
+        if (pair_ok && i + 1 < n) {
+            *reinterpret_cast<ulonglong2 *>(dst + i) = make_ulonglong2(w0, w1);
+        } else {
+            dst[i] = w0;
+            if (i + 1 < n) dst[i + 1] = w1;
+        }
+    }
 }
 
 }  // namespace arvx

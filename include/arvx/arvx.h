@@ -155,7 +155,8 @@ int arvx_pack_occupancy_global(arvx_ctx *ctx, void *dev_global_words);
  * slab of n words with room for cap mixed ones.
  *   arvx_occupancy_compress: device words of ONE slab -> one packet.
  *   arvx_occupancy_expand: the `world` packets of an all-gather, back to back -> the plain
- *   words of every other rank's slab at q * n in dev_full_words (equal slabs); a packet whose
+ *   words of every other rank's slab at q * n in dev_full_words (equal slabs; 16-byte
+ *   aligned); a packet whose
  *   slab had more than cap mixed words sets *dev_overflow = 1 and is skipped: fall back to
  *   the plain all-gather of the packed words then. */
 int64_t arvx_occupancy_packet_words(int64_t n_words64, int64_t cap_words64);
