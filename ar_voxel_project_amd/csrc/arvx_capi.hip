@@ -458,27 +458,20 @@ int arvx_occupancy_compress(arvx_ctx *ctx, const void *dev_words, int64_t n_word
     if (((uintptr_t)dev_words | (uintptr_t)dev_packet) & 7u)
         return fail(ARVX_ERR_INVALID, "buffers must be 8-byte aligned");
     const long long n = n_words64, nb = (n + 63) / 64;
-    const int nsb = (int)((nb + arvx::kScanBlock - 1) / arvx::kScanBlock);
-    if (int rc = ensure_scratch(ctx, (size_t)(nb + nsb + 1) * sizeof(long long) +
-                                         (size_t)(nb + nsb) * sizeof(int) + 64))
+    const int nwg = (int)((nb + arvx::kOccGroupsPerWg - 1) / arvx::kOccGroupsPerWg);
+    if (int rc = ensure_scratch(ctx, (size_t)(nwg + 1) * sizeof(long long) +
+                                         (size_t)nwg * sizeof(int) + 64))
         return rc;
-    long long *d_off = (long long *)ctx->d_scratch;  // nb group offsets
-    long long *d_boff = d_off + nb;                  // nsb + 1 block offsets, last = total
-    int *d_cnt = (int *)(d_boff + nsb + 1);
-    int *d_bsum = d_cnt + nb;
-    const unsigned gw = (unsigned)((nb + 3) / 4);
-    hipLaunchKernelGGL(arvx::occ_classify_kernel, dim3(gw), dim3(256), 0, ctx->stream,
+    long long *d_wgoff = (long long *)ctx->d_scratch;  // nwg + 1 offsets, last = total
+    int *d_wgsum = (int *)(d_wgoff + nwg + 1);
+    hipLaunchKernelGGL(arvx::occ_classify_kernel, dim3(nwg), dim3(256), 0, ctx->stream,
                        (const unsigned long long *)dev_words, n, (unsigned long long *)dev_packet,
-                       d_cnt);
-    hipLaunchKernelGGL(arvx::mc_block_sum_kernel, dim3(nsb), dim3(256), 0, ctx->stream, d_cnt,
-                       (int)nb, d_bsum);
-    hipLaunchKernelGGL(arvx::mc_scan_blocks_kernel, dim3(1), dim3(256), 0, ctx->stream, d_bsum, nsb,
-                       d_boff);
-    hipLaunchKernelGGL(arvx::mc_block_scan_kernel, dim3(nsb), dim3(256), 0, ctx->stream, d_cnt,
-                       (int)nb, d_boff, d_off);
-    hipLaunchKernelGGL(arvx::occ_write_kernel, dim3(gw), dim3(256), 0, ctx->stream,
-                       (const unsigned long long *)dev_words, n, (long long)cap_words64, d_off,
-                       d_boff + nsb, (unsigned long long *)dev_packet);
+                       d_wgsum);
+    hipLaunchKernelGGL(arvx::mc_scan_blocks_kernel, dim3(1), dim3(256), 0, ctx->stream, d_wgsum, nwg,
+                       d_wgoff);
+    hipLaunchKernelGGL(arvx::occ_write_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0,
+                       ctx->stream, (const unsigned long long *)dev_words, n, (long long)cap_words64,
+                       d_wgoff, nwg, (unsigned long long *)dev_packet);
     ARVX_HIP(hipGetLastError());
     return ARVX_OK;
 }

@@ -15,6 +15,7 @@
 #pragma once
 
 #include "arvx_device.h"
+#include "mc_kernels.h"  // wg_exclusive_scan, mc_scan_blocks_kernel
 
 namespace arvx {
 
@@ -23,42 +24,69 @@ __host__ __device__ inline long long occ_packet_header(long long n) {
     return 1 + 2 * nb + (nb + 1) / 2;
 }
 
-// one wave per group of 64 words: the two bitmaps and the group's number of mixed words
+// Three launches: classify (bitmaps + the number of mixed words before each group INSIDE its
+// workgroup's 32 groups + the workgroup's total), one workgroup scanning those totals, and
+// the ordered write.  (First version: per-group counts, then the three-launch block scan of
+// the marching-cubes hand-off -- five launches of 2..7 us each for 16 MB of input.)
+constexpr int kOccGroupsPerWave = 8;
+constexpr int kOccGroupsPerWg = 4 * kOccGroupsPerWave;
+
+// a wave classifies eight groups of 64 words (eight 512-byte reads in flight, two ballots
+// each) and lane l < 8 keeps the bitmaps of group l; the workgroup scans its 32 counts
 __global__ __launch_bounds__(256) void occ_classify_kernel(const unsigned long long *__restrict__ words,
                                                            long long n,
                                                            unsigned long long *__restrict__ out,
-                                                           int *__restrict__ counts) {
-    const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                           int *__restrict__ wg_sum) {
+    __shared__ long long wtot[4];
     const long long nb = (n + 63) / 64;
-    if (g >= nb) return;
     const int lane = threadIdx.x & 63;
-    const long long i = g * 64 + lane;
-    const unsigned long long w = i < n ? words[i] : 0ull;
-    const unsigned long long ones = __ballot(i < n && w == ~0ull);
-    const unsigned long long mixed = __ballot(w != 0ull && w != ~0ull);
-    if (lane == 0) {
-        out[1 + g] = ones;
-        out[1 + nb + g] = mixed;
-        counts[g] = __popcll(mixed);
+    const long long g0 =
+        (long long)blockIdx.x * kOccGroupsPerWg + (threadIdx.x >> 6) * kOccGroupsPerWave;
+    unsigned long long w[kOccGroupsPerWave];
+#pragma unroll
+    for (int it = 0; it < kOccGroupsPerWave; ++it) {
+        const long long i = (g0 + it) * 64 + lane;
+        w[it] = i < n ? words[i] : 0ull;
     }
+    unsigned long long my_ones = 0ull, my_mixed = 0ull;
+#pragma unroll
+    for (int it = 0; it < kOccGroupsPerWave; ++it) {
+        // (a word past n reads as 0: neither all-one nor mixed)
+        const unsigned long long ones = __ballot(w[it] == ~0ull);
+        const unsigned long long mixed = __ballot(w[it] != 0ull && w[it] != ~0ull);
+        if (lane == it) {
+            my_ones = ones;
+            my_mixed = mixed;
+        }
+    }
+    const long long g = g0 + lane;
+    long long total;
+    const long long pre = wg_exclusive_scan((long long)__popcll(my_mixed), wtot, &total);
+    if (lane < kOccGroupsPerWave && g < nb) {
+        out[1 + g] = my_ones;
+        out[1 + nb + g] = my_mixed;
+        reinterpret_cast<unsigned *>(out + 1 + 2 * nb)[g] = (unsigned)pre;  // + its workgroup's offset later
+    }
+    if (threadIdx.x == 0) wg_sum[blockIdx.x] = (int)total;
 }
 
-// offsets[g] = mixed words before group g (from the block scan of counts)
+// one wave per group: the group's final offset and its mixed words, in order
 __global__ __launch_bounds__(256) void occ_write_kernel(const unsigned long long *__restrict__ words,
                                                         long long n, long long cap,
-                                                        const long long *__restrict__ offsets,
-                                                        const long long *__restrict__ total,
+                                                        const long long *__restrict__ wg_off,
+                                                        int nwg,
                                                         unsigned long long *__restrict__ out) {
     const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long nb = (n + 63) / 64;
     if (g >= nb) return;
     const int lane = threadIdx.x & 63;
     const long long H = occ_packet_header(n);
+    unsigned *goff = reinterpret_cast<unsigned *>(out + 1 + 2 * nb);
     const unsigned long long mixed = out[1 + nb + g];
-    const long long off = offsets[g];
+    const long long off = wg_off[g / kOccGroupsPerWg] + (long long)goff[g];
     if (lane == 0) {
-        reinterpret_cast<unsigned *>(out + 1 + 2 * nb)[g] = (unsigned)off;
-        if (g == 0) out[0] = (unsigned long long)*total;
+        goff[g] = (unsigned)off;
+        if (g == 0) out[0] = (unsigned long long)wg_off[nwg];
     }
     if ((mixed >> lane) & 1ull) {
         const long long at = off + __popcll(mixed & ((1ull << lane) - 1ull));
