@@ -591,6 +591,12 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
     // the statistics counters live in the row-mapped variant
     static const bool row_map = getenv("ARVX_EXACT_ROWS") != nullptr;
     const bool blocks = split && !row_map && !(flags & ARVX_CARVE_STATS);
+    // few sub-tiles per wave (small grids, slabs): the exact kernel may hand an item's views
+    // to several waves (decided in the kernel from the length of the work lists)
+    static const bool no_item_split = getenv("ARVX_NO_ITEM_SPLIT") != nullptr;
+    if (blocks && aligned && !no_item_split &&
+        (size_t)p.X * p.Y * p.Z <= ((size_t)1 << 26))
+        p.flags |= 8u;
     if (split) {
         if (aligned)
             hipLaunchKernelGGL(arvx::carve_classify_kernel<true>, dim3(grid), dim3(256), 0,

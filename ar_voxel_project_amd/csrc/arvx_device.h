@@ -43,7 +43,8 @@ struct CarveParams {
     int W, H;
     int bgWords, satStride;
     int v0, v1;             // view range [v0, v1)
-    unsigned flags;         // bit0 no cull, bit1 stats, bit2 state is fresh (skip the load)
+    unsigned flags;         // bit0 no cull, bit1 stats, bit2 state is fresh (skip the load),
+                            // bit3 the exact kernel may split items between waves
     int tilesX, tilesY, tilesZ;
     // coarse pre-pass results
     int coarseX, coarseY, coarseZ, nchunks;

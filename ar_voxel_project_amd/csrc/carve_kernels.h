@@ -658,7 +658,14 @@ __global__ __launch_bounds__(256, 8) void carve_classify_kernel(const CarveParam
             for (int kk = 0; kk < 4; ++kk) st[kk] |= kDone4;  // seen, src/VoxelCarving.cpp:54
         }
         subtile_store<kAligned4>(p, t, st);
-    } else if (lane == 0) {
+    } else if ((p.flags & 12u) == 12u) {
+        // the exact kernel may hand this sub-tile to several waves that merge their results
+        // with atomics: the plane must hold the sub-tile's initial state (a fresh model exists
+        // only as a flag until now)
+        subtile_load<kAligned4>(p, t, st);
+        subtile_store<kAligned4>(p, t, st);
+    }
+    if (!any_carved && any_mixed && lane == 0) {
         // hand the sub-tile to carve_exact_kernel: where it is, whether some view sees
         // all of it, and per chunk of 64 views which ones to evaluate (and how to divide)
         // spread the sub-tiles evenly: with the list taken from the block index the lists
@@ -778,10 +785,13 @@ __device__ __forceinline__ bool exact_view(const CarveParams &p, const int view,
 // ~10 us when a thousand waves go for the same list.  A fully static split by the
 // number of views per item removed that but left the waves unevenly loaded: the cost of
 // an item is not known before it has run.)
-// kParts: every item is handed out as kParts units (body gets the part index).
+// kSplit: when there are few items per wave the kernel is bound by its longest item (the
+// views of an item run one after the other), so every item is handed out as 2 or 4 units,
+// each taking every 2nd / 4th of its views; body gets (item, part, list, log2 parts) and
+// merges what the parts find (flags bit3: the caller allows it).
 // srank / nstatic: this wave's rank among the nstatic waves that take an item by index
 // (srank < 0: none for this wave).
-template <int kParts, class Body>
+template <bool kSplit, class Body>
 __device__ __forceinline__ void for_each_work_item(const CarveParams &p, const int lane,
                                                    const int srank, const int nstatic,
                                                    Body body) {
@@ -793,12 +803,27 @@ __device__ __forceinline__ void for_each_work_item(const CarveParams &p, const i
         const int t = __shfl_up(incl, d);
         if (lane >= d) incl += t;
     }
-    const int T = __builtin_amdgcn_readlane(incl, kWorkLists - 1) * kParts;  // units
-    auto run = [&](int u) {  // flat unit u -> item f = u / kParts -> its place in the lists
-        const int f = u / kParts;
+    const int items = __builtin_amdgcn_readlane(incl, kWorkLists - 1);
+    int shift = 0;
+    if (kSplit && (p.flags & 8u)) {
+        // only while every unit still gets a wave of its own, and four parts only while they
+        // leave half of the wave slots empty: the parts of an item do not see each other's
+        // carving, so they evaluate more voxels than one wave would, and four waves on a SIMD
+        // run their views half as fast as two.  (Sphere scene, 36 views, no split / 2 / 4 / 8
+        // parts: 64^3 0.135 / 0.090 / 0.069 / 0.068 ms, 128^3 0.124 / 0.087 / 0.071 / 0.084,
+        // 192^3 0.110 / 0.082 / 0.094, 256^3 0.104 / 0.096; from 320^3 on there are more
+        // items than waves.)
+        if (8 * items <= p.nwaves)
+            shift = 2;
+        else if (2 * items <= p.nwaves)
+            shift = 1;
+    }
+    const int T = items << shift;  // units
+    auto run = [&](int u) {  // flat unit u -> item f -> its place in the lists
+        const int f = u >> shift;
         const int l = __popcll(__ballot(lane < kWorkLists && incl <= f));
         const int start = l ? __builtin_amdgcn_readlane(incl, l - 1) : 0;
-        body((size_t)l * p.workCap + (f - start), u % kParts, l);
+        body((size_t)l * p.workCap + (f - start), u & ((1 << shift) - 1), l, shift);
     };
     const int share = 1;  // (a larger fixed share balanced worse at 1024^3)
     if (srank >= 0) {
@@ -826,8 +851,8 @@ __global__ __launch_bounds__(256, 4) void carve_exact_kernel(const CarveParams p
     WaveTimeline wave_timeline(p.timeline);
 #endif
     const int lane = threadIdx.x & 63;
-    for_each_work_item<1>(p, lane, blockIdx.x * 4 + (threadIdx.x >> 6), p.nwaves,
-                          [&](const size_t it, const int, const int) {
+    for_each_work_item<false>(p, lane, blockIdx.x * 4 + (threadIdx.x >> 6), p.nwaves,
+                          [&](const size_t it, const int, const int, const int) {
             const unsigned long long info = p.itemInfo[it];
             const int tx = (int)(info & 0xffffu), ty = (int)((info >> 16) & 0xffffu);
             const int tz = (int)((info >> 32) & 0xffffu), wave = (int)((info >> 48) & 3u);
@@ -1011,8 +1036,8 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
     // (Tried and dropped: leaving the pure fill of the decided tiles to a quarter of these
     // workgroups so that it overlaps the exact work -- the fill saturates HBM and the
     // exact waves, which live on memory latency, slow down by more than the fill costs.)
-    for_each_work_item<1>(p, lane, blockIdx.x * 4 + (threadIdx.x >> 6), p.nwaves,
-                          [&](const size_t it, const int, const int list) {
+    for_each_work_item<kAligned4>(p, lane, blockIdx.x * 4 + (threadIdx.x >> 6), p.nwaves,
+                          [&](const size_t it, const int part, const int list, const int pshift) {
             // the kernel ends on its longest items (an item's views run one after the other):
             // the items of the heavy weight classes get the SIMD's issue slots first
             // (512^3: -1.2 %, 1024^3: no change; the waves of a SIMD mostly hold items of
@@ -1071,9 +1096,10 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
                 unsigned long long mixed = uniform64(p.itemMasks[(it * p.nchunks + c) * 2]);
                 const unsigned long long fastdiv =
                     uniform64(p.itemMasks[(it * p.nchunks + c) * 2 + 1]);
-                while (mixed && !done) {
+                for (int nth = 0; mixed && !done; ++nth) {
                     const int b = __ffsll((long long)mixed) - 1;
                     mixed &= mixed - 1;
+                    if ((nth & ((1 << pshift) - 1)) != part) continue;  // another part's view
                     done = exact_view_blocks(p, __builtin_amdgcn_readfirstlane(p.v0 + 64 * c + b),
                                              (fastdiv >> b) & 1ull, wy, wx, wz, st);
 #ifdef ARVX_TIMELINE
@@ -1099,7 +1125,25 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
 #pragma unroll
             for (int k = 0; k < 4; ++k) st[k] = buf[rowSlot + 32 * k];
             wave_lds_sync();
-            subtile_store<kAligned4>(p, t, st);
+            if (kAligned4 && pshift) {
+                // the parts of an item carve (clear bit0) and see (set bit1) independently:
+                // both are monotone, so the order in which they reach the plane is irrelevant
+                const size_t row = (size_t)p.X, plane = (size_t)p.X * p.Y;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int z = t.zb + k;
+                    if (t.lane_ok && z < p.Z) {
+                        uint32_t *dst = reinterpret_cast<uint32_t *>(
+                            p.state + (size_t)z * plane + (size_t)t.y * row + t.x);
+                        (void)__hip_atomic_fetch_and(dst, st[k] | 0xfefefefeu, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+                        (void)__hip_atomic_fetch_or(dst, st[k] & 0x02020202u, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            } else {
+                subtile_store<kAligned4>(p, t, st);
+            }
 #ifdef ARVX_TIMELINE
             wave_timeline.tick(3);
 #endif
