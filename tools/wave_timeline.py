@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-wave timeline of the persistent exact kernel from a DIAGNOSTIC build
 (make EXTRA=-DARVX_TIMELINE): when each wave ends, how many items / views it took.
-    ARVX_LIB_PATH=ab_libs/timeline.so python tools/wave_timeline.py 512"""
+    ARVX_LIB_PATH=ab_libs/timeline.so python tools/wave_timeline.py 512 [z0:z1]"""
 import ctypes as C
 import json
 import os
@@ -14,9 +14,10 @@ import numpy as np  # noqa: E402
 from ar_voxel_project_amd import capi, synthetic  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+zr = tuple(int(v) for v in sys.argv[2].split(":")) if len(sys.argv) > 2 else None  # slab z0:z1
 sc = synthetic.sphere_scene(N, 36)
 lib = capi.load_library()
-with capi.Context(N, N, N, sc.voxel_size) as ctx:
+with capi.Context(N, N, N, sc.voxel_size, z_range=zr) as ctx:
     ctx.set_views(sc.M, sc.masks)
     for _ in range(3):
         ctx.reset()
