@@ -786,8 +786,8 @@ __device__ __forceinline__ bool exact_view(const CarveParams &p, const int view,
 // number of views per item removed that but left the waves unevenly loaded: the cost of
 // an item is not known before it has run.)
 // kSplit: when there are few items per wave the kernel is bound by its longest item (the
-// views of an item run one after the other), so every item is handed out as 2 or 4 units,
-// each taking every 2nd / 4th of its views; body gets (item, part, list, log2 parts) and
+// views of an item run one after the other), so every item is handed out as 2, 4 or 8 units,
+// each taking every 2nd / 4th / 8th of its views; body gets (item, part, list, log2 parts) and
 // merges what the parts find (flags bit3: the caller allows it).
 // srank / nstatic: this wave's rank among the nstatic waves that take an item by index
 // (srank < 0: none for this wave).
@@ -806,14 +806,15 @@ __device__ __forceinline__ void for_each_work_item(const CarveParams &p, const i
     const int items = __builtin_amdgcn_readlane(incl, kWorkLists - 1);
     int shift = 0;
     if (kSplit && (p.flags & 8u)) {
-        // only while every unit still gets a wave of its own, and four parts only while they
-        // leave half of the wave slots empty: the parts of an item do not see each other's
-        // carving, so they evaluate more voxels than one wave would, and four waves on a SIMD
-        // run their views half as fast as two.  (Sphere scene, 36 views, no split / 2 / 4 / 8
-        // parts: 64^3 0.135 / 0.090 / 0.069 / 0.068 ms, 128^3 0.124 / 0.087 / 0.071 / 0.084,
-        // 192^3 0.110 / 0.082 / 0.094, 256^3 0.104 / 0.096; from 320^3 on there are more
-        // items than waves.)
-        if (8 * items <= p.nwaves)
+        // only while every unit still gets a wave of its own: the parts of an item do not see
+        // each other's carving, so together they evaluate more voxels than one wave would.
+        // (Sphere scene, 36 views, whole / 2 / 4 / 8 parts: 64^3 0.109 / 0.068 / 0.045 /
+        // 0.035 ms, 128^3 0.103 / 0.065 / 0.047 / 0.048, 192^3 0.093 / 0.068 / 0.058 / 0.115,
+        // 256^3 0.094 / 0.076 / 0.114, 320^3 0.097 / 0.118: from there on there are more
+        // items than half the waves.)
+        if (16 * items <= p.nwaves)
+            shift = 3;
+        else if (4 * items <= p.nwaves)
             shift = 2;
         else if (2 * items <= p.nwaves)
             shift = 1;
@@ -1082,6 +1083,9 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
                 default: __builtin_amdgcn_s_setprio(0); break;
             }
             const unsigned long long info = p.itemInfo[it];
+            // (the first chunk's view masks are requested with the item, not after its set-up)
+            unsigned long long mixed0 = p.itemMasks[it * p.nchunks * 2];
+            unsigned long long fast0 = p.itemMasks[it * p.nchunks * 2 + 1];
 #ifdef ARVX_TIMELINE
             { volatile unsigned long long sink = info; (void)sink; }
             wave_timeline.tick(0);  // since the end of the previous item: the pull + this read
@@ -1126,9 +1130,10 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
 #endif
             for (int c = 0; c < p.nchunks && !done; ++c) {
                 // the same words in every lane: keep them, and the view loop, scalar
-                unsigned long long mixed = uniform64(p.itemMasks[(it * p.nchunks + c) * 2]);
+                unsigned long long mixed =
+                    uniform64(c ? p.itemMasks[(it * p.nchunks + c) * 2] : mixed0);
                 const unsigned long long fastdiv =
-                    uniform64(p.itemMasks[(it * p.nchunks + c) * 2 + 1]);
+                    uniform64(c ? p.itemMasks[(it * p.nchunks + c) * 2 + 1] : fast0);
                 for (int nth = 0; mixed && !done; ++nth) {
                     const int b = __ffsll((long long)mixed) - 1;
                     mixed &= mixed - 1;
