@@ -826,56 +826,61 @@ __device__ __forceinline__ void for_each_work_item(const CarveParams &p, const i
         const int start = l ? __builtin_amdgcn_readlane(incl, l - 1) : 0;
         body((size_t)l * p.workCap + (f - start), u & ((1 << shift) - 1), l, shift);
     };
-    const int share = 1;  // (a larger fixed share balanced worse at 1024^3)
-    if (srank >= 0) {
-        const int b0 = min(T, srank * share), b1 = min(T, b0 + share);
-        for (int f = b0; f < b1; ++f) run(f);
-    }
     // the pool: flat items pool0 + k + kPoolCounters * ticket, counter k
-    const int pool0 = (int)min((long long)T, (long long)nstatic * share);
+    const int pool0 = min(T, nstatic);
     const int P = T - pool0;  // units in the pool
-    if (4 * P > p.nwaves) {
-        // a pool that outlasts the first items: the waves come back at different times and
-        // walk the counters one after the other
-        for (int r = 0; r < kPoolCounters; ++r) {
-            const int k = (w + r) & (kPoolCounters - 1);
-            for (;;) {
+    // A pool that outlasts the first items (4 P > waves): the waves come back at different
+    // times and walk the counters one after the other.
+    // A small pool (slabs, grids around 400^3) or none (smaller grids): nearly every wave
+    // comes back to find nothing left, and finding that out by drawing from eight counters
+    // is eight returning atomics on lines every wave wants -- 4096 waves x 8 failed draws
+    // took 45 us, during which the waves still at work wait behind them.  There a wave LOOKS
+    // at all eight counters with one load first and draws only from one that still holds
+    // tickets; without any it leaves.  (For the large pools the same scheme is slower:
+    // 512^3 +16 %, 1024^3 +3 %.)
+    const bool walk = 4 * P > p.nwaves;
+    int u = (srank >= 0 && srank < T) ? srank : -1;  // the first unit: by index, no atomic
+    int k = w & (kPoolCounters - 1), tried = 0;
+    for (;;) {  // (one loop, so that the body exists once: the kernel is at its register budget)
+        if (u < 0) {
+            if (P <= 0) break;
+            if (walk) {
+                while (tried < kPoolCounters) {
+                    int ticket = 0;
+                    if (lane == 0) ticket = atomicAdd(&p.poolNext[k * kCounterStride], 1);
+                    ticket = __builtin_amdgcn_readfirstlane(ticket);
+                    const long long f = (long long)pool0 + k + (long long)kPoolCounters * ticket;
+                    if (f < T) {
+                        u = (int)f;
+                        break;
+                    }
+                    k = (k + 1) & (kPoolCounters - 1);
+                    ++tried;
+                }
+                if (u < 0) break;
+            } else {
+                const int drawn = lane < kPoolCounters
+                                      ? __hip_atomic_load(&p.poolNext[lane * kCounterStride],
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                      : 0;
+                // counter l holds tickets [0, nk)
+                const int nk = (P - lane + kPoolCounters - 1) / kPoolCounters;
+                const unsigned avail = (unsigned)__ballot(lane < kPoolCounters && drawn < nk);
+                if (!avail) break;
+                // the first counter with tickets at or after k, cyclically
+                const unsigned rot = ((avail >> k) | (avail << (kPoolCounters - k))) &
+                                     ((1u << kPoolCounters) - 1u);
+                k = (k + __ffs((int)rot) - 1) & (kPoolCounters - 1);
                 int ticket = 0;
                 if (lane == 0) ticket = atomicAdd(&p.poolNext[k * kCounterStride], 1);
                 ticket = __builtin_amdgcn_readfirstlane(ticket);
                 const long long f = (long long)pool0 + k + (long long)kPoolCounters * ticket;
-                if (f >= T) break;
-                run((int)f);
+                if (f >= T) continue;  // somebody was faster: look again
+                u = (int)f;
             }
         }
-        return;
-    }
-    // A small pool (slabs, grids around 400^3) or none (smaller grids): nearly every wave
-    // comes back to find nothing left, and finding that out by drawing from eight counters
-    // is eight returning atomics on lines every wave wants -- 4096 waves x 8 failed draws
-    // took 45 us, during which the waves still at work wait behind them.  Here a wave LOOKS
-    // at all eight counters with one load first and draws only from one that still holds
-    // tickets; without any it leaves.  (For the large pools above the same scheme is slower:
-    // 512^3 +16 %, 1024^3 +3 %.)
-    int k = w & (kPoolCounters - 1);
-    while (P > 0) {
-        const int drawn = lane < kPoolCounters
-                              ? __hip_atomic_load(&p.poolNext[lane * kCounterStride],
-                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                              : 0;
-        // counter l holds tickets [0, nk)
-        const int nk = (P - lane + kPoolCounters - 1) / kPoolCounters;
-        const unsigned avail = (unsigned)__ballot(lane < kPoolCounters && drawn < nk);
-        if (!avail) break;
-        // the first counter with tickets at or after k, cyclically
-        const unsigned rot =
-            ((avail >> k) | (avail << (kPoolCounters - k))) & ((1u << kPoolCounters) - 1u);
-        k = (k + __ffs((int)rot) - 1) & (kPoolCounters - 1);
-        int ticket = 0;
-        if (lane == 0) ticket = atomicAdd(&p.poolNext[k * kCounterStride], 1);
-        ticket = __builtin_amdgcn_readfirstlane(ticket);
-        const long long f = (long long)pool0 + k + (long long)kPoolCounters * ticket;
-        if (f < T) run((int)f);  // (else somebody was faster: look again)
+        run(u);
+        u = -1;
     }
 }
 
