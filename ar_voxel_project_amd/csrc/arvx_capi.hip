@@ -598,11 +598,12 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
         (size_t)p.X * p.Y * p.Z <= ((size_t)1 << 26))
         p.flags |= 8u;
     if (split) {
+        const dim3 cgrid(8u * (unsigned)p.tilesX, (unsigned)(p.tilesY + 7) / 8u, (unsigned)p.tilesZ);
         if (aligned)
-            hipLaunchKernelGGL(arvx::carve_classify_kernel<true>, dim3(grid), dim3(256), 0,
+            hipLaunchKernelGGL(arvx::carve_classify_kernel<true>, cgrid, dim3(256), 0,
                                ctx->stream, p);
         else
-            hipLaunchKernelGGL(arvx::carve_classify_kernel<false>, dim3(grid), dim3(256), 0,
+            hipLaunchKernelGGL(arvx::carve_classify_kernel<false>, cgrid, dim3(256), 0,
                                ctx->stream, p);
         ARVX_HIP(hipGetLastError());
         const unsigned pgrid = (unsigned)(p.nwaves / 4);

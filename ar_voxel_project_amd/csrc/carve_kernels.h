@@ -572,13 +572,17 @@ __device__ __forceinline__ void subtile_store(const CarveParams &p, const SubTil
 // of every undecided sub-tile at 8 waves per SIMD, and fatter workgroups lengthen that chain.)
 template <bool kAligned4>
 __global__ __launch_bounds__(256, 8) void carve_classify_kernel(const CarveParams p) {
-    // same block -> tile map as carve_fused_kernel (rows of tiles dealt to the XCDs)
-    const unsigned k = blockIdx.x >> 3;
-    const unsigned trow = (k / p.tilesX) * 8u + (blockIdx.x & 7u);
-    if (trow >= (unsigned)(p.tilesY * p.tilesZ)) return;
-    const int tx = k % p.tilesX;
-    const int ty = trow % p.tilesY;
-    const int tz = trow / p.tilesY;
+    // Rows of tiles (along x) are dealt to the XCDs as in carve_fused_kernel, but the tile
+    // comes straight from a 3-D block index: grid (8 * tilesX, ceil(tilesY / 8), tilesZ), the
+    // dispatcher walks x fastest and hands consecutive workgroups to consecutive XCDs, so
+    // blockIdx.x & 7 is the XCD and the eight rows ty = 8 * blockIdx.y + 0..7 run side by side.
+    // (With a flat index every wave spent ~100 scalar instructions on two integer divisions;
+    // a million one-store fill waves at 1024^3 kept the scalar units busy for longer than
+    // the stores take.)
+    const int tx = (int)(blockIdx.x >> 3);
+    const int ty = (int)(blockIdx.y * 8u + (blockIdx.x & 7u));
+    const int tz = (int)blockIdx.z;
+    if (ty >= p.tilesY) return;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const int ct = tx + p.coarseX * ((ty >> p.cyShift) + p.coarseY * (tz >> p.czShift));
