@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Prints the carve kernel's culling statistics and cull / no-cull timings.
-Usage: python tools/carve_stats.py [grid ...]   (GPU required)"""
+Usage: [ARVX_VIEWS=72] python tools/carve_stats.py [grid ...]   (GPU required)"""
 import json
 import os
 import sys
@@ -28,7 +28,7 @@ def timed(ctx, stream, flags, reps):
 
 def main():
     grids = [int(a) for a in sys.argv[1:] if a.isdigit()] or [512]
-    V = 36
+    V = int(os.environ.get("ARVX_VIEWS", "36"))
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
