@@ -457,3 +457,27 @@ def test_more_than_256_views_uses_fused_kernel(arvx, oracle):
     # 256 views: the largest count the split launch takes
     want = oracle.carve(N, N, N, s, M[:256], masks[:256])
     assert_same(run_gpu(arvx, N, N, N, s, M[:256], masks[:256], 0), want, "256 views")
+
+
+@pytest.mark.parametrize("N,V", [(96, 36), (160, 24), (224, 12), (288, 8), (352, 6), (416, 6)])
+def test_work_distribution_regimes(arvx, oracle, N, V):
+    """The exact kernel hands its sub-tiles out differently depending on how many there are
+    per wave: items shared by 8 / 4 / 2 waves that merge with atomics (small grids), whole
+    items with no pool, a small pool (look before draw), a large pool (walk).  The sphere
+    scene puts these grid sizes into the different regimes; every one must give the oracle's
+    plane, from a fresh model and from a pre-carved one (parts then start from loaded state),
+    and the same with the sharing switched off is checked through the brute-force kernel."""
+    sc = scenes.small_sphere(N, V, W=320, H=240)
+    want = oracle.carve(N, N, N, sc.voxel_size, sc.M, sc.masks)
+    got = run_gpu(arvx, N, N, N, sc.voxel_size, sc.M, sc.masks)
+    assert_same(got, want, f"{N}^3 x {V} fresh")
+    assert_same(run_gpu(arvx, N, N, N, sc.voxel_size, sc.M, sc.masks, 1), want, f"{N}^3 brute force")
+    # second half of the views on top of the first half's result
+    h = V // 2
+    first = oracle.carve(N, N, N, sc.voxel_size, sc.M[:h], sc.masks[:h])
+    with arvx.Context(N, N, N, sc.voxel_size) as ctx:
+        ctx.set_views(sc.M, sc.masks)
+        ctx.carve_views(0, h)
+        assert_same(ctx.download_state(), first, f"{N}^3 first {h} views")
+        ctx.carve_views(h, V - h)
+        assert_same(ctx.download_state(), want, f"{N}^3 remaining views on a carved model")
