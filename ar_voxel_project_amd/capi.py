@@ -38,7 +38,7 @@ SYMBOLS = [
     "arvx_colors_upload", "arvx_closure", "arvx_closure_count", "arvx_closure_download",
     "arvx_mc_cells", "arvx_mc_cells_download",
     "arvx_occupancy_packet_words", "arvx_occupancy_compress", "arvx_occupancy_expand",
-    "arvx_export_model", "arvx_get_stats", "arvx_selftest_divide",
+    "arvx_export_model", "arvx_get_stats", "arvx_selftest_divide", "arvx_selftest_round",
 ]
 
 
@@ -122,6 +122,8 @@ def load_library() -> C.CDLL:
     ab_build = bool(os.environ.get("ARVX_LIB_PATH"))  # an older build may lack newer symbols
     if hasattr(lib, "arvx_selftest_divide") or not ab_build:
         lib.arvx_selftest_divide.argtypes = [p, C.c_int64, f32p, f32p, f32p, f32p]
+    if hasattr(lib, "arvx_selftest_round") or not ab_build:
+        lib.arvx_selftest_round.argtypes = [p, C.POINTER(C.c_int64)]
     if hasattr(lib, "arvx_mc_cells") or not ab_build:
         lib.arvx_mc_cells.argtypes = [p, C.POINTER(C.c_int64)]
         lib.arvx_mc_cells_download.argtypes = [p, C.POINTER(C.c_int32)]
@@ -385,6 +387,12 @@ class Context:
         out = np.empty((len(b), 4), np.float32)
         _check(self._lib.arvx_selftest_divide(self._h, len(b), _fp(a0), _fp(a1), _fp(b), _fp(out)))
         return out
+
+    def selftest_round(self) -> int:
+        """Mismatches between the kernels' pixel rounding and std::round (must be 0)."""
+        n = C.c_int64(-1)
+        _check(self._lib.arvx_selftest_round(self._h, C.byref(n)))
+        return int(n.value)
 
     def stats(self) -> dict:
         s = Stats()

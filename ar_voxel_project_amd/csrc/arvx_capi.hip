@@ -934,6 +934,28 @@ int arvx_selftest_divide(arvx_ctx *ctx, int64_t n, const float *a0, const float 
     return ARVX_OK;
 }
 
+int arvx_selftest_round(arvx_ctx *ctx, int64_t *mismatches) {
+    ARVX_CHECK_CTX(ctx);
+    if (!mismatches) return fail(ARVX_ERR_INVALID, "null mismatches");
+    *mismatches = -1;
+    if (int rc = ensure_scratch(ctx, 64)) return rc;
+    unsigned long long *d_bad = (unsigned long long *)ctx->d_scratch;
+    ARVX_HIP(hipMemsetAsync(d_bad, 0, sizeof *d_bad, ctx->stream));
+    // every float in [+0, 2^24] and in (-0.5, -0]: all quotients that can be inside an image
+    const unsigned ranges[2][2] = {{0x00000000u, 0x4B800000u}, {0x80000000u, 0xBEFFFFFFu}};
+    for (const auto &r : ranges) {
+        const unsigned long long n = (unsigned long long)r[1] - r[0] + 1;
+        hipLaunchKernelGGL(arvx::selftest_round_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256),
+                           0, ctx->stream, r[0], r[1], d_bad);
+        ARVX_HIP(hipGetLastError());
+    }
+    unsigned long long bad = 0;
+    ARVX_HIP(hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    *mismatches = (int64_t)bad;
+    return ARVX_OK;
+}
+
 #ifdef ARVX_TIMELINE
 // diagnostic builds only: per-workgroup {start, end (100 MHz ticks), xcc id, 0} of the last carve
 extern "C" int arvx_debug_timeline(arvx_ctx *ctx, unsigned long long *out, int64_t *n) {

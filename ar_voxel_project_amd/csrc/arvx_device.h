@@ -66,6 +66,18 @@ __device__ __forceinline__ int global_z(const CarveParams &p, int lz) {
     return p.zoff + (((lz >> 3) * p.zstride + p.zphase) << 3) + (lz & 7);
 }
 
+// (int)std::round(u) for u > -0.5 in ONE instruction: v_cvt_rpi_i32_f32 is floor(u + 1/2)
+// with the sum NOT rounded to fp32 first (a rounded sum would turn 0.49999997 into 1).
+// For u > -0.5 that is round-half-away-from-zero: ties k + 1/2 go up, and (-0.5, 0) gives 0
+// like roundf's -0.  Verified on this hardware against floor(u) + (fract(u) >= 0.5) on every
+// float in (-0.5, 2^24] (arvx_selftest_round, tests/test_carve_gpu.py); below -0.5 it differs
+// from std::round (ties go up, not away), and there the callers have already said "outside".
+__device__ __forceinline__ int round_pixel(float u) {
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(u));
+    return r;
+}
+
 // Pixel of a projected voxel from the two quotients u = a0/a2, v = a1/a2.
 // Reference: px = (int)std::round(u), inside iff 0 <= px < W (same for v,H),
 // src/VoxelCarving.cpp:44-45.  Restated without computing round() first:
@@ -77,10 +89,7 @@ __device__ __forceinline__ bool pixel_from_quotients(float u, float v, int W, fl
                                                      float hlim, int &pix) {
     // (bitwise &: with && the compiler builds a chain of exec-masked branches per voxel)
     const bool in = (u > -0.5f) & (u < wlim) & (v > -0.5f) & (v < hlim);
-    // inside that range round-half-away is floor(u) + (frac(u) >= 0.5): u - floor(u) is
-    // exact, and for u in (-0.5, 0) it gives -1 + 1 = 0 like roundf's -0
-    const int px = (int)floorf(u) + (__builtin_amdgcn_fractf(u) >= 0.5f ? 1 : 0);
-    const int py = (int)floorf(v) + (__builtin_amdgcn_fractf(v) >= 0.5f ? 1 : 0);
+    const int px = round_pixel(u), py = round_pixel(v);
     const int at = __mul24(py, W) + px;  // (24-bit multiply: full rate; in range where it counts)
     pix = in ? at : 0;  // 0 keeps the unconditional table read in bounds
     return in;

@@ -1201,6 +1201,17 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
     });
 }
 
+// self-test support: round_pixel against std::round on every float of a bit range
+__global__ __launch_bounds__(256) void selftest_round_kernel(unsigned lo, unsigned hi,
+                                                             unsigned long long *__restrict__ nbad) {
+    const unsigned long long i = lo + (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i > hi) return;
+    const float x = __uint_as_float((unsigned)i);
+    const int want = (int)roundf(x);
+    const int alt = (int)floorf(x) + (__builtin_amdgcn_fractf(x) >= 0.5f ? 1 : 0);
+    if (round_pixel(x) != want || alt != want) atomicAdd(nbad, 1ull);
+}
+
 // self-test support: both division forms on caller-supplied operands
 __global__ __launch_bounds__(256) void selftest_divide_kernel(const float *__restrict__ a0,
                                                               const float *__restrict__ a1,

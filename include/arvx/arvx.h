@@ -235,6 +235,11 @@ int arvx_get_stats(arvx_ctx *ctx, arvx_stats *out);
 int arvx_selftest_divide(arvx_ctx *ctx, int64_t n, const float *a0, const float *a1,
                          const float *b, float *out);
 
+/* Self-test hook: the kernels' one-instruction pixel rounding (v_cvt_rpi_i32_f32) against
+ * std::round on every float in (-0.5, 2^24], i.e. every quotient that can fall inside an
+ * image; *mismatches must come back 0. */
+int arvx_selftest_round(arvx_ctx *ctx, int64_t *mismatches);
+
 #ifdef __cplusplus
 }
 #endif

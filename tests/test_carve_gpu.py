@@ -481,3 +481,11 @@ def test_work_distribution_regimes(arvx, oracle, N, V):
         assert_same(ctx.download_state(), first, f"{N}^3 first {h} views")
         ctx.carve_views(h, V - h)
         assert_same(ctx.download_state(), want, f"{N}^3 remaining views on a carved model")
+
+
+def test_pixel_rounding_instruction_is_std_round(arvx):
+    """The kernels round a quotient to its pixel with one v_cvt_rpi_i32_f32; on every float
+    in (-0.5, 2^24] -- every quotient that can land inside an image -- it must equal
+    (int)std::round (and the floor/fract form it replaced)."""
+    with arvx.Context(4, 4, 4, 0.1) as ctx:
+        assert ctx.selftest_round() == 0
