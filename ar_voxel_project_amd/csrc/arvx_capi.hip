@@ -259,7 +259,9 @@ static int views_common(Ctx *ctx, int V, const float *M, const float *campos, in
     ctx->V = V;
     ctx->W = W;
     ctx->H = H;
-    ctx->bgWords = (int)(((size_t)W * H + 31) / 32);
+    // one word more than the pixels need: bit 32 * (bgWords - 1) is a background bit that is
+    // always 0, which the block-mapped exact kernel reads for voxels outside the image
+    ctx->bgWords = (int)(((size_t)W * H + 31) / 32) + 1;
     ctx->satStride = (W + 1) * (H + 1);
     ARVX_HIP(hipMalloc(&ctx->d_M, (size_t)V * 12 * sizeof(float)));
     ARVX_HIP(hipMalloc(&ctx->d_campos, (size_t)V * 3 * sizeof(float)));
@@ -282,6 +284,8 @@ static int views_preprocess(Ctx *ctx, const uint8_t *d_masks, int C) {
     const int npix = ctx->W * ctx->H;
     dim3 g1((npix + 255) / 256, ctx->V);
     ARVX_HIP(hipGetLastError());  // anything stale would be blamed on the launches below
+    ARVX_HIP(hipMemsetAsync(ctx->d_bg, 0, (size_t)ctx->V * ctx->bgWords * sizeof(uint32_t),
+                            ctx->stream));
     hipLaunchKernelGGL(arvx::mask_to_bits_kernel, g1, dim3(256), 0, ctx->stream, d_masks, C, npix,
                        ctx->d_bg, ctx->bgWords);
     ARVX_HIP(hipGetLastError());

@@ -86,12 +86,12 @@ __device__ __forceinline__ int round_pixel(float u) {
 // both bounds are exact floats for W <= 16384; NaN/Inf fail them, which is the
 // "outside" x86's cvttss2si gives the reference there.
 __device__ __forceinline__ bool pixel_from_quotients(float u, float v, int W, float wlim,
-                                                     float hlim, int &pix) {
+                                                     float hlim, int &pix, int outside_pix = 0) {
     // (bitwise &: with && the compiler builds a chain of exec-masked branches per voxel)
     const bool in = (u > -0.5f) & (u < wlim) & (v > -0.5f) & (v < hlim);
     const int px = round_pixel(u), py = round_pixel(v);
     const int at = __mul24(py, W) + px;  // (24-bit multiply: full rate; in range where it counts)
-    pix = in ? at : 0;  // 0 keeps the unconditional table read in bounds
+    pix = in ? at : outside_pix;  // keeps the unconditional table read in bounds
     return in;
 }
 

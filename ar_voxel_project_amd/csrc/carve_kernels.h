@@ -992,6 +992,9 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
                             {row2.x, row2.y, row2.z}};
     const double p3[3] = {(double)row0.w, (double)row1.w, (double)row2.w};
     const float wlim = (float)p.W - 0.5f, hlim = (float)p.H - 0.5f;
+    // a voxel outside the image reads the always-zero bit behind the view's plane: "not
+    // background" needs no separate masking below
+    const int zero_pix = 32 * (p.bgWords - 1);
     // All sixteen blocks are projected before the table is read: ONE wait per view.  (The
     // sub-tiles that stay fully occupied pay every wait in every view, and they are what
     // the kernel ends on.)
@@ -1004,7 +1007,7 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 in[2 * byi + bzi][j] = false;
-                pix[2 * byi + bzi][j] = 0;
+                pix[2 * byi + bzi][j] = zero_pix;
             }
         if (!__any(st[2 * byi] != kDone4 || st[2 * byi + 1] != kDone4)) continue;
         double p01[3][4];
@@ -1042,7 +1045,7 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
                     u = a0 / a2;
                     v = a1 / a2;
                 }
-                in[m][j] = pixel_from_quotients(u, v, p.W, wlim, hlim, pix[m][j]);
+                in[m][j] = pixel_from_quotients(u, v, p.W, wlim, hlim, pix[m][j], zero_pix);
             }
         }
     }
@@ -1056,7 +1059,7 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
         uint32_t w = st[m];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t isbg = in[m][j] ? ((word[m][j] >> (pix[m][j] & 31)) & 1u) : 0u;
+            const uint32_t isbg = __builtin_amdgcn_ubfe(word[m][j], (uint32_t)pix[m][j], 1u);
             const uint32_t seen = in[m][j] ? (2u << (8 * j)) : 0u;
             w = (w | seen) & ~(isbg << (8 * j));
         }
