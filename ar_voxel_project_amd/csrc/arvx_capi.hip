@@ -1193,7 +1193,6 @@ int arvx_mc_cells_download(arvx_ctx *ctx, int32_t *cells) {
 
 int arvx_fast_carve(arvx_ctx *ctx) {
     ARVX_CHECK_CTX(ctx);
-    if (int mrc = materialize(ctx)) return mrc;
     if (!ctx->views_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
     if (ctx->z0 != 0 || ctx->z1 != ctx->Z || ctx->stripe_world > 1)
         return fail(ARVX_ERR_STATE,
@@ -1201,6 +1200,9 @@ int arvx_fast_carve(arvx_ctx *ctx) {
     ctx->color_ready = false;
     ctx->closure_ready = false;
     arvx::FloodParams fp;
+    // a fresh model (the usual case: src/main.cpp calls fastCarve on a new Model) is neither
+    // filled nor read: the kernels know its bytes, and flood_apply writes the whole plane
+    fp.fresh = ctx->fresh_pending ? 1 : 0;
     fp.X = ctx->X;
     fp.Y = ctx->Y;
     fp.Z = ctx->Z;
@@ -1297,6 +1299,7 @@ int arvx_fast_carve(arvx_ctx *ctx) {
         hipLaunchKernelGGL(arvx::flood_apply_kernel, dim3((unsigned)((ctx->nvox + 255) / 256)),
                            dim3(256), 0, ctx->stream, ctx->d_state, fp);
     ARVX_HIP(hipGetLastError());
+    ctx->fresh_pending = false;  // the plane now holds every voxel's state
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
     return ARVX_OK;
 }

@@ -37,6 +37,8 @@ struct FloodParams {
     int *changed;
     uint8_t *dirty_cur;   // per tile: some word of the tile or of a face neighbour changed
     uint8_t *dirty_next;  //           in the previous launch (flood_step_kernel)
+    int fresh;  // the model is fresh (all occupied, none seen): its plane is not read, and
+                // flood_apply writes every voxel instead of the changed ones
 };
 
 // open = carvable & !seen0, one wave per (row, word)
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void flood_pack_open_kernel(const uint8_t *__r
     bool o = false;
     if (x < p.X) {
         const size_t i = row * p.X + x;
-        o = !(carved_tmp[i] & 1u) && !(state[i] & 2u);
+        o = !(carved_tmp[i] & 1u) && (p.fresh || !(state[i] & 2u));
     }
     const unsigned long long b = __ballot(o);
     if ((threadIdx.x & 63) == 0) {
@@ -78,7 +80,8 @@ __global__ __launch_bounds__(256) void flood_pack_open8_kernel(const uint8_t *__
     if (g * 8 < p.X) {
         const size_t i = row * p.X + (size_t)g * 8;
         const unsigned long long c = *(const unsigned long long *)(carved_tmp + i);
-        const unsigned long long s = *(const unsigned long long *)(state + i);
+        const unsigned long long s =
+            p.fresh ? 0x0101010101010101ull : *(const unsigned long long *)(state + i);
         // open = carved on the fresh plane (bit0 clear) and not seen (bit1 clear)
         const unsigned long long m = ~c & ~(s >> 1) & 0x0101010101010101ull;
         b = (uint8_t)((m * 0x0102040810204080ull) >> 56);  // byte j's bit 0 -> bit j
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(256) void flood_apply_kernel(uint8_t *__restrict__ 
         if (xx < 0 || xx >= p.X || yy < 0 || yy >= p.Y || zz < 0 || zz >= p.Z) return false;
         return (p.reach[((size_t)zz * p.Y + yy) * p.XW + (xx >> 6)] >> (xx & 63)) & 1ull;
     };
-    uint8_t s = state[i];
+    uint8_t s = p.fresh ? (uint8_t)1 : state[i];
     if (bit(x, y, z)) {
         s = (uint8_t)((s & ~1u) | 2u);  // carved (src/VoxelCarving.cpp:125) and visited (:108)
     } else if (!(s & 2u)) {
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256) void flood_apply_wide_kernel(uint8_t *__restri
     if (z > 0) nb |= rb[-(ptrdiff_t)rowUnits * p.Y];
     if (z + 1 < p.Z) nb |= rb[(ptrdiff_t)rowUnits * p.Y];
     if (t == 0) nb |= 1u;  // the seed is visited whatever happens (:100)
-    if ((e | nb) == 0u) return;
+    if ((e | nb) == 0u && !p.fresh) return;
     // bit j -> 0x01 in byte j
     auto spread = [](unsigned b) -> unsigned long long {
         const unsigned long long v = ((b & 0xFFu) * 0x0101010101010101ull) & 0x8040201008040201ull;
@@ -330,18 +333,22 @@ __global__ __launch_bounds__(256) void flood_apply_wide_kernel(uint8_t *__restri
     // carved: clear bit0, set bit1; pushed by a carved neighbour: set bit1
     unsigned long long *sp = (unsigned long long *)(state + row * p.X + (size_t)g * kV);
     if (kV == 8) {
-        const unsigned long long s = sp[0];
+        const unsigned long long s = p.fresh ? 0x0101010101010101ull : sp[0];
         const unsigned long long E = spread(e), N = spread(nb);
         const unsigned long long ns = (s & ~E) | ((E | N) << 1);
-        if (ns != s) sp[0] = ns;
+        if (ns != s || p.fresh) sp[0] = ns;
     } else {
-        const ulonglong2 s = *(const ulonglong2 *)sp;
+        ulonglong2 s;
+        if (p.fresh)
+            s.x = s.y = 0x0101010101010101ull;
+        else
+            s = *(const ulonglong2 *)sp;
         const unsigned long long E0 = spread(e), N0 = spread(nb);
         const unsigned long long E1 = spread(e >> 8), N1 = spread(nb >> 8);
         ulonglong2 ns;
         ns.x = (s.x & ~E0) | ((E0 | N0) << 1);
         ns.y = (s.y & ~E1) | ((E1 | N1) << 1);
-        if (ns.x != s.x || ns.y != s.y) *(ulonglong2 *)sp = ns;
+        if (ns.x != s.x || ns.y != s.y || p.fresh) *(ulonglong2 *)sp = ns;
     }
 }
 
