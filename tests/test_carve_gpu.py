@@ -489,3 +489,16 @@ def test_pixel_rounding_instruction_is_std_round(arvx):
     (int)std::round (and the floor/fract form it replaced)."""
     with arvx.Context(4, 4, 4, 0.1) as ctx:
         assert ctx.selftest_round() == 0
+
+
+def test_fuzz_split_against_brute_force(arvx):
+    """tools/fuzz_cull.py in small: random ragged grids, cameras and noise masks; the split
+    carve (from a fresh and from a pre-carved model) must equal the brute-force kernel."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_cull", os.path.join(root, "tools", "fuzz_cull.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(2026)
+    assert all(fz.one_case(rng, i) for i in range(120))
