@@ -502,3 +502,23 @@ def test_fuzz_split_against_brute_force(arvx):
     spec.loader.exec_module(fz)
     rng = np.random.default_rng(2026)
     assert all(fz.one_case(rng, i) for i in range(120))
+
+
+def test_fuzz_against_oracle(arvx, oracle):
+    """Random small ragged grids, cameras (some inside the grid), image sizes, channel counts
+    and noise masks: GPU plane == oracle plane, every voxel, 200 cases."""
+    rng = np.random.default_rng(4242)
+    for i in range(200):
+        X, Y, Z = (int(rng.integers(1, 56)) for _ in range(3))
+        V = int(rng.integers(1, 20))
+        W, H = int(rng.integers(8, 120)), int(rng.integers(8, 90))
+        s = np.float32(0.512 / max(X, Y, Z))
+        _, _, M = scenes.random_cameras(V, 0.512, seed=int(rng.integers(1 << 30)), W=W, H=H,
+                                        inside=rng.random() < 0.4)
+        masks = scenes.noise_masks(V, H, W, C=int(rng.choice([1, 3])),
+                                   p_bg=float(rng.uniform(0.2, 0.8)),
+                                   block=int(rng.choice([1, 3, 8, 32])),
+                                   seed=int(rng.integers(1 << 30)))
+        want = oracle.carve(X, Y, Z, s, M, masks)
+        assert_same(run_gpu(arvx, X, Y, Z, s, M, masks), want,
+                    f"case {i}: {X}x{Y}x{Z} V={V} {W}x{H}")
