@@ -101,3 +101,27 @@ def test_fast_carve_rejects_slabs(arvx):
         ctx.set_views(sc.M, sc.masks)
         with pytest.raises(arvx.ArvxError):
             ctx.fast_carve()
+
+
+def test_fast_carve_fuzz(arvx, oracle):
+    """Random small ragged grids, cameras and noise masks, fresh models and models with
+    random pre-seen voxels (walls to the reference's BFS): GPU plane == oracle plane."""
+    rng = np.random.default_rng(77)
+    for i in range(120):
+        X, Y, Z = (int(rng.integers(1, 72)) for _ in range(3))
+        if rng.random() < 0.5:
+            X = max(8, X // 8 * 8)  # the 8- and 16-voxel-wide apply / pack kernels
+        V = int(rng.integers(1, 6))
+        W, H = int(rng.integers(16, 160)), int(rng.integers(16, 120))
+        s = np.float32(0.512 / max(X, Y, Z))
+        _, _, M = scenes.random_cameras(V, 0.512, seed=int(rng.integers(1 << 30)), W=W, H=H)
+        masks = scenes.noise_masks(V, H, W, block=int(rng.choice([1, 4, 12, 40])),
+                                   p_bg=float(rng.uniform(0.4, 0.9)), seed=int(rng.integers(1 << 30)))
+        state = None
+        if rng.random() < 0.4:  # some voxels already seen (and a few already carved)
+            state = np.ones((Z, Y, X), np.uint8)
+            state[rng.random((Z, Y, X)) < 0.05] = 3
+            state[rng.random((Z, Y, X)) < 0.01] = 2
+        want = oracle.fast_carve(X, Y, Z, s, M, masks, state=state)
+        got = gpu_fast(arvx, X, Y, Z, s, M, masks, state=state)
+        assert_same(got, want, f"case {i}: {X}x{Y}x{Z} V={V} pre={'yes' if state is not None else 'no'}")
