@@ -55,3 +55,42 @@ def test_fast_carve_256(arvx, oracle, scene):
         ctx.fast_carve()  # the cached work buffer is reused
         again = ctx.download_state()
     assert np.array_equal(got, want) and np.array_equal(again, want)
+
+
+def test_pipeline_fuzz(arvx, oracle):
+    """The same sequence on random small ragged grids with random cameras, noise masks and
+    noise images: carve (or greedy carve), colour (either mode), handleUnseen, closure,
+    marching-cubes cells -- every intermediate result equal to the oracle's."""
+    rng = np.random.default_rng(99)
+    for i in range(60):
+        X, Y, Z = (int(rng.integers(2, 48)) for _ in range(3))
+        Vn = int(rng.integers(1, 7))
+        W, H = int(rng.integers(16, 120)), int(rng.integers(16, 90))
+        s = np.float32(0.512 / max(X, Y, Z))
+        _, Rt, M = scenes.random_cameras(Vn, 0.512, seed=int(rng.integers(1 << 30)), W=W, H=H)
+        # F11: "camera position" = translation column of the world->camera matrix
+        campos = np.ascontiguousarray(Rt[:, :, 3], dtype=np.float32)
+        masks = scenes.noise_masks(Vn, H, W, block=int(rng.choice([2, 6, 20])),
+                                   p_bg=float(rng.uniform(0.3, 0.7)), seed=int(rng.integers(1 << 30)))
+        images = rng.integers(0, 256, size=(Vn, H, W, 3), dtype=np.uint8)
+        mode = int(rng.integers(0, 2))
+        greedy = rng.random() < 0.3
+        st = (oracle.fast_carve if greedy else oracle.carve)(X, Y, Z, s, M, masks)
+        model = oracle.color(X, Y, Z, s, M, campos, images, mode, oracle.model_from_state(st))
+        unseen = oracle.handle_unseen(st, model)
+        closed = oracle.closure(X, Y, Z, unseen)
+        with arvx.Context(X, Y, Z, s) as ctx:
+            ctx.set_views(M, masks, campos=campos)
+            ctx.set_images(images)
+            if greedy:
+                ctx.fast_carve()
+            else:
+                ctx.carve()
+            what = f"case {i}: {X}x{Y}x{Z} V={Vn} mode={mode} greedy={greedy}"
+            assert np.array_equal(ctx.download_state(), st), what
+            ctx.color(mode)
+            assert np.array_equal(ctx.export_model(False), model), what + " colours"
+            assert np.array_equal(ctx.export_model(True), unseen), what + " handleUnseen"
+            ctx.closure(3, True)
+            assert np.array_equal(ctx.export_model(True), closed), what + " closure"
+            assert np.array_equal(ctx.mc_cells(), oracle.mc_cells(X, Y, Z, closed)), what + " cells"
