@@ -38,6 +38,7 @@ SYMBOLS = [
     "arvx_colors_upload", "arvx_closure", "arvx_closure_count", "arvx_closure_download",
     "arvx_mc_cells", "arvx_mc_cells_download",
     "arvx_occupancy_packet_words", "arvx_occupancy_compress", "arvx_occupancy_expand",
+    "arvx_occupancy_expand_striped",
     "arvx_export_model", "arvx_get_stats", "arvx_selftest_divide", "arvx_selftest_round",
 ]
 
@@ -132,6 +133,10 @@ def load_library() -> C.CDLL:
         lib.arvx_occupancy_compress.argtypes = [p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         lib.arvx_occupancy_expand.argtypes = [p, C.c_void_p, C.c_int, C.c_int, C.c_int64,
                                               C.c_int64, C.c_void_p, C.c_void_p]
+        if hasattr(lib, "arvx_occupancy_expand_striped") or not ab_build:
+            lib.arvx_occupancy_expand_striped.argtypes = [p, C.c_void_p, C.c_int, C.c_int64,
+                                                          C.c_int64, C.c_int64, C.c_void_p,
+                                                          C.c_void_p]
     for name in SYMBOLS:
         if ab_build and not hasattr(lib, name):
             continue
@@ -309,6 +314,13 @@ class Context:
                                                self_rank, n_words64, cap_words64,
                                                C.c_void_p(dev_full_ptr),
                                                C.c_void_p(dev_overflow_ptr)))
+
+    def occupancy_expand_striped(self, dev_packets_ptr: int, world: int, n_words64: int,
+                                 cap_words64: int, words_per_group: int, dev_full_ptr: int,
+                                 dev_overflow_ptr: int) -> None:
+        _check(self._lib.arvx_occupancy_expand_striped(
+            self._h, C.c_void_p(dev_packets_ptr), world, n_words64, cap_words64, words_per_group,
+            C.c_void_p(dev_full_ptr), C.c_void_p(dev_overflow_ptr)))
 
     def set_stream(self, stream_ptr: int) -> None:
         _check(self._lib.arvx_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))

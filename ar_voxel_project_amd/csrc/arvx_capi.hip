@@ -494,7 +494,29 @@ int arvx_occupancy_expand(arvx_ctx *ctx, const void *dev_packets, int world, int
     const long long per = (nb + 2 * arvx::kExpandChunks - 1) / (2 * arvx::kExpandChunks);
     hipLaunchKernelGGL(arvx::occ_expand_kernel, dim3((unsigned)((per * world + 3) / 4)), dim3(256), 0,
                        ctx->stream, (const unsigned long long *)dev_packets, S, world, self_rank, n,
-                       (long long)cap_words64, (unsigned long long *)dev_full_words, dev_overflow);
+                       (long long)cap_words64, (unsigned long long *)dev_full_words, dev_overflow,
+                       0ll);
+    ARVX_HIP(hipGetLastError());
+    return ARVX_OK;
+}
+
+int arvx_occupancy_expand_striped(arvx_ctx *ctx, const void *dev_packets, int world,
+                                  int64_t n_words64, int64_t cap_words64, int64_t words_per_group,
+                                  void *dev_full_words, int *dev_overflow) {
+    ARVX_CHECK_CTX(ctx);
+    if (!dev_packets || !dev_full_words || !dev_overflow || world < 1 || n_words64 <= 0 ||
+        cap_words64 < 0 || words_per_group < 2 || (words_per_group & 1) ||
+        n_words64 % words_per_group)
+        return fail(ARVX_ERR_INVALID, "bad argument (words per group must be even and divide n)");
+    if (((uintptr_t)dev_packets & 7u) || ((uintptr_t)dev_full_words & 15u))
+        return fail(ARVX_ERR_INVALID, "packets must be 8-byte, the word plane 16-byte aligned");
+    const long long n = n_words64, nb = (n + 63) / 64;
+    const long long S = arvx::occ_packet_header(n) + cap_words64;
+    const long long per = (nb + 2 * arvx::kExpandChunks - 1) / (2 * arvx::kExpandChunks);
+    hipLaunchKernelGGL(arvx::occ_expand_kernel, dim3((unsigned)((per * world + 3) / 4)), dim3(256), 0,
+                       ctx->stream, (const unsigned long long *)dev_packets, S, world, -1, n,
+                       (long long)cap_words64, (unsigned long long *)dev_full_words, dev_overflow,
+                       (long long)words_per_group);
     ARVX_HIP(hipGetLastError());
     return ARVX_OK;
 }

@@ -100,11 +100,17 @@ __global__ __launch_bounds__(256) void occ_write_kernel(const unsigned long long
 // 2c + l/32.
 constexpr int kExpandChunks = 4;
 
+// wpg = 0: contiguous slabs, rank q's words go to q * n, `self` is skipped (its words are
+// there already).  wpg > 0: striped slabs -- the planes are cut into groups of 8 (wpg words
+// each, even) and rank q owns groups q, q + world, ...: its word i goes to
+// ((i / wpg) * world + q) * wpg + i % wpg, and every rank is expanded, the caller's included
+// (pass self = -1).
 __global__ __launch_bounds__(256) void occ_expand_kernel(const unsigned long long *__restrict__ in,
                                                          long long S, int world, int self,
                                                          long long n, long long cap,
                                                          unsigned long long *__restrict__ full,
-                                                         int *__restrict__ overflow) {
+                                                         int *__restrict__ overflow,
+                                                         long long wpg) {
     const long long nb = (n + 63) / 64;
     const long long per = (nb + 2 * kExpandChunks - 1) / (2 * kExpandChunks);  // waves per slab
     const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -120,8 +126,8 @@ __global__ __launch_bounds__(256) void occ_expand_kernel(const unsigned long lon
     }
     const long long H = occ_packet_header(n);
     const unsigned *goff = reinterpret_cast<const unsigned *>(pk + 1 + 2 * nb);
-    unsigned long long *dst = full + (long long)q * n;
-    const bool pair_ok = (((long long)q * n) & 1) == 0;  // 16-byte aligned pairs
+    unsigned long long *dst = full + (wpg ? 0 : (long long)q * n);
+    const bool pair_ok = wpg ? true : (((long long)q * n) & 1) == 0;  // 16-byte aligned pairs
     const int bit = 2 * (lane & 31);
     unsigned long long ones[kExpandChunks], mixed[kExpandChunks];
     long long off[kExpandChunks];
@@ -142,11 +148,13 @@ __global__ __launch_bounds__(256) void occ_expand_kernel(const unsigned long lon
         unsigned long long w0 = (o2 & 1u) ? ~0ull : 0ull, w1 = (o2 & 2u) ? ~0ull : 0ull;
         if (m2 & 1u) w0 = pk[at];
         if (m2 & 2u) w1 = pk[at + (m2 & 1u)];
+        // (striped: i is even and wpg is even, so i and i + 1 lie in the same group)
+        const long long at_dst = wpg ? ((i / wpg) * world + q) * wpg + i % wpg : i;
         if (pair_ok && i + 1 < n) {
-            *reinterpret_cast<ulonglong2 *>(dst + i) = make_ulonglong2(w0, w1);
+            *reinterpret_cast<ulonglong2 *>(dst + at_dst) = make_ulonglong2(w0, w1);
         } else {
-            dst[i] = w0;
-            if (i + 1 < n) dst[i + 1] = w1;
+            dst[at_dst] = w0;
+            if (i + 1 < n) dst[at_dst + 1] = w1;
         }
     }
 }

@@ -13,9 +13,10 @@ N = 1   512^3 grid x 36 views (the configuration the metric is quoted on)
 N > 1   one rank per GPU; rank r carves Z slab r of a grid that holds N x 512^3
         voxels (weak scaling), then ONE collective over RCCL merges the
         bit-packed occupancy of all slabs: by default an all-gather of compressed
-        packets (two bitmaps + the mixed 64-bit words of each slab, expanded by one
-        kernel on the receivers), --collective allgather for the plain in-place
-        all-gather, --collective allreduce for the north star's all-reduce.
+        packets (two bitmaps + the mixed 64-bit words of each rank's planes, expanded
+        by one kernel on the receivers) over striped, load-balanced slabs,
+        --collective allgather for the plain in-place all-gather of contiguous slabs,
+        --collective allreduce for the north star's all-reduce (striped slabs).
 
 The JSON line also carries `roofline` (algorithmic HBM bytes of SURVEY 8d / the
 carve kernel's launch time measured with HIP events on its own stream) and
@@ -152,7 +153,9 @@ def main():
         nvox_global = X * Y * Z
         flags = capi.CARVE_NO_CULL if (args.no_cull or no_cull) else 0
         # allreduce: striped (load-balanced) slabs; allgather needs contiguous ones
-        layout = "striped" if (world > 1 and collective in ("allreduce", "none")) else "slab"
+        # striped (load-balanced) slabs wherever the collective can place scattered words;
+        # the plain all-gather needs contiguous ones
+        layout = "striped" if (world > 1 and collective != "allgather") else "slab"
         if layout == "striped":
             ctx = capi.Context(X, Y, Z, sc.voxel_size, device=local_rank, stripes=(world, rank))
         else:
@@ -186,7 +189,10 @@ def main():
             if ex is not None:
                 b = nstep[0] % 2
                 ex.prepare(b, verify=False)  # compressed: overflow is checked after drain()
-                ctx.pack_occupancy_global(ex.full[b].data_ptr())
+                if collective == "compressed":  # the rank's planes in local order -> one packet
+                    ctx.pack_occupancy(ex.local[b].data_ptr())
+                else:
+                    ctx.pack_occupancy_global(ex.full[b].data_ptr())
                 ex.launch(b, async_op=True)
             nstep[0] += 1
 

@@ -165,6 +165,14 @@ int arvx_occupancy_compress(arvx_ctx *ctx, const void *dev_words, int64_t n_word
 int arvx_occupancy_expand(arvx_ctx *ctx, const void *dev_packets, int world, int self_rank,
                           int64_t n_words64, int64_t cap_words64, void *dev_full_words,
                           int *dev_overflow);
+/* The same for striped slabs (arvx_ctx_create_striped: rank q owns the 8-plane groups q,
+ * q + world, ...; a packet holds a rank's planes in its local order, arvx_pack_occupancy):
+ * word i of rank q goes to ((i / wpg) * world + q) * wpg + i % wpg of the whole grid's plane,
+ * wpg = words_per_group = X*Y*8/64 (must be even).  Every rank's packet is expanded, the
+ * caller's own included. */
+int arvx_occupancy_expand_striped(arvx_ctx *ctx, const void *dev_packets, int world,
+                                  int64_t n_words64, int64_t cap_words64, int64_t words_per_group,
+                                  void *dev_full_words, int *dev_overflow);
 
 /* ---- hot path --------------------------------------------------------- */
 

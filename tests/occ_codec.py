@@ -64,6 +64,23 @@ def expand(packets, world, self_rank, n, cap, full):
     return overflow
 
 
+def expand_striped(packets, world, n, cap, wpg, full):
+    """Every rank's packet (the caller's too) -> its 8-plane groups q, q + world, ... of the
+    whole plane (wpg words per group).  -> True if some packet had outgrown cap."""
+    tmp = np.zeros(world * n, U64)
+    over = expand(packets, world, -1, n, cap, tmp)
+    H = header_words(n)
+    S = H + cap
+    for q in range(world):
+        if int(packets[q * S]) > cap:
+            continue
+        loc = tmp[q * n:(q + 1) * n].reshape(-1, wpg)
+        for gl in range(loc.shape[0]):
+            g = gl * world + q
+            full[g * wpg:(g + 1) * wpg] = loc[gl]
+    return over
+
+
 def _arr(ptr, nwords, dtype=U64):
     ct = {U64: C.c_uint64, np.int32: C.c_int32}[dtype]
     return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(nwords,))
@@ -75,6 +92,12 @@ class NumpyCodec:
     def occupancy_compress(self, words_ptr, n, packet_ptr, cap):
         pk = _arr(packet_ptr, header_words(n) + cap)
         pk[:] = compress(_arr(words_ptr, n), cap)
+
+    def occupancy_expand_striped(self, packets_ptr, world, n, cap, wpg, full_ptr, overflow_ptr):
+        S = header_words(n) + cap
+        if expand_striped(_arr(packets_ptr, world * S), world, n, cap, wpg,
+                          _arr(full_ptr, world * n)):
+            _arr(overflow_ptr, 1, np.int32)[0] = 1
 
     def occupancy_expand(self, packets_ptr, world, self_rank, n, cap, full_ptr, overflow_ptr):
         S = header_words(n) + cap

@@ -137,3 +137,38 @@ def test_carved_slabs_round_trip():
         assert not d_flag.item()
         assert torch.equal(d_full, torch.cat(packed))
     c.close()
+
+
+@pytest.mark.parametrize("wpg,groups,world", [(2, 3, 2), (32, 5, 3), (1024, 4, 8)])
+def test_expand_striped_matches_restatement(ctx, wpg, groups, world):
+    """Striped slabs: word i of rank q lands at ((i / wpg) * world + q) * wpg + i % wpg, for
+    every rank including the caller; an overflowing packet leaves its words alone."""
+    rng = np.random.default_rng(wpg + world)
+    n = wpg * groups
+    slabs = [_words(rng, n, 0.6, 0.3) for _ in range(world)]
+    need = max(int(((w != 0) & (w != occ_codec.ONES)).sum()) for w in slabs)
+    for cap, over in ((need + 1, False), (max(need - 1, 0), need > 0)):
+        S = occ_codec.header_words(n) + cap
+        d_pk = torch.zeros(world * S, dtype=torch.int64, device="cuda")
+        d_ws = [_dev(w) for w in slabs]
+        _settle()
+        for q, d_w in enumerate(d_ws):
+            ctx.occupancy_compress(d_w.data_ptr(), n, d_pk[q * S:].data_ptr(), cap)
+        ctx.synchronize()
+        pk = d_pk.cpu().numpy().view(np.uint64)
+        full0 = rng.integers(0, 2 ** 62, world * n, dtype=np.uint64)
+        d_full = _dev(full0)
+        d_flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _settle()
+        ctx.occupancy_expand_striped(d_pk.data_ptr(), world, n, cap, wpg, d_full.data_ptr(),
+                                     d_flag.data_ptr())
+        ctx.synchronize()
+        want = full0.copy()
+        assert occ_codec.expand_striped(pk, world, n, cap, wpg, want) == over
+        assert bool(d_flag.item()) == over
+        assert np.array_equal(d_full.cpu().numpy().view(np.uint64), want)
+        if not over:
+            for q, w in enumerate(slabs):
+                for gl in range(groups):
+                    g = gl * world + q
+                    assert np.array_equal(want[g * wpg:(g + 1) * wpg], w[gl * wpg:(gl + 1) * wpg])

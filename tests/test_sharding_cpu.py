@@ -73,9 +73,15 @@ def _worker(rank, world, port, mode, tmpdir, layout="slab", tight_cap=None):
         for step in range(3):  # buffers are reused across steps
             b = step % 2
             ex.prepare(b)
-            buf = ex.full[b].numpy()
-            for z in planes:  # what arvx_pack_occupancy_global does on the device
-                buf[z * wpp:(z + 1) * wpp] = pack_bits(full[z])
+            if mode == "compressed" and layout == "striped":
+                # what arvx_pack_occupancy does on the device: the rank's planes, local order
+                loc = ex.local[b].numpy().view(np.int32)
+                for k, z in enumerate(planes):
+                    loc[k * wpp:(k + 1) * wpp] = pack_bits(full[z])
+            else:
+                buf = ex.full[b].numpy()
+                for z in planes:  # what arvx_pack_occupancy_global does on the device
+                    buf[z * wpp:(z + 1) * wpp] = pack_bits(full[z])
             ex.launch(b, async_op=True)
             if mode == "compressed" and step == 0:
                 # the first exchange ships worst-case packets; size the next ones to need
@@ -99,7 +105,8 @@ def _worker(rank, world, port, mode, tmpdir, layout="slab", tight_cap=None):
 
 
 @pytest.mark.parametrize("mode,layout", [("allreduce", "slab"), ("allgather", "slab"),
-                                         ("allreduce", "striped"), ("compressed", "slab")])
+                                         ("allreduce", "striped"), ("compressed", "slab"),
+                                         ("compressed", "striped")])
 def test_occupancy_exchange_world2_gloo(tmp_path, oracle, mode, layout):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path), layout), nprocs=world,
@@ -107,9 +114,10 @@ def test_occupancy_exchange_world2_gloo(tmp_path, oracle, mode, layout):
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
-def test_compressed_exchange_overflow_falls_back_gloo(tmp_path, oracle):
+@pytest.mark.parametrize("layout", ["slab", "striped"])
+def test_compressed_exchange_overflow_falls_back_gloo(tmp_path, oracle, layout):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), "compressed", str(tmp_path), "slab", 1),
+    mp.spawn(_worker, args=(world, _free_port(), "compressed", str(tmp_path), layout, 1),
              nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
@@ -155,5 +163,8 @@ def test_exchange_rejects_unaligned_slabs():
         sharding.OccupancyExchange(8, 8, 9, 2, 0, "cpu", mode="allgather")
     with pytest.raises(ValueError):
         sharding.OccupancyExchange(8, 8, 16, 2, 0, "cpu", mode="allgather", layout="striped")
+    with pytest.raises(ValueError):  # Z must hold whole stripes of every rank
+        sharding.OccupancyExchange(8, 8, 24, 2, 0, "cpu", mode="compressed", layout="striped",
+                                   codec=object())
     with pytest.raises(ValueError):
         sharding.OccupancyExchange(8, 8, 12, 2, 0, "cpu", layout="striped")
