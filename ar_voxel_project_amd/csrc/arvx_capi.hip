@@ -417,7 +417,11 @@ int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
     ARVX_CHECK_CTX(ctx);
     if (int mrc = materialize(ctx)) return mrc;
     if (!dev_words) return fail(ARVX_ERR_INVALID, "null dev_words");
-    if (ctx->nvox % 32 == 0 && (uintptr_t)ctx->owned() % 8 == 0) {
+    if (ctx->nvox % 32 == 0 && (uintptr_t)ctx->owned() % 16 == 0 && (uintptr_t)dev_words % 4 == 0) {
+        const size_t nwords = ctx->nvox / 32;
+        hipLaunchKernelGGL(arvx::pack_occupancy32_kernel, dim3((unsigned)((nwords + 255) / 256)),
+                           dim3(256), 0, ctx->stream, ctx->owned(), nwords, (uint32_t *)dev_words);
+    } else if (ctx->nvox % 32 == 0 && (uintptr_t)ctx->owned() % 8 == 0) {
         const size_t nbytes = ctx->nvox / 8;
         hipLaunchKernelGGL(arvx::pack_occupancy8_kernel, dim3((unsigned)((nbytes + 255) / 256)),
                            dim3(256), 0, ctx->stream, ctx->owned(), nbytes, (uint8_t *)dev_words);

@@ -1337,6 +1337,20 @@ __global__ __launch_bounds__(256) void pack_occupancy8_kernel(const uint8_t *__r
     out[t] = (uint8_t)(((s & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
 }
 
+// 32 voxels per thread: two 16-byte loads in, one 32-bit word of the plane out.  Needs a
+// 16-aligned plane and n % 32 == 0.
+__global__ __launch_bounds__(256) void pack_occupancy32_kernel(const uint8_t *__restrict__ state,
+                                                               size_t nwords,
+                                                               uint32_t *__restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nwords) return;
+    const ulonglong2 a = ((const ulonglong2 *)state)[2 * t], b = ((const ulonglong2 *)state)[2 * t + 1];
+    const unsigned long long one = 0x0101010101010101ull, mul = 0x0102040810204080ull;
+    out[t] = (uint32_t)(((a.x & one) * mul) >> 56) | ((uint32_t)(((a.y & one) * mul) >> 56) << 8) |
+             ((uint32_t)(((b.x & one) * mul) >> 56) << 16) |
+             ((uint32_t)(((b.y & one) * mul) >> 56) << 24);
+}
+
 // the global (slab / striped) form of the same; plane % 64 == 0
 __global__ __launch_bounds__(256) void pack_occupancy_global8_kernel(
     const uint8_t *__restrict__ state, size_t plane, int Zloc, int zoff, int zstride, int zphase,
