@@ -71,7 +71,10 @@ template <int PRED>
 static int launch_bit_pack(Ctx *ctx, const uint8_t *state, const arvx::BitGrid &g,
                            int apply_unseen, unsigned long long *bits) {
     const size_t nwords = (size_t)g.XW * g.Y * g.Z;
-    if (g.X % 8 == 0)
+    if (g.X % 32 == 0 && ((uintptr_t)state & 15u) == 0)
+        hipLaunchKernelGGL(arvx::bit_pack32_kernel<PRED>, dim3((unsigned)((nwords * 2 + 255) / 256)),
+                           dim3(256), 0, ctx->stream, state, g, apply_unseen, bits);
+    else if (g.X % 8 == 0)
         hipLaunchKernelGGL(arvx::bit_pack8_kernel<PRED>, dim3((unsigned)((nwords * 8 + 255) / 256)),
                            dim3(256), 0, ctx->stream, state, g, apply_unseen, bits);
     else

@@ -61,6 +61,31 @@ __global__ __launch_bounds__(256) void bit_pack8_kernel(const uint8_t *__restric
     ((uint8_t *)bits)[t] = b;
 }
 
+// X % 32 == 0 and a 16-byte aligned plane: one thread turns 32 voxels into one 32-bit half of
+// a word of the plane (two 16-byte loads)
+template <int PRED>
+__global__ __launch_bounds__(256) void bit_pack32_kernel(const uint8_t *__restrict__ state,
+                                                         const BitGrid g, int apply_unseen,
+                                                         unsigned long long *__restrict__ bits) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int rowHalves = g.XW * 2;
+    const size_t nrows = (size_t)g.Y * g.Z;
+    if (t >= nrows * rowHalves) return;
+    const size_t row = t / rowHalves;
+    const int h = (int)(t % rowHalves);
+    uint32_t w = 0;
+    if (h * 32 < g.X) {
+        const ulonglong2 *src = (const ulonglong2 *)(state + row * g.X + (size_t)h * 32);
+        const ulonglong2 a = src[0], b = src[1];
+        const unsigned long long mul = 0x0102040810204080ull;
+        w = (uint32_t)((bit_pred8<PRED>(a.x, apply_unseen) * mul) >> 56) |
+            ((uint32_t)((bit_pred8<PRED>(a.y, apply_unseen) * mul) >> 56) << 8) |
+            ((uint32_t)((bit_pred8<PRED>(b.x, apply_unseen) * mul) >> 56) << 16) |
+            ((uint32_t)((bit_pred8<PRED>(b.y, apply_unseen) * mul) >> 56) << 24);
+    }
+    ((uint32_t *)bits)[t] = w;
+}
+
 // any X: one wave per word
 template <int PRED>
 __global__ __launch_bounds__(256) void bit_pack_kernel(const uint8_t *__restrict__ state,
