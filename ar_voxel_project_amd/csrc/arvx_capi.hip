@@ -1269,7 +1269,12 @@ int arvx_fast_carve(arvx_ctx *ctx) {
 
     // carvable = what the dense carve clears on a fresh plane (not read: `fresh`)
     if (int rc = launch_carve(ctx, d_tmp, 0, ctx->V, 0, true)) return rc;
-    if (by8) {
+    if (fp.X % 32 == 0 && (((uintptr_t)d_tmp | (uintptr_t)ctx->d_state) & 15u) == 0) {
+        ARVX_HIP(hipMemsetAsync(fp.reach, 0, nwords * sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(arvx::flood_pack_open32_kernel,
+                           dim3((unsigned)((nwords * 2 + 255) / 256)), dim3(256), 0, ctx->stream,
+                           d_tmp, ctx->d_state, fp);
+    } else if (by8) {
         ARVX_HIP(hipMemsetAsync(fp.reach, 0, nwords * sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(arvx::flood_pack_open8_kernel,
                            dim3((unsigned)((nwords * 8 + 255) / 256)), dim3(256), 0, ctx->stream,
