@@ -26,7 +26,7 @@ COLOR_AVERAGE = 1
 
 # every symbol include/arvx/arvx.h declares
 SYMBOLS = [
-    "arvx_version", "arvx_last_error", "arvx_device_count",
+    "arvx_version", "arvx_last_error", "arvx_device_count", "arvx_projection_assoc",
     "arvx_ctx_create", "arvx_ctx_create_slab", "arvx_ctx_create_striped", "arvx_ctx_destroy",
     "arvx_ctx_set_stream", "arvx_ctx_synchronize", "arvx_ctx_voxels",
     "arvx_compose_projection", "arvx_set_views", "arvx_set_views_device",
@@ -60,17 +60,20 @@ class Stats(C.Structure):
     ]
 
 
-_lib = None
+_libs: dict = {}
+# the build with the other grouping of the M*world row sums (csrc/arvx_device.h, row_sum)
+ASSOC_LEFT_LIB_PATH = os.path.join(_HERE, "lib", "libarvx_assoc_left.so")
 
 
-def load_library() -> C.CDLL:
-    """Load libarvx.so (built in-tree by ar_voxel_project_amd.build)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """Load libarvx.so (built in-tree by ar_voxel_project_amd.build), or another build
+    of it at `path` (tests of the ARVX_ASSOC_LEFT variant)."""
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise FileNotFoundError(
-            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or make -C ar_voxel_project_amd/csrc); there is no CPU fallback")
     # torch (device memory / streams / torch.distributed in bench and tests) ships its
     # own HIP runtime; it must be loaded BEFORE libarvx.so pulls in /opt/rocm's, or a
@@ -79,11 +82,13 @@ def load_library() -> C.CDLL:
         import torch  # noqa: F401
     except ImportError:
         pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     p = C.c_void_p
     f32p = C.POINTER(C.c_float)
     u8p = C.POINTER(C.c_uint8)
     lib.arvx_version.restype = C.c_int
+    if hasattr(lib, "arvx_projection_assoc"):
+        lib.arvx_projection_assoc.restype = C.c_int
     lib.arvx_last_error.restype = C.c_char_p
     lib.arvx_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.arvx_ctx_create.argtypes = [C.POINTER(p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
@@ -145,7 +150,7 @@ def load_library() -> C.CDLL:
             fn.restype = C.c_int64
         elif name not in ("arvx_last_error",):
             fn.restype = C.c_int
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 
@@ -154,9 +159,10 @@ def occupancy_packet_words(n_words64: int, cap_words64: int) -> int:
     return int(load_library().arvx_occupancy_packet_words(n_words64, cap_words64))
 
 
-def _check(rc: int) -> None:
+def _check(rc: int, lib: Optional[C.CDLL] = None) -> None:
     if rc != 0:
-        raise ArvxError(rc, load_library().arvx_last_error().decode("utf-8", "replace"))
+        lib = lib or load_library()
+        raise ArvxError(rc, lib.arvx_last_error().decode("utf-8", "replace"))
 
 
 def _f32(a) -> np.ndarray:
@@ -187,29 +193,33 @@ class Context:
 
     def __init__(self, X: int, Y: int, Z: int, voxel_size: float, device: int = 0,
                  z_range: Optional[Sequence[int]] = None,
-                 stripes: Optional[Sequence[int]] = None):
+                 stripes: Optional[Sequence[int]] = None, lib_path: Optional[str] = None):
         """z_range=(z0,z1): contiguous slab.  stripes=(world, rank): 8-plane groups
-        rank, rank+world, ... (load-balanced multi-GPU split)."""
-        self._lib = load_library()
+        rank, rank+world, ... (load-balanced multi-GPU split).  lib_path: another build of
+        the library (ASSOC_LEFT_LIB_PATH)."""
+        self._lib = load_library(lib_path)
         self._h = C.c_void_p()
         self.X, self.Y, self.Z = int(X), int(Y), int(Z)
         self.voxel_size = float(np.float32(voxel_size))
         if stripes is not None:
             world, rank = int(stripes[0]), int(stripes[1])
-            _check(self._lib.arvx_ctx_create_striped(C.byref(self._h), device, X, Y, Z,
+            self._ck(self._lib.arvx_ctx_create_striped(C.byref(self._h), device, X, Y, Z,
                                                      C.c_float(voxel_size), world, rank))
             self.planes = stripe_planes(Z, world, rank)
             self.z_range = None
         else:
             z0, z1 = (0, Z) if z_range is None else (int(z_range[0]), int(z_range[1]))
             self.z_range = (z0, z1)
-            _check(self._lib.arvx_ctx_create_slab(C.byref(self._h), device, X, Y, Z,
+            self._ck(self._lib.arvx_ctx_create_slab(C.byref(self._h), device, X, Y, Z,
                                                   C.c_float(voxel_size), z0, z1))
             self.planes = np.arange(z0, z1)
         nz = len(self.planes)  # global z of every local plane
         self.shape = (nz, Y, X)  # numpy view of the state plane: [z][y][x]
         self.nvox = nz * Y * X
         self._keep = []
+
+    def _ck(self, rc: int) -> None:
+        _check(rc, self._lib)
 
     def close(self) -> None:
         if self._h:
@@ -242,7 +252,7 @@ class Context:
         if campos is not None:
             campos = _f32(campos).reshape(V, 3)
             cp = _fp(campos)
-        _check(self._lib.arvx_set_views(self._h, V, _fp(M), cp, ptrs, W, H, Cn, W * Cn))
+        self._ck(self._lib.arvx_set_views(self._h, V, _fp(M), cp, ptrs, W, H, Cn, W * Cn))
         self.V, self.W, self.H = V, W, H
 
     def set_views_device(self, M, dev_masks_ptr: int, W: int, H: int, Cn: int,
@@ -254,7 +264,7 @@ class Context:
             campos = _f32(campos).reshape(V, 3)
             cp = _fp(campos)
         self._keep = [M, campos]
-        _check(self._lib.arvx_set_views_device(self._h, V, _fp(M), cp,
+        self._ck(self._lib.arvx_set_views_device(self._h, V, _fp(M), cp,
                                                C.c_void_p(dev_masks_ptr), W, H, Cn))
         self.V, self.W, self.H = V, W, H
 
@@ -264,26 +274,26 @@ class Context:
         V, H, W, Cn = images.shape
         assert Cn == 3 and V == self.V and H == self.H and W == self.W
         ptrs = (C.c_void_p * V)(*[images[i].ctypes.data for i in range(V)])
-        _check(self._lib.arvx_set_images(self._h, ptrs, W * 3))
+        self._ck(self._lib.arvx_set_images(self._h, ptrs, W * 3))
 
     # -- state --
     def reset(self) -> None:
-        _check(self._lib.arvx_state_reset(self._h))
+        self._ck(self._lib.arvx_state_reset(self._h))
 
     def upload_state(self, state) -> None:
         state = np.ascontiguousarray(state, dtype=np.uint8).reshape(-1)
         assert state.size == self.nvox
-        _check(self._lib.arvx_state_upload(self._h, state.ctypes.data_as(C.POINTER(C.c_uint8))))
+        self._ck(self._lib.arvx_state_upload(self._h, state.ctypes.data_as(C.POINTER(C.c_uint8))))
 
     def download_state(self) -> np.ndarray:
         out = np.empty(self.nvox, np.uint8)
-        _check(self._lib.arvx_state_download(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        self._ck(self._lib.arvx_state_download(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out.reshape(self.shape)
 
     def state_device_ptr(self) -> int:
         ptr = C.c_void_p()
         n = C.c_size_t()
-        _check(self._lib.arvx_state_device_ptr(self._h, C.byref(ptr), C.byref(n)))
+        self._ck(self._lib.arvx_state_device_ptr(self._h, C.byref(ptr), C.byref(n)))
         return int(ptr.value)
 
     def upload_halo(self, below=None, above=None) -> None:
@@ -294,23 +304,23 @@ class Context:
             assert a.size == self.X * self.Y
             self._keep.append(a)
             return a.ctypes.data_as(C.POINTER(C.c_uint8))
-        _check(self._lib.arvx_state_upload_halo(self._h, ptr(below), ptr(above)))
+        self._ck(self._lib.arvx_state_upload_halo(self._h, ptr(below), ptr(above)))
 
     def pack_occupancy(self, dev_words_ptr: int) -> None:
-        _check(self._lib.arvx_pack_occupancy(self._h, C.c_void_p(dev_words_ptr)))
+        self._ck(self._lib.arvx_pack_occupancy(self._h, C.c_void_p(dev_words_ptr)))
 
     def pack_occupancy_global(self, dev_global_words_ptr: int) -> None:
-        _check(self._lib.arvx_pack_occupancy_global(self._h, C.c_void_p(dev_global_words_ptr)))
+        self._ck(self._lib.arvx_pack_occupancy_global(self._h, C.c_void_p(dev_global_words_ptr)))
 
     # -- compressed occupancy exchange (device pointers; see include/arvx/arvx.h) --
     def occupancy_compress(self, dev_words_ptr: int, n_words64: int, dev_packet_ptr: int,
                            cap_words64: int) -> None:
-        _check(self._lib.arvx_occupancy_compress(self._h, C.c_void_p(dev_words_ptr), n_words64,
+        self._ck(self._lib.arvx_occupancy_compress(self._h, C.c_void_p(dev_words_ptr), n_words64,
                                                  C.c_void_p(dev_packet_ptr), cap_words64))
 
     def occupancy_expand(self, dev_packets_ptr: int, world: int, self_rank: int, n_words64: int,
                          cap_words64: int, dev_full_ptr: int, dev_overflow_ptr: int) -> None:
-        _check(self._lib.arvx_occupancy_expand(self._h, C.c_void_p(dev_packets_ptr), world,
+        self._ck(self._lib.arvx_occupancy_expand(self._h, C.c_void_p(dev_packets_ptr), world,
                                                self_rank, n_words64, cap_words64,
                                                C.c_void_p(dev_full_ptr),
                                                C.c_void_p(dev_overflow_ptr)))
@@ -318,63 +328,63 @@ class Context:
     def occupancy_expand_striped(self, dev_packets_ptr: int, world: int, n_words64: int,
                                  cap_words64: int, words_per_group: int, dev_full_ptr: int,
                                  dev_overflow_ptr: int) -> None:
-        _check(self._lib.arvx_occupancy_expand_striped(
+        self._ck(self._lib.arvx_occupancy_expand_striped(
             self._h, C.c_void_p(dev_packets_ptr), world, n_words64, cap_words64, words_per_group,
             C.c_void_p(dev_full_ptr), C.c_void_p(dev_overflow_ptr)))
 
     def set_stream(self, stream_ptr: int) -> None:
-        _check(self._lib.arvx_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
+        self._ck(self._lib.arvx_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
 
     def synchronize(self) -> None:
-        _check(self._lib.arvx_ctx_synchronize(self._h))
+        self._ck(self._lib.arvx_ctx_synchronize(self._h))
 
     # -- hot path --
     def carve(self, flags: int = 0) -> None:
-        _check(self._lib.arvx_carve(self._h, flags))
+        self._ck(self._lib.arvx_carve(self._h, flags))
 
     def carve_views(self, first: int, count: int, flags: int = 0) -> None:
-        _check(self._lib.arvx_carve_views(self._h, first, count, flags))
+        self._ck(self._lib.arvx_carve_views(self._h, first, count, flags))
 
     def fast_carve(self) -> None:
-        _check(self._lib.arvx_fast_carve(self._h))
+        self._ck(self._lib.arvx_fast_carve(self._h))
 
     def color(self, mode: int) -> None:
-        _check(self._lib.arvx_color(self._h, mode))
+        self._ck(self._lib.arvx_color(self._h, mode))
 
     def surface(self):
         n = C.c_int64()
-        _check(self._lib.arvx_surface_count(self._h, C.byref(n)))
+        self._ck(self._lib.arvx_surface_count(self._h, C.byref(n)))
         idx = np.empty(n.value, np.int64)
         rgb = np.empty((n.value, 3), np.float32)
         if n.value:
-            _check(self._lib.arvx_surface_download(
+            self._ck(self._lib.arvx_surface_download(
                 self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)), _fp(rgb)))
         return idx, rgb
 
     def surface_depth(self) -> np.ndarray:
         n = C.c_int64()
-        _check(self._lib.arvx_surface_count(self._h, C.byref(n)))
+        self._ck(self._lib.arvx_surface_count(self._h, C.byref(n)))
         d = np.empty(n.value, np.float32)
         if n.value:
-            _check(self._lib.arvx_surface_depth_download(self._h, _fp(d)))
+            self._ck(self._lib.arvx_surface_depth_download(self._h, _fp(d)))
         return d
 
     def upload_colors(self, index, rgb) -> None:
         index = np.ascontiguousarray(index, dtype=np.int64)
         rgb = _f32(rgb).reshape(-1, 3)
         assert len(index) == len(rgb)
-        _check(self._lib.arvx_colors_upload(self._h, len(index),
+        self._ck(self._lib.arvx_colors_upload(self._h, len(index),
                                             index.ctypes.data_as(C.POINTER(C.c_int64)), _fp(rgb)))
 
     def closure(self, kernel_size: int = 3, apply_unseen: bool = True):
         """applyClosure; returns (flat indices of the filled voxels, their RGBA)."""
-        _check(self._lib.arvx_closure(self._h, kernel_size, int(apply_unseen)))
+        self._ck(self._lib.arvx_closure(self._h, kernel_size, int(apply_unseen)))
         n = C.c_int64()
-        _check(self._lib.arvx_closure_count(self._h, C.byref(n)))
+        self._ck(self._lib.arvx_closure_count(self._h, C.byref(n)))
         idx = np.empty(n.value, np.int64)
         rgba = np.empty((n.value, 4), np.float32)
         if n.value:
-            _check(self._lib.arvx_closure_download(
+            self._ck(self._lib.arvx_closure_download(
                 self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)), _fp(rgba)))
         return idx, rgba
 
@@ -382,33 +392,33 @@ class Context:
         """(n, 4) int32 -- x, y, z, cube index of the cells marchingCubes would
         triangulate, in its visiting order (x outermost, z innermost)."""
         n = C.c_int64()
-        _check(self._lib.arvx_mc_cells(self._h, C.byref(n)))
+        self._ck(self._lib.arvx_mc_cells(self._h, C.byref(n)))
         cells = np.empty((n.value, 4), np.int32)
         if n.value:
-            _check(self._lib.arvx_mc_cells_download(
+            self._ck(self._lib.arvx_mc_cells_download(
                 self._h, cells.ctypes.data_as(C.POINTER(C.c_int32))))
         return cells
 
     def export_model(self, apply_unseen: bool = False) -> np.ndarray:
         out = np.empty((self.nvox, 4), np.float32)
-        _check(self._lib.arvx_export_model(self._h, _fp(out), int(apply_unseen)))
+        self._ck(self._lib.arvx_export_model(self._h, _fp(out), int(apply_unseen)))
         return out
 
     def selftest_divide(self, a0, a1, b) -> np.ndarray:
         a0, a1, b = _f32(a0).reshape(-1), _f32(a1).reshape(-1), _f32(b).reshape(-1)
         out = np.empty((len(b), 4), np.float32)
-        _check(self._lib.arvx_selftest_divide(self._h, len(b), _fp(a0), _fp(a1), _fp(b), _fp(out)))
+        self._ck(self._lib.arvx_selftest_divide(self._h, len(b), _fp(a0), _fp(a1), _fp(b), _fp(out)))
         return out
 
     def selftest_round(self) -> int:
         """Mismatches between the kernels' pixel rounding and std::round (must be 0)."""
         n = C.c_int64(-1)
-        _check(self._lib.arvx_selftest_round(self._h, C.byref(n)))
+        self._ck(self._lib.arvx_selftest_round(self._h, C.byref(n)))
         return int(n.value)
 
     def stats(self) -> dict:
         s = Stats()
-        _check(self._lib.arvx_get_stats(self._h, C.byref(s)))
+        self._ck(self._lib.arvx_get_stats(self._h, C.byref(s)))
         out = {k: int(getattr(s, k)) for k, _ in Stats._fields_ if k != "reserved"}
         out["slices_evaluated"] = int(s.reserved[0])  # 256-voxel slices projected exactly
         out["open_voxels_in_slices"] = int(s.reserved[1])  # of those voxels, not yet finished

@@ -115,6 +115,14 @@ int arvx_version(void) { return ARVX_VERSION; }
 
 const char *arvx_last_error(void) { return g_last_error.c_str(); }
 
+int arvx_projection_assoc(void) {
+#ifdef ARVX_ASSOC_LEFT
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int arvx_device_count(int *count) {
     if (!count) return fail(ARVX_ERR_INVALID, "null count");
     *count = 0;

@@ -4,7 +4,10 @@
 // reference src/VoxelCarving.cpp:18-21,41-54 and src/Model.h:134-140):
 //   w    = (float(y)*s, float(x)*s, float(-z)*s, 1)              fp32
 //   p_k  = double(M[r][k]) * double(w[k])                        exact in fp64
-//   a_r  = float(((p0 + p1) + p2) + p3)                          cv::gemm generic path
+//   a_r  = float(p0 + ((p1 + p2) + p3))                          cv::gemm generic path, 4-way
+//          unrolled `s0 += s1 + s2 + s3`; built with -DARVX_ASSOC_LEFT:
+//          float(((p0 + p1) + p2) + p3), the other plausible grouping (oracle:
+//          -DARVX_ORACLE_ASSOC_LEFT) -- tests/test_assoc_gpu.py tells the two apart
 //   u,v  = a_0 / a_2, a_1 / a_2                                  IEEE fp32 divide
 //   px   = (int)roundf(u), py = (int)roundf(v); inside iff 0<=px<W, 0<=py<H
 // The library is built with -ffp-contract=off so only explicit fma() fuses.
@@ -127,8 +130,14 @@ __device__ __forceinline__ bool pixel_of(float a0, float a1, float a2, int W, in
     return pixel_from_quotients(a0 / a2, a1 / a2, W, (float)W - 0.5f, (float)H - 0.5f, pix);
 }
 
-__device__ __forceinline__ float row_sum(double p01, double p2, double p3) {
-    return (float)((p01 + p2) + p3);
+// One row of M * world from its four exact fp64 products (p0: the y term, p1: the x term,
+// p2: the z term of Model::toWord's swapped coordinates, p3 = M[r][3]).
+__device__ __forceinline__ float row_sum(double p0, double p1, double p2, double p3) {
+#ifdef ARVX_ASSOC_LEFT
+    return (float)(((p0 + p1) + p2) + p3);
+#else
+    return (float)(p0 + ((p1 + p2) + p3));
+#endif
 }
 
 }  // namespace arvx

@@ -388,15 +388,17 @@ __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p
             const int view = __builtin_amdgcn_readfirstlane(vc + b);
             const float *__restrict__ Mv = p.M + 12 * view;
             const uint32_t *__restrict__ bgv = p.bg + (size_t)view * p.bgWords;
-            double p01[3][4], p3[3], m2[3];
+            // (row-wise lane map: 4 x, one y, 4 z per lane.  The products are hoisted; the
+            // sums follow row_sum's grouping, which the compiler hoists where it can)
+            double p0[3], p1[3][4], p3[3], m2[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const double p0 = (double)Mv[4 * r] * dwy;
+                p0[r] = (double)Mv[4 * r] * dwy;
                 const double m1 = (double)Mv[4 * r + 1];
                 m2[r] = (double)Mv[4 * r + 2];
                 p3[r] = (double)Mv[4 * r + 3];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) p01[r][j] = p0 + m1 * dwx[j];
+                for (int j = 0; j < 4; ++j) p1[r][j] = m1 * dwx[j];
             }
             const bool fast = (fastdiv >> b) & 1ull;  // wave-uniform
             const float wlim = (float)p.W - 0.5f, hlim = (float)p.H - 0.5f;
@@ -423,9 +425,9 @@ __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p
                 bool in[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float a0 = row_sum(p01[0][j], p20, p3[0]);
-                    const float a1 = row_sum(p01[1][j], p21, p3[1]);
-                    const float a2 = row_sum(p01[2][j], p22, p3[2]);
+                    const float a0 = row_sum(p0[0], p1[0][j], p20, p3[0]);
+                    const float a1 = row_sum(p0[1], p1[1][j], p21, p3[1]);
+                    const float a2 = row_sum(p0[2], p1[2][j], p22, p3[2]);
                     float u, v;
                     if (fast) {
                         divide2_shared_rcp(a0, a1, a2, u, v);
@@ -706,15 +708,15 @@ __device__ __forceinline__ bool exact_view(const CarveParams &p, const int view,
                                            const int lane) {
     const float *__restrict__ Mv = p.M + 12 * view;
     const uint32_t *__restrict__ bgv = p.bg + (size_t)view * p.bgWords;
-    double p01[3][4], p3[3], m2[3];
+    double p0[3], p1[3][4], p3[3], m2[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        const double p0 = (double)Mv[4 * r] * dwy;
+        p0[r] = (double)Mv[4 * r] * dwy;
         const double m1 = (double)Mv[4 * r + 1];
         m2[r] = (double)Mv[4 * r + 2];
         p3[r] = (double)Mv[4 * r + 3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) p01[r][j] = p0 + m1 * dwx[j];
+        for (int j = 0; j < 4; ++j) p1[r][j] = m1 * dwx[j];
     }
     const float wlim = (float)p.W - 0.5f, hlim = (float)p.H - 0.5f;
     bool saw_bg = false, saw_other = false;  // ARVX_CARVE_STATS only
@@ -739,9 +741,9 @@ __device__ __forceinline__ bool exact_view(const CarveParams &p, const int view,
         bool in[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float a0 = row_sum(p01[0][j], p20, p3[0]);
-            const float a1 = row_sum(p01[1][j], p21, p3[1]);
-            const float a2 = row_sum(p01[2][j], p22, p3[2]);
+            const float a0 = row_sum(p0[0], p1[0][j], p20, p3[0]);
+            const float a1 = row_sum(p0[1], p1[1][j], p21, p3[1]);
+            const float a2 = row_sum(p0[2], p1[2][j], p22, p3[2]);
             float u, v;
             if (fast) {
                 divide2_shared_rcp(a0, a1, a2, u, v);
@@ -1001,27 +1003,74 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
     int pix[4][4];
     bool in[4][4];
 #pragma unroll
-    for (int byi = 0; byi < 2; ++byi) {
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int bzi = 0; bzi < 2; ++bzi)
+        for (int j = 0; j < 4; ++j) {
+            in[m][j] = false;
+            pix[m][j] = zero_pix;
+        }
+    auto project = [&](const int m, const int j, const double s0, const double s1,
+                       const double s2) {
+        const float a0 = (float)s0, a1 = (float)s1, a2 = (float)s2;
+        float u, v;
+        if (fast) {
+            divide2_shared_rcp(a0, a1, a2, u, v);
+        } else {
+            u = a0 / a2;
+            v = a1 / a2;
+        }
+        in[m][j] = pixel_from_quotients(u, v, p.W, wlim, hlim, pix[m][j], zero_pix);
+    };
+#ifndef ARVX_ASSOC_LEFT
+    // a_r = p0[y] + ((p1[x] + p2[z]) + p3) (row_sum): the inner sum q depends on x and z
+    // only, so it is formed once per (x, z) of the lane -- 4 x 2 values per row -- and a voxel
+    // costs ONE fp64 add per row.  p1 is an exact product, so fma(m1, wx, p2) IS
+    // round(p1 + p2).
+    double p0[2][3];
+#pragma unroll
+    for (int byi = 0; byi < 2; ++byi)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) p0[byi][r] = (double)mf[r][0] * (double)wy[byi];
+#pragma unroll
+    for (int bzi = 0; bzi < 2; ++bzi) {
+        if (!__any(st[bzi] != kDone4 || st[2 + bzi] != kDone4)) continue;
+        double q[3][4];
+        {
+            const double dwz = (double)wz[bzi];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double p2 = (double)mf[r][2] * dwz;
+                const double m1 = (double)mf[r][1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[r][j] = fma(m1, (double)wx[j], p2) + p3[r];
+            }
+        }
+#pragma unroll
+        for (int byi = 0; byi < 2; ++byi) {
+            const int m = 2 * byi + bzi;
+            const uint32_t w = st[m];
+            if (!__any(w != kDone4)) continue;  // these four blocks are finished
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                in[2 * byi + bzi][j] = false;
-                pix[2 * byi + bzi][j] = zero_pix;
+                if (!__any(((w >> (8 * j)) & 0xffu) != 2u)) continue;  // block j is finished
+                project(m, j, p0[byi][0] + q[0][j], p0[byi][1] + q[1][j], p0[byi][2] + q[2][j]);
             }
+        }
+    }
+#else
+    // a_r = ((p0[y] + p1[x]) + p2[z]) + p3: the inner sum depends on y and x
+#pragma unroll
+    for (int byi = 0; byi < 2; ++byi) {
         if (!__any(st[2 * byi] != kDone4 || st[2 * byi + 1] != kDone4)) continue;
         double p01[3][4];
         {
             const double dwy = (double)wy[byi];
-            double dwx[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dwx[j] = (double)wx[j];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const double p0 = (double)mf[r][0] * dwy;
                 const double m1 = (double)mf[r][1];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) p01[r][j] = p0 + m1 * dwx[j];
+                for (int j = 0; j < 4; ++j) p01[r][j] = fma(m1, (double)wx[j], p0);
             }
         }
 #pragma unroll
@@ -1035,20 +1084,12 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (!__any(((w >> (8 * j)) & 0xffu) != 2u)) continue;  // block j is finished
-                const float a0 = row_sum(p01[0][j], p20, p3[0]);
-                const float a1 = row_sum(p01[1][j], p21, p3[1]);
-                const float a2 = row_sum(p01[2][j], p22, p3[2]);
-                float u, v;
-                if (fast) {
-                    divide2_shared_rcp(a0, a1, a2, u, v);
-                } else {
-                    u = a0 / a2;
-                    v = a1 / a2;
-                }
-                in[m][j] = pixel_from_quotients(u, v, p.W, wlim, hlim, pix[m][j], zero_pix);
+                project(m, j, (p01[0][j] + p20) + p3[0], (p01[1][j] + p21) + p3[1],
+                        (p01[2][j] + p22) + p3[2]);
             }
         }
     }
+#endif
     uint32_t word[4][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void color_vote_kernel(const VoteParams p) {
             const double p1 = (double)Mv[4 * r + 1] * d1w;
             const double p2 = (double)Mv[4 * r + 2] * d2w;
             const double p3 = (double)Mv[4 * r + 3];
-            a[r] = row_sum(p0 + p1, p2, p3);
+            a[r] = row_sum(p0, p1, p2, p3);
         }
         int pix;
         if (!pixel_of(a[0], a[1], a[2], p.W, p.H, pix)) continue;  // ColorReconstruction.h:54-57

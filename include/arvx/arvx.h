@@ -68,6 +68,12 @@ typedef struct arvx_stats {
 int arvx_version(void);
 const char *arvx_last_error(void);
 int arvx_device_count(int *count);
+/* How this build sums the four products of a row of M * world (the cv::gemm call behind
+ * `intr * pose * world`, reference src/VoxelCarving.cpp:19): 0 = p0 + ((p1 + p2) + p3)
+ * -- the default, OpenCV's 4-way unrolled `s0 += s1 + s2 + s3` --, 1 = ((p0 + p1) + p2) + p3
+ * (built with -DARVX_ASSOC_LEFT as libarvx_assoc_left.so, for a host whose OpenCV sums that
+ * way; the two differ by double rounding in about one voxel-view in 1e8). */
+int arvx_projection_assoc(void);
 
 /* ---- context --------------------------------------------------------- */
 

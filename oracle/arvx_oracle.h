@@ -38,6 +38,9 @@ void arvx_oracle_compose(const float K[9], const float Rt[12], float M[12]);
 int arvx_oracle_project(const float M[12], float s, int x, int y, int z,
                         int W, int H, int *px, int *py);
 
+/* 0: M*world summed as p0+((p1+p2)+p3) (default); 1: ((p0+p1)+p2)+p3. */
+int arvx_oracle_assoc(void);
+
 /* Raw projection, no rounding: out[0..2] = proj (f32), out[3]=u, out[4]=v. */
 void arvx_oracle_project_raw(const float M[12], float s, int x, int y, int z,
                              float out[5]);

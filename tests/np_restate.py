@@ -15,14 +15,16 @@ def to_word(s, x, y, z):
     return wx, wy, wz
 
 
-def project_raw(M, s, x, y, z):
+def project_raw(M, s, x, y, z, assoc_left=False):
     """proj = M * world via the cv::gemm generic path: exact f64 products, summed
-    ((p0+p1)+p2)+p3, rounded to f32; then the two f32 divides."""
+    p0+((p1+p2)+p3) (`s0 += s1 + s2 + s3`; assoc_left: ((p0+p1)+p2)+p3),
+    rounded to f32; then the two f32 divides."""
     M = np.asarray(M, F32).reshape(3, 4).astype(F64)
     w0, w1, w2 = (a.astype(F64) for a in to_word(s, x, y, z))
     a = []
     for r in range(3):
-        acc = ((M[r, 0] * w0 + M[r, 1] * w1) + M[r, 2] * w2) + M[r, 3] * 1.0
+        p0, p1, p2, p3 = M[r, 0] * w0, M[r, 1] * w1, M[r, 2] * w2, M[r, 3] * 1.0
+        acc = ((p0 + p1) + p2) + p3 if assoc_left else p0 + ((p1 + p2) + p3)
         a.append(acc.astype(F32))
     with np.errstate(divide="ignore", invalid="ignore"):
         u = (a[0] / a[2]).astype(F32)
