@@ -5,8 +5,12 @@
 
 One step = one pass of the hot path over one synthetic batch: a fresh model
 (all voxels occupied) is carved by all V silhouette views (sphere
-of radius 0.35E, ring cameras, 640x480 masks).  Masks, matrices and the state
-plane are resident in HBM before the timed region starts.
+of radius 0.35E, ring cameras, 640x480 masks).  The u8 masks and the state plane are
+resident in HBM before the timed region starts; everything DERIVED from the masks --
+the 1-bit background planes and the summed-area tables the carve kernels read -- is
+rebuilt inside every timed step (arvx_set_views_device), then arvx_carve runs.
+`value` / `ms_per_step` are that whole step; `carve_kernel_ms` is the carve alone and
+`views_kernel_ms` the derivation, both by HIP events on the launch stream.
 
 metric  Mvoxel-views/s = voxels x views / carve time  (BASELINE.json)
 N = 1   512^3 grid x 36 views (the configuration the metric is quoted on)
@@ -82,13 +86,13 @@ def cpu_baseline(sc, X, Y, Z, budget_s=12.0):
     out["cpu_model"] = model
     mt_planes = int(min(Z, max(8, planes * min(ncores, 32) // 4)))
     t0 = time.perf_counter()
-    pyoracle.carve(X, Y, mt_planes, sc.voxel_size, sc.M, sc.masks, threads=ncores)
+    plane = pyoracle.carve(X, Y, mt_planes, sc.voxel_size, sc.M, sc.masks, threads=ncores)
     dmt = time.perf_counter() - t0
     out["all_cores"] = {"value": X * Y * mt_planes * sc.V / dmt / 1e6,
                         "unit": "Mvoxel-views/s", "cores": ncores, "kind": "port",
                         "sample": f"x-fastest OpenMP oracle, planes z=0..{mt_planes - 1} "
                                   f"({dmt:.1f} s)"}
-    return out
+    return out, plane  # plane: the oracle's state of planes z = 0..mt_planes-1
 
 
 def main():
@@ -171,7 +175,7 @@ def main():
         if world > 1 and collective != "none":
             ex = sharding.OccupancyExchange(X, Y, Z, world, rank, dev, mode=collective, buffers=2,
                                             layout=layout, codec=ctx)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
               for _ in range(steps)]
         nstep = [0]
         merge_ok = [None]
@@ -183,9 +187,13 @@ def main():
             ctx.reset()
             if i is not None:
                 ev[i][0].record(stream)
-            ctx.carve(flags)
+            # masks are the resident input; bit planes + summed-area tables are derived
+            ctx.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
             if i is not None:
                 ev[i][1].record(stream)
+            ctx.carve(flags)
+            if i is not None:
+                ev[i][2].record(stream)
             if ex is not None:
                 b = nstep[0] % 2
                 ex.prepare(b, verify=False)  # compressed: overflow is checked after drain()
@@ -224,7 +232,8 @@ def main():
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        views_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))
+        kern_ms = float(np.mean([b.elapsed_time(c) for _, b, c in ev]))
         occ = None
         overflowed = bool(ex is not None and ex.overflowed())
         st = ctx.download_state() if (rank == 0 or ex is not None) else None
@@ -250,7 +259,8 @@ def main():
         if ex is not None:  # bytes each rank contributes to the collective
             xbytes = ((ex.header + packet_cap) * 8 if collective == "compressed"
                       else ex.total_words * 4 if collective == "allreduce" else ex.my_words * 4)
-        return dict(X=X, Y=Y, Z=Z, V=V, dt=dt, kern_ms=kern_ms, sc=sc, occ=occ,
+        return dict(X=X, Y=Y, Z=Z, V=V, dt=dt, kern_ms=kern_ms, views_ms=views_ms, sc=sc, occ=occ,
+                    state=st if (world == 1 and rank == 0) else None,
                     nplanes=nplanes, layout=layout, nvox=nvox_global, merge_ok=merge_ok[0],
                     overflowed=overflowed, exchange_bytes_per_rank=xbytes)
 
@@ -276,35 +286,48 @@ def main():
     value = vv * args.steps / r["dt"] / 1e6
     ms_per_step = r["dt"] / args.steps * 1e3
 
-    # roofline of the carve kernel: SURVEY 8(d) algorithmic bytes, HBM-read side:
+    # roofline of the carve kernels: SURVEY 8(d) algorithmic bytes, HBM-read side:
     # N*V (one state byte per voxel-view) + V*W*H (one mask byte per pixel), for the
     # voxels THIS rank's launch processes.
     nv_rank = r["X"] * r["Y"] * r["nplanes"]
     alg_bytes = nv_rank * r["V"] + r["V"] * r["sc"].W * r["sc"].H
     achieved = alg_bytes / (r["kern_ms"] * 1e-3) / 1e9
-    traffic = None
+    traffic = traffic_step = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and world == 1:
         try:
             tj = json.load(open(tpath))
             key = f"{r['X']}x{r['Y']}x{r['Z']}x{r['V']}" + ("_nocull" if args.no_cull else "")
-            traffic = tj.get(key, {}).get("bytes_per_launch") if world == 1 else None
+            traffic = tj.get(key, {}).get("bytes_per_launch")
+            traffic_step = tj.get(key, {}).get("bytes_per_step")
         except Exception:
             traffic = None
+    phys = (traffic / (r["kern_ms"] * 1e-3) / 1e9) if traffic else None
+    step_kernel_ms = r["kern_ms"] + r["views_ms"]
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "physical_GBps": (traffic / (r["kern_ms"] * 1e-3) / 1e9) if traffic else None,
+                "frac_is": "effective (algorithmic bytes of the per-view streaming formulation / "
+                           "time); see physical_frac for what the chip moves",
+                "physical_GBps": phys,
+                "physical_frac": (phys / HBM_PEAK_GBS) if phys else None,
                 "kernel": "carve_coarse_kernel + carve_classify_kernel + carve_exact_blocks_kernel "
                           "(one arvx_carve call)",
                 "kernel_ms": r["kern_ms"],
                 "algorithmic_bytes": alg_bytes,
+                "step": {"kernels": "mask_to_bits + sat_rows + sat_cols (arvx_set_views_device) "
+                                    "+ the three carve kernels",
+                         "kernel_ms": step_kernel_ms,
+                         "effective_frac": alg_bytes / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic_step,
+                         "physical_frac": (traffic_step / (step_kernel_ms * 1e-3) / 1e9 /
+                                           HBM_PEAK_GBS) if traffic_step else None},
                 "note": "algorithmic = N*V + V*W*H read bytes of the per-view streaming "
                         "formulation (SURVEY 8d); the kernels read the state at most once and "
-                        "decide most 16x8x8 sub-tiles from a pixel-rectangle test, so this "
-                        "is an EFFECTIVE rate and may exceed the physical peak; `traffic` "
+                        "decide most 16x8x8 sub-tiles from a pixel-rectangle test, so `frac` "
+                        "is an EFFECTIVE rate and exceeds the physical peak; `traffic` "
                         "is the rocprofv3 PMC FETCH_SIZE+WRITE_SIZE byte count per launch (profiles/"
-                        "traffic.json), `physical_GBps` = traffic / kernel time: the kernel is "
-                        "bound by VALU issue and L2/Infinity-Cache latency, not by HBM"}
+                        "traffic.json) and `physical_frac` = traffic / kernel time / peak: the "
+                        "kernels are bound by VALU issue and L2/Infinity-Cache latency, not HBM"}
 
     out = {
         "metric": "Mvoxel-views/s (voxels x views / s) + carve wall-time, 512^3 grid x 36 views",
@@ -312,16 +335,35 @@ def main():
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"synthetic sphere silhouettes, {r['X']}x{r['Y']}x{r['Z']} grid, "
-                               f"{r['V']} views 640x480, dense carve, all views in one arvx_carve call",
+                               f"{r['V']} views 640x480, per step: derive bit planes + summed-area "
+                               f"tables from the resident u8 masks, then dense carve of a fresh "
+                               f"model by all views",
                    "grid": [r["X"], r["Y"], r["Z"]], "views": r["V"],
                    "parallelism": f"z-slab x{world} ({r['layout']})" if world > 1 else "single GPU",
                    "collective": args.collective if world > 1 else "none",
                    "merged_plane_holds_rank0_planes": r["merge_ok"],
                    "exchange_bytes_per_rank": r["exchange_bytes_per_rank"],
                    "cull": not args.no_cull},
-        "carve_kernel_ms": r["kern_ms"], "occupied_fraction": r["occ"],
+        "carve_kernel_ms": r["kern_ms"], "views_kernel_ms": r["views_ms"],
+        "carve_only_value": vv / (r["kern_ms"] * 1e-3) / 1e6,
+        "occupied_fraction": r["occ"],
         "roofline": roofline,
     }
+
+    if world == 8 and (args.grid, args.views) == (512, 36):
+        # BASELINE config 4 as it is written: 1024^3 x 72 views over the 8 GPUs
+        try:
+            k = max(3, args.steps // 2)
+            c4 = run_config(512, 72, k, 2, args.collective)
+            if rank == 0:
+                out["c4_1024x72"] = {
+                    "workload": f"{c4['X']}x{c4['Y']}x{c4['Z']} x 72 views, 8 GPUs",
+                    "value": c4["nvox"] * 72 / (c4["dt"] / k) / 1e6, "unit": "Mvoxel-views/s",
+                    "ms_per_step": c4["dt"] / k * 1e3, "carve_kernel_ms": c4["kern_ms"],
+                    "views_kernel_ms": c4["views_ms"], "merge_ok": c4["merge_ok"]}
+        except Exception as ex:  # noqa: BLE001
+            if rank == 0:
+                out["c4_1024x72"] = {"error": str(ex)}
 
     if rank == 0 and world == 1 and args.extra_grid and args.extra_grid != args.grid:
         try:
@@ -333,6 +375,7 @@ def main():
                 "workload": f"{e['X']}^3 x {e['V']} views (north-star target config)",
                 "value": evv / (e["dt"] / k) / 1e6,
                 "unit": "Mvoxel-views/s", "carve_kernel_ms": e["kern_ms"],
+                "views_kernel_ms": e["views_ms"], "ms_per_step": e["dt"] / k * 1e3,
                 "roofline_frac": eb / (e["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "occupied_fraction": e["occ"]}
         except Exception as ex:  # e.g. not enough memory on a shared box
@@ -357,9 +400,18 @@ def main():
             out["ablation_no_cull"] = {"error": str(ex)}
 
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(r["sc"], r["X"], r["Y"], r["Z"])
+        out["cpu_baseline"], oracle_plane = cpu_baseline(r["sc"], r["X"], r["Y"], r["Z"])
+        # the state the timed steps left on the GPU against the oracle's, voxel for voxel
+        nz = oracle_plane.shape[0]
+        same = bool(np.array_equal(r["state"][:nz], oracle_plane))
+        out["parity_vs_oracle"] = same
+        out["parity_planes"] = f"z=0..{nz - 1} of {r['Z']}"
+        if not same:
+            print("[bench] GPU state differs from the oracle in "
+                  f"{int((r['state'][:nz] != oracle_plane).sum())} voxels", file=sys.stderr)
     elif rank == 0:
         out["cpu_baseline"] = None
+        out["parity_vs_oracle"] = None
 
     if rank == 0:
         print(json.dumps(out))

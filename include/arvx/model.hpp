@@ -169,6 +169,15 @@ class Model {
         for (auto &b : s) b &= (uint8_t)(kOcc | kSeen);
         return s;
     }
+    // one byte per voxel, 1 where marching cubes counts the voxel as inside (w >= threshold,
+    // the complement of src/MarchingCubes.h:481): the occupancy the cell walk runs on
+    std::vector<uint8_t> inside_state(float threshold) const {
+        std::vector<uint8_t> s(state_.size());
+        const uint8_t one = (1.0f >= threshold) ? kOcc : 0;  // MODEL / UNSEEN colour: w = 1
+        for (size_t i = 0; i < s.size(); ++i) s[i] = (state_[i] & kOcc) ? one : 0;
+        for (const auto &kv : colors_) s[(size_t)kv.first] = (kv.second.w() >= threshold) ? kOcc : 0;
+        return s;
+    }
     // take the carve result back: occupancy and seen from the device plane.  The
     // device plane started from this model's bits, so it already holds them; a
     // voxel that is still occupied keeps its UNSEEN paint bit, a carved one loses

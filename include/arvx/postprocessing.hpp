@@ -19,6 +19,7 @@ inline int applyClosure(Model *model, int kernelSize) {
         std::cerr << "Invalid kernel size for post processing, skipping..." << std::endl;
         return -1;
     }
+    detail::timing(kStagePostProcessing, true);
     arvx_ctx *ctx = nullptr;
     detail::check(arvx_ctx_create(&ctx, 0, model->getX(), model->getY(), model->getZ(),
                                   model->getSize()),
@@ -52,6 +53,7 @@ inline int applyClosure(Model *model, int kernelSize) {
     for (int64_t k = 0; k < n; ++k)
         model->set_flat((int)fidx[k], Vec4f(frgba[4 * k], frgba[4 * k + 1], frgba[4 * k + 2],
                                             frgba[4 * k + 3]));
+    detail::timing(kStagePostProcessing, false);
     std::cout << "LOG - PP: postprocessing completed." << std::endl;
     return 0;
 }

@@ -55,10 +55,33 @@ class Error : public std::runtime_error {
 };
 
 // called after each view when intermediateMeshes is set (the reference writes
-// out/intermediate/image_<i>_mesh.off there, src/VoxelCarving.cpp:65-68)
+// out/intermediate/image_<i>_mesh.off there, src/VoxelCarving.cpp:65-68); without a hook
+// carve() does what the reference does (include/arvx/marching_cubes.hpp is needed for that:
+// it installs the default)
 using IntermediateHook = std::function<void(int view, Model &model)>;
 
+// Timing sink: the reference brackets its stages with Benchmark::GetInstance().LogCarving(true/
+// false) etc. (src/VoxelCarving.cpp:62,70,76,165; src/ColorReconstruction.cpp:24,44,50,68;
+// src/Postprocessing3d.cpp; src/MarchingCubes.cpp:10,19).  The same brackets are reported here
+// to a callback instead of a singleton: sink(stage, start).  include/arvx/benchmark.hpp is a
+// sink that prints the reference's table.
+enum Stage { kStageCarving = 0, kStageColoring, kStagePostProcessing, kStageMarchingCubes };
+using TimingSink = std::function<void(Stage stage, bool start)>;
+inline TimingSink &timingSink() {
+    static TimingSink sink;
+    return sink;
+}
+inline void setTimingSink(TimingSink sink) { timingSink() = std::move(sink); }
+
 namespace detail {
+
+inline void timing(Stage stage, bool start) {
+    if (timingSink()) timingSink()(stage, start);
+}
+inline IntermediateHook &defaultIntermediateHook() {
+    static IntermediateHook hook;
+    return hook;
+}
 
 inline void check(int rc, const char *what) {
     if (rc != ARVX_OK) {
@@ -162,7 +185,9 @@ class Session {
 inline void carve(const Intrinsics &intr, Model &model, const std::vector<View> &views,
                   bool intermediateMeshes = false, const IntermediateHook &hook = nullptr) {
     std::cout << "LOG - VC: starting carving process (version 1)." << std::endl;
+    detail::timing(kStageCarving, true);
     detail::Session s(intr, model, views);
+    const IntermediateHook &each = hook ? hook : detail::defaultIntermediateHook();
     if (!intermediateMeshes) {
         detail::check(arvx_carve(s.ctx(), 0), "arvx_carve");
         s.pull_state();
@@ -171,39 +196,46 @@ inline void carve(const Intrinsics &intr, Model &model, const std::vector<View> 
             detail::check(arvx_carve_views(s.ctx(), i, 1, 0), "arvx_carve_views");
             s.pull_state();
             std::cout << "LOG - VC: completed carving of a single image." << std::endl;
-            if (hook) {
+            if (each) {
                 std::cout << "LOG - VC: generating intermediate mesh for image " << i << std::endl;
-                hook(i, model);
+                each(i, model);
             }
         }
     }
+    detail::timing(kStageCarving, false);
     std::cout << "LOG - VC: carving complete." << std::endl;
 }
 
 // reference fastCarve(): greedy flood from voxel (0,0,0).
 inline void fastCarve(const Intrinsics &intr, Model &model, const std::vector<View> &views) {
     std::cout << "LOG - VC: starting carving process (version 2)." << std::endl;
+    detail::timing(kStageCarving, true);
     detail::Session s(intr, model, views);
     detail::check(arvx_fast_carve(s.ctx()), "arvx_fast_carve");
     s.pull_state();
+    detail::timing(kStageCarving, false);
     std::cout << "LOG - VC: carving complete." << std::endl;
 }
 
 inline void reconstructClosestColor(const Intrinsics &intr, Model &model,
                                     const std::vector<View> &views) {
     std::cout << "LOG - CR: starting color reconstruction (closest color)." << std::endl;
+    detail::timing(kStageColoring, true);
     detail::Session s(intr, model, views);
     s.set_images(views);
     s.color(ARVX_COLOR_CLOSEST);
+    detail::timing(kStageColoring, false);
     std::cout << "LOG - CR: color reconstruction finished." << std::endl;
 }
 
 inline void reconstructAvgColor(const Intrinsics &intr, Model &model,
                                 const std::vector<View> &views) {
     std::cout << "LOG - CR: starting color reconstruction (average color)." << std::endl;
+    detail::timing(kStageColoring, true);
     detail::Session s(intr, model, views);
     s.set_images(views);
     s.color(ARVX_COLOR_AVERAGE);
+    detail::timing(kStageColoring, false);
     std::cout << "LOG - CR: color reconstruction finished." << std::endl;
 }
 

@@ -208,6 +208,34 @@ void arvx_oracle_carve_mt(int X, int Y, int Z, float s, int V, const float *M,
             }
 }
 
+/* The same carve on a list of z planes only (a Z slab or the striped planes of one rank of
+ * the multi-GPU split): state holds plane zlist[k] at k*X*Y.  src/VoxelCarving.cpp:38-55. */
+void arvx_oracle_carve_planes_mt(int X, int Y, float s, int V, const float *M,
+                                 const uint8_t *masks, int W, int H, int C, long stride,
+                                 const int32_t *zlist, int nz, uint8_t *state, int threads) {
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < nz; ++k)
+        for (int y = 0; y < Y; ++y)
+            for (int x = 0; x < X; ++x) {
+                const int z = zlist[k];
+                long i = flatten(X, Y, x, y, k);
+                uint8_t st = state[i];
+                for (int v = 0; v < V; ++v) {
+                    int px, py;
+                    if (!arvx_oracle_project(M + 12 * v, s, x, y, z, W, H, &px, &py)) continue;
+                    if (mask_is_background(masks + (long)v * H * stride, C, stride, px, py))
+                        st &= (uint8_t)~ARVX_ORACLE_OCC;
+                    st |= ARVX_ORACLE_SEEN;
+                }
+                state[i] = st;
+            }
+}
+
 /* Reference-shaped CPU baseline (timing only): src/VoxelCarving.cpp:23-58
  * with its per-voxel `intr * pose * world`, AoS Vector4f voxels
  * (src/Model.h:100) and bit-packed seen (std::vector<bool>, :102).
@@ -492,6 +520,104 @@ long arvx_oracle_mc_cells(int X, int Y, int Z, const float *rgba, float threshol
                     cells[4 * n + 3] = idx;
                 }
                 n++;
+            }
+    return n;
+}
+
+/* ---- marching cubes: src/MarchingCubes.cpp:8-31, src/MarchingCubes.h:414-578 ------------
+ * Triangle table: Paul Bourke's (public domain), shared as data with the product
+ * (include/arvx/mc_triangles.inc; the reference's copy: src/MarchingCubes.h:147-405).  The
+ * edge table (:112-145) is not stored: an edge is cut iff its two corners differ. */
+static const char *const MC_TRIANGLES[256] = {
+#include "../include/arvx/mc_triangles.inc"
+};
+static const int MC_SECOND[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7}; /* :491 */
+
+static int rgb_is_default(const float c[3]) { /* :454,458 MODEL_COLOR / UNSEEN_COLOR */
+    return (c[0] == MODEL_COLOR[0] && c[1] == MODEL_COLOR[1] && c[2] == MODEL_COLOR[2]) ||
+           (c[0] == UNSEEN_COLOR[0] && c[1] == UNSEEN_COLOR[1] && c[2] == UNSEEN_COLOR[2]);
+}
+
+/* VertexInterp, :428-468 */
+static void vertex_interp(float threshold, const float p0[3], const float v0[4],
+                          const float p1[3], const float v1[4], float coord[3],
+                          float color[3]) {
+    if (v0[3] == 0.0f && v1[3] != 0.0f) { /* :432-436 */
+        memcpy(color, v1, 12);
+        memcpy(coord, p1, 12);
+        return;
+    }
+    if (v0[3] != 0.0f && v1[3] == 0.0f) { /* :437-441 */
+        memcpy(color, v0, 12);
+        memcpy(coord, p0, 12);
+        return;
+    }
+    float f;
+    if (v0[3] == v1[3]) f = 0.5f;
+    else f = (threshold - v0[3]) / (v1[3] - v0[3]); /* :443-449 */
+    const float g = 1 - f;
+    for (int k = 0; k < 3; ++k) coord[k] = g * p0[k] + f * p1[k]; /* :450 (-ffp-contract=off) */
+    if (rgb_is_default(v0)) memcpy(color, v1, 12);                 /* :454-457 */
+    else if (rgb_is_default(v1)) memcpy(color, v0, 12);            /* :458-461 */
+    else
+        for (int k = 0; k < 3; ++k) color[k] = g * v0[k] + f * v1[k]; /* :464 */
+}
+
+static uint32_t mean_color_floats(float c1, float c2, float c3) { /* :414-416 */
+    return (uint32_t)roundf((c1 + c2 + c3) / 3);
+}
+
+static int hexv(char c) { return c <= '9' ? c - '0' : c - 'a' + 10; }
+
+/* The mesh marchingCubes() builds before it scales and writes it: 3 fresh vertices per
+ * triangle (:561-568), vertex coordinates in voxel units; faces = (r, g, b) per triangle
+ * (the vertex ids of triangle t are 3t, 3t+1, 3t+2).  Returns the number of triangles,
+ * writes at most cap of them. */
+long arvx_oracle_mc_mesh(int X, int Y, int Z, const float *rgba, float threshold,
+                         float *verts, uint32_t *face_rgb, long cap) {
+    static const int corner[8][3] = {{1, 0, 0}, {0, 0, 0}, {0, 1, 0}, {1, 1, 0},
+                                     {1, 0, 1}, {0, 0, 1}, {0, 1, 1}, {1, 1, 1}}; /* :537-552 */
+    static const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
+    long n = 0;
+    for (int x = -1; x < X; x++)        /* src/MarchingCubes.cpp:12-18 */
+        for (int y = -1; y < Y; y++)
+            for (int z = -1; z < Z; z++) {
+                const float *val[8];
+                float p[8][3];
+                int idx = 0;
+                for (int i = 0; i < 8; i++) {
+                    const int cx = x + corner[i][0], cy = y + corner[i][1],
+                              cz = z + corner[i][2];
+                    val[i] = (cx < 0 || cx >= X || cy < 0 || cy >= Y || cz < 0 || cz >= Z)
+                                 ? zero4 /* Model::get, src/Model.h:119-124 */
+                                 : rgba + 4 * flatten(X, Y, cx, cy, cz);
+                    p[i][0] = (float)cx;
+                    p[i][1] = (float)cy;
+                    p[i][2] = (float)cz;
+                    if (val[i][3] < threshold) idx |= 1 << i; /* :479-484 */
+                }
+                int edges = 0;
+                for (int e = 0; e < 12; e++)
+                    if (((idx >> (e % 8)) & 1) != ((idx >> MC_SECOND[e]) & 1)) edges |= 1 << e;
+                if (edges == 0) continue; /* :486-488 */
+                float coord[12][3], color[12][3];
+                for (int e = 0; e < 12; e++) /* :493-497 */
+                    if (edges & (1 << e))
+                        vertex_interp(threshold, p[e % 8], val[e % 8], p[MC_SECOND[e]],
+                                      val[MC_SECOND[e]], coord[e], color[e]);
+                for (const char *t = MC_TRIANGLES[idx]; t[0]; t += 3) { /* :500-509 */
+                    const int e0 = hexv(t[0]), e1 = hexv(t[1]), e2 = hexv(t[2]);
+                    if (n < cap) {
+                        memcpy(verts + 9 * n, coord[e0], 12);
+                        memcpy(verts + 9 * n + 3, coord[e1], 12);
+                        memcpy(verts + 9 * n + 6, coord[e2], 12);
+                        /* col[2] = vertList[triTable[..][i + 1]].color: :506 */
+                        const float *c0 = color[e0], *c1 = color[e1], *c2 = color[e1];
+                        for (int k = 0; k < 3; k++) /* :570-573 */
+                            face_rgb[3 * n + k] = mean_color_floats(c0[k], c1[k], c2[k]);
+                    }
+                    n++;
+                }
             }
     return n;
 }

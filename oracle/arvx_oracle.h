@@ -61,6 +61,11 @@ void arvx_oracle_carve_mt(int X, int Y, int Z, float s, int V, const float *M,
                           const uint8_t *masks, int W, int H, int C,
                           long stride, uint8_t *state, int threads);
 
+/* Same, but only the global z planes zlist[0..nz): state = nz planes of X*Y bytes. */
+void arvx_oracle_carve_planes_mt(int X, int Y, float s, int V, const float *M,
+                                 const uint8_t *masks, int W, int H, int C, long stride,
+                                 const int32_t *zlist, int nz, uint8_t *state, int threads);
+
 /* Reference-shaped dense carve used only as the timed CPU baseline:
  * AoS RGBA float voxels, bit-packed seen, x->y->z loop order, M recomputed
  * per voxel from K and Rt as the reference does.  zlo/zhi restrict the z
@@ -102,6 +107,12 @@ void arvx_oracle_closure(int X, int Y, int Z, float *rgba);
  * such cells; writes at most `cap` of them. */
 long arvx_oracle_mc_cells(int X, int Y, int Z, const float *rgba, float threshold,
                           int32_t *cells, long cap);
+
+/* The mesh marchingCubes() builds (before WriteMesh scales it): verts = 9 floats per
+ * triangle (three fresh vertices, voxel units), face_rgb = 3 per triangle.  Returns the
+ * number of triangles; writes at most `cap`. */
+long arvx_oracle_mc_mesh(int X, int Y, int Z, const float *rgba, float threshold,
+                         float *verts, uint32_t *face_rgb, long cap);
 
 #ifdef __cplusplus
 }

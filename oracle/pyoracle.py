@@ -111,6 +111,20 @@ def carve(X, Y, Z, s, M, masks, state=None, threads=0):
     return st
 
 
+def carve_planes(X, Y, s, M, masks, planes, state=None, threads=0):
+    """Dense carve of the global z planes `planes` only (a slab / one rank's stripes);
+    returns (len(planes), Y, X)."""
+    M = _f32(M).reshape(-1, 12)
+    m = _masks4(masks)
+    V, H, W, Cn = m.shape
+    zl = np.ascontiguousarray(planes, np.int32)
+    st = (np.full((len(zl), Y, X), OCC, np.uint8) if state is None
+          else _u8(state).copy().reshape(len(zl), Y, X))
+    lib().arvx_oracle_carve_planes_mt(X, Y, C.c_float(s), V, _p(M), _p(m), W, H, Cn,
+                                      C.c_long(W * Cn), _p(zl), len(zl), _p(st), int(threads))
+    return st
+
+
 def carve_view(X, Y, Z, s, M, mask, state):
     M = _f32(M).reshape(12)
     m = _u8(mask)
@@ -195,3 +209,30 @@ def mc_cells(X, Y, Z, rgba, threshold=0.5):
     out = np.zeros((max(n, 1), 4), np.int32)
     L.arvx_oracle_mc_cells(X, Y, Z, _p(r), C.c_float(threshold), _p(out), C.c_long(n))
     return out[:n]
+
+
+def mc_mesh(X, Y, Z, rgba, threshold=0.5):
+    """marchingCubes' mesh: (verts (3T, 3) float32 in voxel units, face_rgb (T, 3) uint32);
+    triangle t uses vertices 3t, 3t+1, 3t+2."""
+    r = _f32(rgba)
+    L = lib()
+    L.arvx_oracle_mc_mesh.restype = C.c_long
+    n = L.arvx_oracle_mc_mesh(X, Y, Z, _p(r), C.c_float(threshold), None, None, C.c_long(0))
+    verts = np.zeros((max(n, 1) * 3, 3), np.float32)
+    rgb = np.zeros((max(n, 1), 3), np.uint32)
+    L.arvx_oracle_mc_mesh(X, Y, Z, _p(r), C.c_float(threshold), _p(verts), _p(rgb), C.c_long(n))
+    return verts[:3 * n], rgb[:n]
+
+
+def off_text(verts, face_rgb, scale_factor=1.0, translation=(0.0, 0.0, 0.0)):
+    """SimpleMesh::WriteMesh (src/MarchingCubes.h:60-87): default ostream float format
+    (= printf %g, 6 significant digits) of vertex * scaleFactor + translation in fp32."""
+    v = np.asarray(verts, np.float32)
+    t = np.asarray(translation, np.float32)
+    out = (v * np.float32(scale_factor)).astype(np.float32) + t
+    n = len(face_rgb)
+    lines = ["OFF", f"{len(v)} {n} 0"]
+    lines += ["%g %g %g" % (float(a), float(b), float(c)) for a, b, c in out]
+    lines += ["3 %d %d %d %d %d %d" % (3 * i, 3 * i + 1, 3 * i + 2, r, g, b)
+              for i, (r, g, b) in enumerate(np.asarray(face_rgb).tolist())]
+    return "\n".join(lines) + "\n"

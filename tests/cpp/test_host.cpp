@@ -8,6 +8,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <string>
 #include <vector>
 
 #include "arvx/calibration.hpp"
@@ -162,6 +163,40 @@ static int run_carve(const char *scene, const char *out, const char *mode) {
     return 0;
 }
 
+// model file: int32 X,Y,Z ; float voxel size ; X*Y*Z * 4 floats (Model::voxels, x fastest).
+// Writes what the reference's marchingCubes(&model, scale, t, threshold, out) writes.
+static int run_mc(const char *model_path, const char *out_off, float scale, float tx, float ty,
+                  float tz, float threshold) {
+    std::ifstream f(model_path, std::ios::binary);
+    int32_t hd[3];
+    float size;
+    f.read((char *)hd, sizeof hd);
+    f.read((char *)&size, 4);
+    const int X = hd[0], Y = hd[1], Z = hd[2];
+    std::vector<float> rgba((size_t)X * Y * Z * 4);
+    f.read((char *)rgba.data(), (std::streamsize)(rgba.size() * 4));
+    if (!f) { std::fprintf(stderr, "short model file\n"); return 2; }
+    Model model(X, Y, Z, size);
+    for (int z = 0; z < Z; ++z)
+        for (int y = 0; y < Y; ++y)
+            for (int x = 0; x < X; ++x) {
+                const float *v = &rgba[4 * ((size_t)x + (size_t)X * (y + (size_t)Y * z))];
+                model.set(x, y, z, Vec4f(v[0], v[1], v[2], v[3]));
+            }
+    try {
+        if (!arvx::marchingCubes(&model, scale, arvx::Vec3f(tx, ty, tz), threshold, out_off))
+            return 7;
+        // an unwritable path: false, as in the reference (src/MarchingCubes.cpp:23-26)
+        if (arvx::marchingCubes(&model, scale, arvx::Vec3f(tx, ty, tz), threshold,
+                                "/nonexistent_dir/mesh.off"))
+            return 8;
+    } catch (const arvx::Error &e) {
+        std::fprintf(stderr, "arvx::Error %d: %s\n", e.code, e.what());
+        return 3;
+    }
+    return 0;
+}
+
 static int test_calibration(const char *path) {
     double K[9];
     std::vector<double> dist;
@@ -178,6 +213,9 @@ int main(int argc, char **argv) {
     if (argc >= 2 && !std::strcmp(argv[1], "model")) return test_model();
     if (argc == 3 && !std::strcmp(argv[1], "calibration")) return test_calibration(argv[2]);
     if (argc == 5 && !std::strcmp(argv[1], "carve")) return run_carve(argv[2], argv[3], argv[4]);
+    if (argc == 9 && !std::strcmp(argv[1], "mc"))
+        return run_mc(argv[2], argv[3], std::stof(argv[4]), std::stof(argv[5]), std::stof(argv[6]),
+                      std::stof(argv[7]), std::stof(argv[8]));
     std::fprintf(stderr, "usage: test_host model | test_host carve <scene> <out> <mode>\n");
     return 2;
 }

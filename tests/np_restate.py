@@ -143,3 +143,80 @@ def closure(X, Y, Z, rgba):
         mean = (ssum / cnt[..., None].astype(F32)).astype(F32)
     out = np.where(occ[..., None], a, np.where(cnt[..., None] > 0, mean, F32(0)))
     return out.reshape(-1, 4).astype(F32)
+
+
+# ---- marching cubes (src/MarchingCubes.cpp:8-31, src/MarchingCubes.h:414-578) ---------------
+
+_MC_SECOND = [1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7]
+_MC_CORNER = [(1, 0, 0), (0, 0, 0), (0, 1, 0), (1, 1, 0), (1, 0, 1), (0, 0, 1), (0, 1, 1), (1, 1, 1)]
+_MODEL_RGB, _UNSEEN_RGB = (50.0, 168.0, 141.0), (204.0, 0.0, 0.0)
+
+
+def mc_triangle_rows():
+    """Bourke's triangle table from the shared data file (include/arvx/mc_triangles.inc)."""
+    import os
+    import re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include",
+                        "arvx", "mc_triangles.inc")
+    src = open(path).read()
+    rows = re.findall(r'"([0-9a-b]*)"', src[src.index("*/"):])
+    assert len(rows) == 256
+    return [[int(c, 16) for c in r] for r in rows]
+
+
+def _vertex_interp(thr, p0, v0, p1, v1):
+    """VertexInterp, src/MarchingCubes.h:428-468, in float32 element ops."""
+    if v0[3] == 0 and v1[3] != 0:
+        return p1.copy(), v1[:3].copy()
+    if v0[3] != 0 and v1[3] == 0:
+        return p0.copy(), v0[:3].copy()
+    f = F32(0.5) if v0[3] == v1[3] else F32(F32(thr - v0[3]) / F32(v1[3] - v0[3]))
+    g = F32(F32(1) - f)
+    coord = (g * p0).astype(F32) + (f * p1).astype(F32)
+    c0, c1 = v0[:3], v1[:3]
+    if tuple(c0) in (_MODEL_RGB, _UNSEEN_RGB):
+        col = c1.copy()
+    elif tuple(c1) in (_MODEL_RGB, _UNSEEN_RGB):
+        col = c0.copy()
+    else:
+        col = (g * c0).astype(F32) + (f * c1).astype(F32)
+    return coord.astype(F32), col.astype(F32)
+
+
+def mc_mesh(X, Y, Z, rgba, threshold=0.5):
+    """-> (verts (3T,3) float32, face_rgb (T,3) int): the reference's cell walk, one Python
+    loop per cell -- small grids only."""
+    rows = mc_triangle_rows()
+    thr = F32(threshold)
+    vox = np.asarray(rgba, F32).reshape(Z, Y, X, 4)
+    zero = np.zeros(4, F32)
+
+    def get(x, y, z):  # Model::get: zero outside the grid
+        if x < 0 or x >= X or y < 0 or y >= Y or z < 0 or z >= Z:
+            return zero
+        return vox[z, y, x]
+
+    verts, faces = [], []
+    for x in range(-1, X):
+        for y in range(-1, Y):
+            for z in range(-1, Z):
+                val = [get(x + a, y + b, z + c) for a, b, c in _MC_CORNER]
+                idx = sum(1 << i for i in range(8) if val[i][3] < thr)
+                if idx in (0, 255):
+                    continue
+                pts = [np.array([x + a, y + b, z + c], F32) for a, b, c in _MC_CORNER]
+                vl = {}
+                for e in range(12):
+                    a, b = e % 8, _MC_SECOND[e]
+                    if ((idx >> a) & 1) != ((idx >> b) & 1):
+                        vl[e] = _vertex_interp(thr, pts[a], val[a], pts[b], val[b])
+                row = rows[idx]
+                for t in range(0, len(row), 3):
+                    e0, e1, e2 = row[t:t + 3]
+                    verts += [vl[e0][0], vl[e1][0], vl[e2][0]]
+                    c0, c1, c2 = vl[e0][1], vl[e1][1], vl[e1][1]  # the `i + 1` of :506
+                    s = ((c0 + c1).astype(F32) + c2).astype(F32) / F32(3)
+                    faces.append(np.floor(np.abs(s.astype(F64)) + 0.5).astype(np.int64))
+    if not faces:
+        return np.zeros((0, 3), F32), np.zeros((0, 3), np.int64)
+    return np.array(verts, F32), np.array(faces, np.int64)

@@ -402,7 +402,7 @@ def test_dataset_silhouettes_plumbing(arvx, oracle, which, N):
     masks with synthetic ring poses: plumbing, not a parity claim about the reference's
     run.  Ragged real silhouettes with JPEG speckle: oracle == culled == brute force."""
     from tests import golden_io
-    masks = golden_io.dataset_masks(which)
+    masks = golden_io.dataset_masks(which, recentre=(which == "human"))
     V = masks.shape[0]
     sc = scenes.syn.sphere_scene(N, V)  # ring cameras + dataset intrinsics, 640x480
     want = oracle.carve(N, N, N, sc.voxel_size, sc.M, masks)

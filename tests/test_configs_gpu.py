@@ -1,0 +1,119 @@
+"""Every configuration of BASELINE.json at ITS size, GPU plane == oracle plane, every voxel.
+
+  C1  Data/box_dataset, 128^3, the data set's 8 views ("12" do not exist)
+  C2  Data/human_dataset, 256^3, all 24 views of the data set -- and 36 (BASELINE's count:
+      the 24 silhouettes reused for the extra ring cameras)
+  C3  synthetic sphere, 512^3 x 36                      (the bench workload)
+  C4  synthetic sphere, 1024^3 x 72, Z-slab split over 8 GPUs: one rank's contiguous slab
+      and one rank's striped planes, against the oracle on exactly those planes
+  C5  Data/human_dataset, 512^3 x 24 views: carve + colour vote (both modes) + marching-cubes
+      hand-off (cell list)
+
+Data-set inputs are the reference's own files as PIL decodes them, with synthetic ring cameras
+(no OpenCV-aruco here; the human silhouettes are re-centred on the principal point so that
+their visual hull under those cameras is not empty): real ragged silhouettes and photographs,
+not the reference's poses --
+the claim is GPU == oracle on these inputs."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import golden_io, scenes
+
+pytestmark = pytest.mark.gpu
+THREADS = os.cpu_count() or 8
+
+
+def assert_same(got, want, what):
+    if not np.array_equal(got, want):
+        bad = np.argwhere(got != want)
+        raise AssertionError(f"{what}: {len(bad)} of {got.size} voxels differ, first "
+                             f"(z,y,x)={tuple(bad[0])} gpu={got[tuple(bad[0])]} "
+                             f"oracle={want[tuple(bad[0])]}")
+
+
+def gpu_carve(arvx, N, sc_M, masks, s, **ctx_kw):
+    with arvx.Context(N, N, N, s, **ctx_kw) as ctx:
+        ctx.set_views(sc_M, masks)
+        ctx.carve()
+        return ctx.download_state()
+
+
+def test_c1_box_dataset_128(arvx, oracle):
+    masks = golden_io.dataset_masks("box")
+    assert masks.shape == (8, 480, 640)
+    sc = scenes.syn.sphere_scene(128, 8)
+    want = oracle.carve(128, 128, 128, sc.voxel_size, sc.M, masks, threads=THREADS)
+    assert_same(gpu_carve(arvx, 128, sc.M, masks, sc.voxel_size), want, "C1")
+    assert 0.0 < (want & 1).mean() < 1.0
+
+
+@pytest.mark.parametrize("V", [24, 36])
+def test_c2_human_dataset_256(arvx, oracle, V):
+    m24 = golden_io.dataset_masks("human", recentre=True)
+    assert m24.shape == (24, 480, 640)
+    masks = m24[np.arange(V) % 24]
+    sc = scenes.syn.sphere_scene(256, V)
+    want = oracle.carve(256, 256, 256, sc.voxel_size, sc.M, masks, threads=THREADS)
+    assert_same(gpu_carve(arvx, 256, sc.M, masks, sc.voxel_size), want, f"C2 x {V}")
+    assert 0.0 < (want & 1).mean() < 1.0
+
+
+def test_c3_sphere_512_x36(arvx, oracle):
+    sc = scenes.syn.sphere_scene(512, 36)
+    want = oracle.carve(512, 512, 512, sc.voxel_size, sc.M, sc.masks, threads=THREADS)
+    assert_same(gpu_carve(arvx, 512, sc.M, sc.masks, sc.voxel_size), want, "C3")
+    assert abs(float((want & 1).mean()) - 0.1806) < 0.001
+
+
+@pytest.mark.parametrize("split", ["slab", "striped"])
+def test_c4_sphere_1024_x72_one_rank_of_8(arvx, oracle, split):
+    """72 views = two chunks of 64 in the work lists.  Rank 3 of 8: planes [384, 512) as a
+    contiguous slab (the colour pass's halo planes are recomputed, not compared), or the
+    8-plane groups 3, 11, 19, ... of the striped split."""
+    N, V = 1024, 72
+    sc = scenes.syn.sphere_scene(N, V)
+    if split == "slab":
+        kw = dict(z_range=(384, 512))
+        planes = np.arange(384, 512)
+    else:
+        kw = dict(stripes=(8, 3))
+        planes = arvx.stripe_planes(N, 8, 3)
+    want = oracle.carve_planes(N, N, sc.voxel_size, sc.M, sc.masks, planes, threads=THREADS)
+    with arvx.Context(N, N, N, sc.voxel_size, **kw) as ctx:
+        assert np.array_equal(ctx.planes, planes)
+        ctx.set_views(sc.M, sc.masks)
+        ctx.carve()
+        got = ctx.download_state()
+    assert_same(got, want, f"C4 {split}")
+    assert 0.0 < (want & 1).mean() < 1.0 and (want == 3).any() and (want == 2).any()
+
+
+def test_c5_human_dataset_512_carve_colour_mc(arvx, oracle):
+    N, V = 512, 24
+    masks = golden_io.dataset_masks("human", recentre=True)
+    images = golden_io.dataset_images("human")
+    assert images.shape == (V, 480, 640, 3)
+    sc = scenes.syn.sphere_scene(N, V)
+    s = sc.voxel_size
+    st = oracle.carve(N, N, N, s, sc.M, masks, threads=THREADS)
+    base = oracle.model_from_state(st)
+    with arvx.Context(N, N, N, s) as ctx:
+        ctx.set_views(sc.M, masks, campos=sc.campos)
+        ctx.set_images(images)
+        ctx.carve()
+        assert_same(ctx.download_state(), st, "C5 carve")
+        cells = ctx.mc_cells()
+        assert np.array_equal(cells, oracle.mc_cells(N, N, N, base))
+        del cells
+        for mode in (arvx.COLOR_CLOSEST, arvx.COLOR_AVERAGE):
+            want = oracle.color(N, N, N, s, sc.M, sc.campos, images, mode, base)
+            ctx.color(mode)
+            idx, rgb = ctx.surface()
+            changed = np.flatnonzero((want != base).any(axis=1))
+            assert len(idx) > 100000 and np.isin(changed, idx).all()
+            assert np.array_equal(rgb, want[idx, :3]), f"C5 colour mode {mode}"
+            depth = ctx.surface_depth()
+            assert depth.shape == (len(idx),) and np.isfinite(depth).all()
+            del want

@@ -42,7 +42,7 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     rows = [("C1 box 128^3 x 8 (data set masks)", 128, golden_io.dataset_masks("box"), False),
-            ("C2 human 256^3 x 8 of 24 (data set masks)", 256, golden_io.dataset_masks("human"), False),
+            ("C2 human 256^3 x 24 (data set masks, re-centred)", 256, golden_io.dataset_masks("human", recentre=True), False),
             ("C3 sphere 512^3 x 36", 512, 36, False),
             ("H  sphere 1024^3 x 36", 1024, 36, False),
             ("C4' sphere 1024^3 x 72, one GPU", 1024, 72, False),

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condenses gpurun_out/prof_<tag>/ (written by tools/profile_r1.sh) into
+"""Condenses gpurun_out/prof_<tag>/ (written by tools/profile_r1.sh / tools/profile.sh) into
 profiles/<name>/: the rocprofv3 kernel_stats.csv files plus summary.json with the
 per-launch means of every PMC counter for the carve kernels."""
 import collections
@@ -17,7 +17,10 @@ def kernel_key(name):
     for k in ("coarse", "classify", "exact", "fused"):
         if "carve_" + k in name:
             return k
-    return "other"
+    for k in ("mask_to_bits", "sat_rows", "sat_cols", "views_"):  # arvx_set_views_device
+        if k in name:
+            return k.rstrip("_")
+    return None
 
 
 def main():
@@ -33,8 +36,8 @@ def main():
             for f in glob.glob(f"{base}/{sub}/runc/*_counter_collection.csv"):
                 agg = collections.defaultdict(lambda: collections.defaultdict(list))
                 for r in csv.DictReader(open(f)):
-                    if "carve_" in r["Kernel_Name"]:
-                        k = kernel_key(r["Kernel_Name"])
+                    k = kernel_key(r["Kernel_Name"])
+                    if k:
                         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 for k, cs in agg.items():
                     for c, v in cs.items():
@@ -43,8 +46,8 @@ def main():
             os.makedirs(os.path.join(out_dir, tag), exist_ok=True)
             shutil.copy(f, os.path.join(out_dir, tag, "kernel_stats.csv"))
             for r in csv.DictReader(open(f)):
-                if "carve_" in r["Name"]:
-                    k = kernel_key(r["Name"])
+                k = kernel_key(r["Name"])
+                if k:
                     d.setdefault(k, {})["kernel_avg_ns"] = float(r["AverageNs"])
                     d[k]["kernel_calls"] = int(r["Calls"])
         summary[tag] = d
