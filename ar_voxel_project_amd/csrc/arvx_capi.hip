@@ -16,6 +16,7 @@
 
 #include "arvx_ctx.h"
 #include "carve_kernels.h"
+#include "views_kernels.h"
 #include "color_kernels.h"
 #include "closure_kernels.h"
 #include "bitplane_kernels.h"
@@ -295,6 +296,22 @@ static int views_preprocess(Ctx *ctx, const uint8_t *d_masks, int C) {
     const int npix = ctx->W * ctx->H;
     dim3 g1((npix + 255) / 256, ctx->V);
     ARVX_HIP(hipGetLastError());  // anything stale would be blamed on the launches below
+    if (ctx->W % 64 == 0 && (C == 1 || C == 3)) {  // two launches: views_kernels.h
+        const dim3 gr((ctx->H + 3) / 4, ctx->V);
+        if (C == 1)
+            hipLaunchKernelGGL(arvx::views_rows_kernel<1>, gr, dim3(256), 0, ctx->stream, d_masks,
+                               ctx->W, ctx->H, ctx->d_bg, ctx->bgWords, ctx->d_sat, ctx->satStride);
+        else
+            hipLaunchKernelGGL(arvx::views_rows_kernel<3>, gr, dim3(256), 0, ctx->stream, d_masks,
+                               ctx->W, ctx->H, ctx->d_bg, ctx->bgWords, ctx->d_sat, ctx->satStride);
+        ARVX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(arvx::views_cols_kernel, dim3((ctx->W + 1 + 63) / 64, ctx->V),
+                           dim3(64 * arvx::kColGroups), 0, ctx->stream, ctx->W, ctx->H, ctx->d_sat,
+                           ctx->satStride);
+        ARVX_HIP(hipGetLastError());
+        ctx->views_ready = true;
+        return ARVX_OK;
+    }
     ARVX_HIP(hipMemsetAsync(ctx->d_bg, 0, (size_t)ctx->V * ctx->bgWords * sizeof(uint32_t),
                             ctx->stream));
     hipLaunchKernelGGL(arvx::mask_to_bits_kernel, g1, dim3(256), 0, ctx->stream, d_masks, C, npix,

@@ -522,3 +522,26 @@ def test_fuzz_against_oracle(arvx, oracle):
         want = oracle.carve(X, Y, Z, s, M, masks)
         assert_same(run_gpu(arvx, X, Y, Z, s, M, masks), want,
                     f"case {i}: {X}x{Y}x{Z} V={V} {W}x{H}")
+
+
+@pytest.mark.parametrize("W,H,C", [(64, 3, 1), (128, 50, 3), (192, 117, 1), (640, 480, 3),
+                                   (96, 64, 3), (65, 64, 1)])
+def test_view_preprocessing_paths(arvx, oracle, W, H, C):
+    """Image widths that are a multiple of 64 derive bit planes and summed-area tables with
+    the two-launch kernels of csrc/views_kernels.h (1 and 3 channels), the others with the
+    general ones: same planes, same tables -- checked through the carve they drive, from host
+    masks and from masks already on the device (re-derived twice)."""
+    import torch
+    N, V = 40, 5
+    s = np.float32(0.512 / N)
+    _, _, M = scenes.random_cameras(V, 0.512, seed=W + H + C, W=W, H=H, inside=False)
+    masks = scenes.noise_masks(V, H, W, C=C, block=5, p_bg=0.4, seed=W * 7 + C)
+    want = oracle.carve(N, N, N, s, M, masks)
+    assert_same(run_gpu(arvx, N, N, N, s, M, masks), want, f"{W}x{H}x{C} host masks")
+    d_masks = torch.from_numpy(np.ascontiguousarray(masks)).cuda()
+    with arvx.Context(N, N, N, s) as ctx:
+        for _ in range(2):
+            ctx.reset()
+            ctx.set_views_device(M, d_masks.data_ptr(), W, H, C)
+            ctx.carve()
+            assert_same(ctx.download_state(), want, f"{W}x{H}x{C} device masks")
