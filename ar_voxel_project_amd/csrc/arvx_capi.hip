@@ -17,6 +17,7 @@
 #include "arvx_ctx.h"
 #include "carve_kernels.h"
 #include "views_kernels.h"
+#include "state_kernels.h"
 #include "color_kernels.h"
 #include "closure_kernels.h"
 #include "bitplane_kernels.h"
@@ -178,13 +179,12 @@ int arvx_ctx_create_slab(arvx_ctx **out, int device, int X, int Y, int Z, float 
         return arvx::fail_hip(e, "hipStreamCreate", __FILE__, __LINE__);
     }
     c->stream = c->own_stream;
-    e = hipMalloc(&c->d_state, c->nvox_ext);
-    if (e == hipSuccess) e = hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long));
+    e = hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long));
     if (e != hipSuccess) {
         arvx_ctx_destroy(c);
-        return arvx::fail_hip(e, "hipMalloc(state)", __FILE__, __LINE__);
+        return arvx::fail_hip(e, "hipMalloc(stats)", __FILE__, __LINE__);
     }
-    c->fresh_pending = true;  // a fresh Model: filled on first read, see materialize()
+    c->fresh_pending = true;  // a fresh Model exists only as this flag: see need_rec / need_bytes
     e = hipMemsetAsync(c->d_stats, 0, 64, c->stream);
     if (e != hipSuccess) {
         arvx_ctx_destroy(c);
@@ -229,6 +229,8 @@ int arvx_ctx_destroy(arvx_ctx *ctx) {
     ctx->free_mc();
     ctx->release_pools();
     if (ctx->d_flood) (void)hipFree(ctx->d_flood);
+    if (ctx->d_flood_rec) (void)hipFree(ctx->d_flood_rec);
+    if (ctx->d_rec) (void)hipFree(ctx->d_rec);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -305,9 +307,14 @@ static int views_preprocess(Ctx *ctx, const uint8_t *d_masks, int C) {
             hipLaunchKernelGGL(arvx::views_rows_kernel<3>, gr, dim3(256), 0, ctx->stream, d_masks,
                                ctx->W, ctx->H, ctx->d_bg, ctx->bgWords, ctx->d_sat, ctx->satStride);
         ARVX_HIP(hipGetLastError());
-        hipLaunchKernelGGL(arvx::views_cols_kernel, dim3((ctx->W + 1 + 63) / 64, ctx->V),
-                           dim3(64 * arvx::kColGroups), 0, ctx->stream, ctx->W, ctx->H, ctx->d_sat,
-                           ctx->satStride);
+        const dim3 gc((ctx->W + arvx::kColsPerWg) / arvx::kColsPerWg, ctx->V);
+        const dim3 bc(arvx::kColsPerWg * arvx::kColGroups);
+        if (ctx->H <= 16 * arvx::kColGroups)
+            hipLaunchKernelGGL(arvx::views_cols_kernel<false>, gc, bc, 0, ctx->stream, ctx->W, ctx->H,
+                               ctx->d_sat, ctx->satStride);
+        else
+            hipLaunchKernelGGL(arvx::views_cols_kernel<true>, gc, bc, 0, ctx->stream, ctx->W, ctx->H,
+                               ctx->d_sat, ctx->satStride);
         ARVX_HIP(hipGetLastError());
         ctx->views_ready = true;
         return ARVX_OK;
@@ -385,20 +392,111 @@ int arvx_set_views_device(arvx_ctx *ctx, int V, const float *M, const float *cam
 
 // ---- state -------------------------------------------------------------------
 
-static int materialize(Ctx *ctx);
+// grid geometry of a context as the kernels see it (planes ze0..ze1-1: owned + halo)
+static void carve_geometry(const Ctx *ctx, arvx::CarveParams &p) {
+    memset(&p, 0, sizeof p);
+    p.X = ctx->X;
+    p.Y = ctx->Y;
+    p.Z = ctx->ze1 - ctx->ze0;  // owned planes plus halo (recomputed, never exchanged)
+    p.zoff = ctx->ze0;
+    p.zstride = ctx->stripe_world;
+    p.zphase = ctx->stripe_rank;
+    p.s = ctx->s;
+    p.tilesX = (p.X + arvx::kTileX - 1) / arvx::kTileX;
+    p.tilesY = (p.Y + arvx::kTileY - 1) / arvx::kTileY;
+    p.tilesZ = (p.Z + arvx::kTileZ - 1) / arvx::kTileZ;
+    // coarse tile 64x32x32; striped slabs: 64x64x8, so that it stays inside one stripe
+    p.cyShift = ctx->stripe_world > 1 ? 3 : 2;
+    p.czShift = ctx->stripe_world > 1 ? 0 : 2;
+    p.coarseX = (p.X + arvx::kCoarseX - 1) / arvx::kCoarseX;
+    p.coarseY = (p.Y + (8 << p.cyShift) - 1) / (8 << p.cyShift);
+    p.coarseZ = (p.Z + (8 << p.czShift) - 1) / (8 << p.czShift);
+}
+
+// a record buffer for this context's grid, every record "finished" when it is new
+static int ensure_records(Ctx *ctx, void **buf, size_t *cap) {
+    arvx::CarveParams g;
+    carve_geometry(ctx, g);
+    const size_t need = arvx::rec_count(g) * arvx::kRecU16 * sizeof(uint16_t);
+    if (*cap >= need) return ARVX_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    ARVX_HIP(hipMalloc(buf, need));
+    *cap = need;
+    hipLaunchKernelGGL(arvx::rec_init_kernel, dim3(2048), dim3(256), 0, ctx->stream,
+                       (uint32_t *)*buf, need / 4);
+    ARVX_HIP(hipGetLastError());
+    return ARVX_OK;
+}
+
+// The state as records: what the carve works on.
+static int need_rec(Ctx *ctx) {
+    void *buf = ctx->d_rec;
+    if (int rc = ensure_records(ctx, &buf, &ctx->rec_bytes)) return rc;
+    ctx->d_rec = (uint16_t *)buf;
+    if (ctx->rec_valid) return ARVX_OK;
+    arvx::CarveParams g;
+    carve_geometry(ctx, g);
+    g.rec = ctx->d_rec;
+    if (ctx->bytes_valid) {
+        hipLaunchKernelGGL(arvx::rec_from_bytes_kernel,
+                           dim3((unsigned)((size_t)g.tilesX * g.tilesY * g.tilesZ)), dim3(256), 0,
+                           ctx->stream, g, (const uint8_t *)ctx->d_state);
+    } else {  // a fresh model: all occupied, none seen
+        g.flags = 4u | 16u;
+        hipLaunchKernelGGL(arvx::carve_fill_kernel,
+                           dim3((unsigned)((size_t)g.coarseX * g.coarseY * g.coarseZ)), dim3(256), 0,
+                           ctx->stream, g);
+        ctx->fresh_pending = false;
+    }
+    ARVX_HIP(hipGetLastError());
+    ctx->rec_valid = true;
+    return ARVX_OK;
+}
+
+// The state as one byte per voxel: what the C-ABI's state calls and the stages that are not
+// ported to records yet work on.
+static int need_bytes(Ctx *ctx) {
+    if (!ctx->d_state) ARVX_HIP(hipMalloc(&ctx->d_state, ctx->nvox_ext));
+    if (ctx->bytes_valid) return ARVX_OK;
+    if (ctx->rec_valid) {
+        arvx::CarveParams g;
+        carve_geometry(ctx, g);
+        g.rec = ctx->d_rec;
+        hipLaunchKernelGGL(arvx::rec_to_bytes_kernel,
+                           dim3((unsigned)((size_t)g.tilesX * g.tilesY * g.tilesZ)), dim3(256), 0,
+                           ctx->stream, g, ctx->d_state);
+        ARVX_HIP(hipGetLastError());
+    } else {  // a fresh model
+        ARVX_HIP(hipMemsetAsync(ctx->d_state, 0x01, ctx->nvox_ext, ctx->stream));
+        ctx->fresh_pending = false;
+    }
+    ctx->bytes_valid = true;
+    return ARVX_OK;
+}
+
+// the byte plane is about to be written by its user
+static int own_bytes(Ctx *ctx) {
+    if (int rc = need_bytes(ctx)) return rc;
+    ctx->rec_valid = false;
+    return ARVX_OK;
+}
 
 int arvx_state_reset(arvx_ctx *ctx) {
     ARVX_CHECK_CTX(ctx);
     ctx->color_ready = false;
     ctx->closure_ready = false;
-    ctx->fresh_pending = true;  // see materialize()
+    ctx->fresh_pending = true;  // materialised by need_rec / need_bytes, or never (a carve of a
+    ctx->rec_valid = false;     // fresh model writes every record)
+    ctx->bytes_valid = false;
     return ARVX_OK;
 }
 
 int arvx_state_upload(arvx_ctx *ctx, const uint8_t *state) {
     ARVX_CHECK_CTX(ctx);
-    if (int mrc = materialize(ctx)) return mrc;
     if (!state) return fail(ARVX_ERR_INVALID, "null state");
+    if (int mrc = own_bytes(ctx)) return mrc;  // (halo planes keep what they hold)
     ctx->color_ready = false;
     ctx->closure_ready = false;
     ARVX_HIP(hipMemcpyAsync(ctx->owned(), state, ctx->nvox, hipMemcpyHostToDevice, ctx->stream));
@@ -408,9 +506,9 @@ int arvx_state_upload(arvx_ctx *ctx, const uint8_t *state) {
 
 int arvx_state_upload_halo(arvx_ctx *ctx, const uint8_t *plane_below, const uint8_t *plane_above) {
     ARVX_CHECK_CTX(ctx);
-    if (int mrc = materialize(ctx)) return mrc;
     const size_t plane = (size_t)ctx->X * ctx->Y;
     if (ctx->stripe_world > 1) return fail(ARVX_ERR_STATE, "striped slabs keep no halo planes");
+    if (int mrc = own_bytes(ctx)) return mrc;
     ctx->color_ready = false;
     ctx->closure_ready = false;
     if (plane_below && ctx->ze0 < ctx->z0)
@@ -425,8 +523,8 @@ int arvx_state_upload_halo(arvx_ctx *ctx, const uint8_t *plane_below, const uint
 
 int arvx_state_download(arvx_ctx *ctx, uint8_t *state) {
     ARVX_CHECK_CTX(ctx);
-    if (int mrc = materialize(ctx)) return mrc;
     if (!state) return fail(ARVX_ERR_INVALID, "null state");
+    if (int mrc = need_bytes(ctx)) return mrc;
     ARVX_HIP(hipMemcpyAsync(state, ctx->owned(), ctx->nvox, hipMemcpyDeviceToHost, ctx->stream));
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
     return ARVX_OK;
@@ -435,7 +533,7 @@ int arvx_state_download(arvx_ctx *ctx, uint8_t *state) {
 int arvx_state_device_ptr(arvx_ctx *ctx, void **ptr, size_t *bytes) {
     if (!ctx || !ptr) return fail(ARVX_ERR_INVALID, "null argument");
     ARVX_HIP(hipSetDevice(ctx->device));
-    if (int mrc = materialize(ctx)) return mrc;
+    if (int mrc = need_bytes(ctx)) return mrc;
     *ptr = ctx->owned();
     if (bytes) *bytes = ctx->nvox;
     return ARVX_OK;
@@ -443,8 +541,22 @@ int arvx_state_device_ptr(arvx_ctx *ctx, void **ptr, size_t *bytes) {
 
 int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
     ARVX_CHECK_CTX(ctx);
-    if (int mrc = materialize(ctx)) return mrc;
     if (!dev_words) return fail(ARVX_ERR_INVALID, "null dev_words");
+    if (ctx->X % 32 == 0 && (uintptr_t)dev_words % 4 == 0 && (ctx->rec_valid || !ctx->bytes_valid)) {
+        // straight from the records: 2 bits per voxel in, 1 out
+        if (int mrc = need_rec(ctx)) return mrc;
+        arvx::CarveParams g;
+        carve_geometry(ctx, g);
+        g.rec = ctx->d_rec;
+        const int nz = ctx->z1 - ctx->z0;
+        const size_t nwords = (size_t)(ctx->X / 32) * ctx->Y * nz;
+        hipLaunchKernelGGL(arvx::pack_occupancy_rec_kernel, dim3((unsigned)((nwords + 255) / 256)),
+                           dim3(256), 0, ctx->stream, g, ctx->z0 - ctx->ze0, nz, 0,
+                           (uint32_t *)dev_words);
+        ARVX_HIP(hipGetLastError());
+        return ARVX_OK;
+    }
+    if (int mrc = need_bytes(ctx)) return mrc;
     if (ctx->nvox % 32 == 0 && (uintptr_t)ctx->owned() % 16 == 0 && (uintptr_t)dev_words % 4 == 0) {
         const size_t nwords = ctx->nvox / 32;
         hipLaunchKernelGGL(arvx::pack_occupancy32_kernel, dim3((unsigned)((nwords + 255) / 256)),
@@ -465,10 +577,23 @@ int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
 
 int arvx_pack_occupancy_global(arvx_ctx *ctx, void *dev_global_words) {
     ARVX_CHECK_CTX(ctx);
-    if (int mrc = materialize(ctx)) return mrc;
     if (!dev_global_words) return fail(ARVX_ERR_INVALID, "null dev_global_words");
     const size_t plane = (size_t)ctx->X * ctx->Y;
     if (plane % 64) return fail(ARVX_ERR_INVALID, "X*Y must be a multiple of 64");
+    if (ctx->X % 32 == 0 && (ctx->rec_valid || !ctx->bytes_valid)) {
+        if (int mrc = need_rec(ctx)) return mrc;
+        arvx::CarveParams g;
+        carve_geometry(ctx, g);
+        g.rec = ctx->d_rec;
+        const int nz = ctx->z1 - ctx->z0;
+        const size_t nwords = (size_t)(ctx->X / 32) * ctx->Y * nz;
+        hipLaunchKernelGGL(arvx::pack_occupancy_rec_kernel, dim3((unsigned)((nwords + 255) / 256)),
+                           dim3(256), 0, ctx->stream, g, ctx->z0 - ctx->ze0, nz, 1,
+                           (uint32_t *)dev_global_words);
+        ARVX_HIP(hipGetLastError());
+        return ARVX_OK;
+    }
+    if (int mrc = need_bytes(ctx)) return mrc;
     // plane % 64 == 0 and an aligned allocation: every plane starts on an 8-byte boundary
     const size_t nbytes = ctx->nvox / 8;
     hipLaunchKernelGGL(arvx::pack_occupancy_global8_kernel, dim3((unsigned)((nbytes + 255) / 256)),
@@ -555,24 +680,18 @@ int arvx_occupancy_expand_striped(arvx_ctx *ctx, const void *dev_packets, int wo
 
 // ---- carve -------------------------------------------------------------------
 
-// Launches the fused carve over planes [ze0, ze1) of `state` (owned + halo).
-// `fresh`: the plane is known to be all-occupied/unseen, so it is not read.
-static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned flags,
+// Launches the carve over planes [ze0, ze1) (owned + halo) of the records at `rec`.
+// `fresh`: the model is all-occupied/unseen and exists only as that flag: nothing is read,
+// every record of the grid is written.
+static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned flags,
                         bool fresh) {
     arvx::CarveParams p;
-    p.state = state;
+    carve_geometry(ctx, p);
+    p.rec = rec;
     p.M = ctx->d_M;
     p.bg = ctx->d_bg;
     p.sat = ctx->d_sat;
     p.stats = ctx->d_stats;
-    p.timeline = nullptr;
-    p.X = ctx->X;
-    p.Y = ctx->Y;
-    p.Z = ctx->ze1 - ctx->ze0;  // owned planes plus halo (recomputed, never exchanged)
-    p.zoff = ctx->ze0;
-    p.zstride = ctx->stripe_world;
-    p.zphase = ctx->stripe_rank;
-    p.s = ctx->s;
     p.W = ctx->W;
     p.H = ctx->H;
     p.bgWords = ctx->bgWords;
@@ -580,41 +699,29 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
     p.v0 = first;
     p.v1 = first + count;
     p.flags = (flags & 3u) | (fresh ? 4u : 0u);
-    p.tilesX = (p.X + arvx::kTileX - 1) / arvx::kTileX;
-    p.tilesY = (p.Y + arvx::kTileY - 1) / arvx::kTileY;
-    p.tilesZ = (p.Z + arvx::kTileZ - 1) / arvx::kTileZ;
-    // coarse tile 64x32x32; striped slabs: 64x64x8, so that it stays inside one stripe
-    p.cyShift = ctx->stripe_world > 1 ? 3 : 2;
-    p.czShift = ctx->stripe_world > 1 ? 0 : 2;
-    p.coarseX = (p.X + arvx::kCoarseX - 1) / arvx::kCoarseX;
-    p.coarseY = (p.Y + (8 << p.cyShift) - 1) / (8 << p.cyShift);
-    p.coarseZ = (p.Z + (8 << p.czShift) - 1) / (8 << p.czShift);
     p.nchunks = (count + 63) / 64;
-    p.coarseMixed = p.coarseFg = nullptr;
-    p.coarseCarved = nullptr;
-    p.workCount = p.poolNext = nullptr;
-    p.workCap = 0;
-    p.nwaves = 0;
-    p.itemInfo = p.itemMasks = nullptr;
     if (flags & ARVX_CARVE_STATS) ARVX_HIP(hipMemsetAsync(ctx->d_stats, 0, 64, ctx->stream));
     // rows of tiles (along x) are dealt to the XCDs cyclically: see carve_fused_kernel
     const size_t rows8 = ((size_t)p.tilesY * p.tilesZ + 7) / 8 * 8;
     const unsigned grid = (unsigned)(rows8 * p.tilesX);
     const bool cull = !(flags & ARVX_CARVE_NO_CULL);
     const bool split = cull && !(flags & ARVX_CARVE_FUSED) && p.nchunks <= arvx::kMaxChunks;
+    const size_t ncoarse = (size_t)p.coarseX * p.coarseY * p.coarseZ;
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    if (ncu <= 0) ncu = 256;
     if (cull) {
-        const size_t ncoarse = (size_t)p.coarseX * p.coarseY * p.coarseZ;
         const size_t words = ncoarse * p.nchunks;
-        const size_t off_work = (2 * words * sizeof(unsigned long long) + ncoarse + 255) / 256 * 256;
+        // coarse masks | coarse codes | undecided list | two list counters
+        const size_t off_list = (2 * words * sizeof(unsigned long long) + ncoarse + 255) / 256 * 256;
+        const size_t off_work = off_list + ((ncoarse + 2 * 64) * sizeof(int) + 255) / 256 * 256;
         const size_t nctr = (size_t)arvx::kWorkLists * arvx::kCounterStride;
         // sub-tile i (of 4 per tile) goes to list i % 8 of one of eight weight classes: a
         // list never gets more than every 8th sub-tile
         const size_t cap = ((size_t)p.tilesX * p.tilesY * p.tilesZ * 4 + 7) / 8;
         const size_t nitems = cap * arvx::kWorkLists;
         // one persistent workgroup per workgroup slot of the chip (4 per CU at 128 VGPRs)
-        int ncu = 256;
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        const unsigned pgrid = (unsigned)(ncu > 0 ? ncu : 256) * 4u;
+        const unsigned pgrid = (unsigned)ncu * 4u;
         const size_t nwaves = (size_t)pgrid * 4;
         const size_t nctr_pool = (size_t)arvx::kPoolCounters * arvx::kCounterStride;
         const size_t ints = nctr + nctr_pool;  // list fill counters, pool ticket counters
@@ -632,6 +739,18 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
         p.coarseFg = p.coarseMixed + words;
         p.coarseCarved = (uint8_t *)(p.coarseFg + words);
         if (split) {
+            int *lst = (int *)((uint8_t *)ctx->d_coarse + off_list);
+            // two counters, 64 ints apart, used alternately (carve_coarse_kernel): both zero
+            // before the first carve that uses this layout
+            if (ctx->carve_layout != need) {
+                ARVX_HIP(hipMemsetAsync(lst, 0, 2 * 64 * sizeof(int), ctx->stream));
+                ctx->carve_layout = need;
+                ctx->carve_seq = 0;
+            }
+            p.undecidedCount = lst + 64 * (ctx->carve_seq & 1);
+            p.undecidedCountNext = lst + 64 * ((ctx->carve_seq + 1) & 1);
+            p.undecidedList = lst + 2 * 64;
+            ++ctx->carve_seq;
             int *base = (int *)((uint8_t *)ctx->d_coarse + off_work);
             p.workCount = base;
             p.poolNext = base + nctr;
@@ -645,24 +764,22 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
                            dim3(256), 0, ctx->stream, p);
         ARVX_HIP(hipGetLastError());
     }
-    const bool aligned = (p.X % 4 == 0) && (((uintptr_t)p.state & 3u) == 0);
     // the statistics counters live in the row-mapped variant
     static const bool row_map = getenv("ARVX_EXACT_ROWS") != nullptr;
     const bool blocks = split && !row_map && !(flags & ARVX_CARVE_STATS);
     // few sub-tiles per wave (small grids, slabs): the exact kernel may hand an item's views
     // to several waves (decided in the kernel from the length of the work lists)
     static const bool no_item_split = getenv("ARVX_NO_ITEM_SPLIT") != nullptr;
-    if (blocks && aligned && !no_item_split &&
-        (size_t)p.X * p.Y * p.Z <= ((size_t)1 << 26))
-        p.flags |= 8u;
+    if (blocks && !no_item_split && (size_t)p.X * p.Y * p.Z <= ((size_t)1 << 26)) p.flags |= 8u;
     if (split) {
-        const dim3 cgrid(8u * (unsigned)p.tilesX, (unsigned)(p.tilesY + 7) / 8u, (unsigned)p.tilesZ);
-        if (aligned)
-            hipLaunchKernelGGL(arvx::carve_classify_kernel<true>, cgrid, dim3(256), 0,
-                               ctx->stream, p);
-        else
-            hipLaunchKernelGGL(arvx::carve_classify_kernel<false>, cgrid, dim3(256), 0,
-                               ctx->stream, p);
+        // decided coarse tiles: constant records, one workgroup each
+        hipLaunchKernelGGL(arvx::carve_fill_kernel, dim3((unsigned)ncoarse), dim3(256), 0,
+                           ctx->stream, p);
+        ARVX_HIP(hipGetLastError());
+        // the others: a fixed grid walks the list (8 waves per SIMD)
+        static const int cgrid_env = getenv("ARVX_CLASSIFY_WGS") ? atoi(getenv("ARVX_CLASSIFY_WGS")) : 0;
+        const unsigned cgrid = cgrid_env > 0 ? (unsigned)cgrid_env : (unsigned)ncu * 8u;
+        hipLaunchKernelGGL(arvx::carve_classify_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, p);
         ARVX_HIP(hipGetLastError());
         const unsigned pgrid = (unsigned)(p.nwaves / 4);
 #ifdef ARVX_TIMELINE
@@ -674,18 +791,11 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
         ARVX_HIP(hipMemsetAsync(ctx->d_timeline, 0, (size_t)pgrid * 4 * 64, ctx->stream));
         p.timeline = (unsigned long long *)ctx->d_timeline;
 #endif
-        if (blocks && aligned)
-            hipLaunchKernelGGL(arvx::carve_exact_blocks_kernel<true>, dim3(pgrid), dim3(256), 0,
-                               ctx->stream, p);
-        else if (blocks)
-            hipLaunchKernelGGL(arvx::carve_exact_blocks_kernel<false>, dim3(pgrid), dim3(256), 0,
-                               ctx->stream, p);
-        else if (aligned)
-            hipLaunchKernelGGL(arvx::carve_exact_kernel<true>, dim3(pgrid), dim3(256), 0,
+        if (blocks)
+            hipLaunchKernelGGL(arvx::carve_exact_blocks_kernel, dim3(pgrid), dim3(256), 0,
                                ctx->stream, p);
         else
-            hipLaunchKernelGGL(arvx::carve_exact_kernel<false>, dim3(pgrid), dim3(256), 0,
-                               ctx->stream, p);
+            hipLaunchKernelGGL(arvx::carve_exact_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, p);
         ARVX_HIP(hipGetLastError());
         return ARVX_OK;
     }
@@ -698,23 +808,8 @@ static int launch_carve(Ctx *ctx, uint8_t *state, int first, int count, unsigned
     ARVX_HIP(hipMemsetAsync(ctx->d_timeline, 0, (size_t)grid * 32, ctx->stream));
     p.timeline = (unsigned long long *)ctx->d_timeline;
 #endif
-    if (aligned)
-        hipLaunchKernelGGL(arvx::carve_fused_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream,
-                           p);
-    else
-        hipLaunchKernelGGL(arvx::carve_fused_kernel<false>, dim3(grid), dim3(256), 0,
-                           ctx->stream, p);
+    hipLaunchKernelGGL(arvx::carve_fused_kernel, dim3(grid), dim3(256), 0, ctx->stream, p);
     ARVX_HIP(hipGetLastError());
-    return ARVX_OK;
-}
-
-// arvx_state_reset is lazy: the plane is filled only if somebody reads it before
-// a carve (which writes every voxel) has replaced it.
-static int materialize(Ctx *ctx) {
-    if (ctx->fresh_pending) {
-        ARVX_HIP(hipMemsetAsync(ctx->d_state, 0x01, ctx->nvox_ext, ctx->stream));
-        ctx->fresh_pending = false;
-    }
     return ARVX_OK;
 }
 
@@ -728,8 +823,17 @@ int arvx_carve_views(arvx_ctx *ctx, int first, int count, unsigned flags) {
     ctx->color_ready = false;
     ctx->closure_ready = false;
     const bool fresh = ctx->fresh_pending;
-    ctx->fresh_pending = false;  // the kernel writes every voxel of the plane
-    return launch_carve(ctx, ctx->d_state, first, count, flags, fresh);
+    if (fresh) {  // the kernels write every record of the grid; nothing is read
+        void *buf = ctx->d_rec;
+        if (int rc = ensure_records(ctx, &buf, &ctx->rec_bytes)) return rc;
+        ctx->d_rec = (uint16_t *)buf;
+    } else if (int rc = need_rec(ctx)) {
+        return rc;
+    }
+    ctx->fresh_pending = false;
+    ctx->rec_valid = true;
+    ctx->bytes_valid = false;
+    return launch_carve(ctx, ctx->d_rec, first, count, flags, fresh);
 }
 
 int arvx_carve(arvx_ctx *ctx, unsigned flags) {
@@ -779,7 +883,7 @@ int arvx_set_images(arvx_ctx *ctx, const uint8_t *const *images, size_t stride) 
 
 int arvx_color(arvx_ctx *ctx, int mode) {
     ARVX_CHECK_CTX(ctx);
-    if (int mrc = materialize(ctx)) return mrc;
+    if (int mrc = need_bytes(ctx)) return mrc;
     if (!ctx->views_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
     if (!ctx->images_ready) return fail(ARVX_ERR_STATE, "arvx_set_images has not been called");
     if (!ctx->has_campos) return fail(ARVX_ERR_STATE, "arvx_set_views was given no campos");
@@ -913,7 +1017,7 @@ int arvx_surface_depth_download(arvx_ctx *ctx, float *depth) {
 // Model::voxels of the owned voxels, built on the device in chunks and copied out.
 int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen) {
     ARVX_CHECK_CTX(ctx);
-    if (int mrc = materialize(ctx)) return mrc;
+    if (int mrc = need_bytes(ctx)) return mrc;
     if (!rgba) return fail(ARVX_ERR_INVALID, "null rgba");
     if (ctx->closure_ready && (apply_unseen != 0) != (ctx->closure_unseen != 0))
         return fail(ARVX_ERR_STATE, "arvx_closure was computed with apply_unseen=%d",
@@ -1066,7 +1170,7 @@ int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const flo
 
 int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     ARVX_CHECK_CTX(ctx);
-    if (int mrc = materialize(ctx)) return mrc;
+    if (int mrc = own_bytes(ctx)) return mrc;  // closure_mark_kernel sets bits in the plane
     if (kernel_size < 1 || kernel_size % 2 != 1 || kernel_size > 9)
         return fail(ARVX_ERR_INVALID, "kernel size %d (odd, 1..9)", kernel_size);
     if (ctx->z0 != 0 || ctx->z1 != ctx->Z || ctx->stripe_world > 1)
@@ -1166,7 +1270,7 @@ int arvx_closure_download(arvx_ctx *ctx, int64_t *index, float *rgba) {
 int arvx_mc_cells(arvx_ctx *ctx, int64_t *count) {
     ARVX_CHECK_CTX(ctx);
     if (!count) return fail(ARVX_ERR_INVALID, "null argument");
-    if (int mrc = materialize(ctx)) return mrc;
+    if (int mrc = need_bytes(ctx)) return mrc;
     if (ctx->stripe_world > 1)
         return fail(ARVX_ERR_STATE, "the cell walk needs contiguous slabs (neighbour planes)");
     ctx->free_mc();
@@ -1257,6 +1361,11 @@ int arvx_fast_carve(arvx_ctx *ctx) {
     // a fresh model (the usual case: src/main.cpp calls fastCarve on a new Model) is neither
     // filled nor read: the kernels know its bytes, and flood_apply writes the whole plane
     fp.fresh = ctx->fresh_pending ? 1 : 0;
+    if (fp.fresh) {
+        if (!ctx->d_state) ARVX_HIP(hipMalloc(&ctx->d_state, ctx->nvox_ext));
+    } else if (int mrc = need_bytes(ctx)) {
+        return mrc;
+    }
     fp.X = ctx->X;
     fp.Y = ctx->Y;
     fp.Z = ctx->Z;
@@ -1292,8 +1401,19 @@ int arvx_fast_carve(arvx_ctx *ctx) {
     fp.changed = (int *)(base + o_changed);
     fp.dirty_cur = fp.dirty_next = nullptr;  // set per launch of flood_step_kernel
 
-    // carvable = what the dense carve clears on a fresh plane (not read: `fresh`)
-    if (int rc = launch_carve(ctx, d_tmp, 0, ctx->V, 0, true)) return rc;
+    // carvable = what the dense carve clears on a fresh model: carved into records of its
+    // own, then expanded to the byte form the flood kernels read
+    if (int rc = ensure_records(ctx, &ctx->d_flood_rec, &ctx->flood_rec_bytes)) return rc;
+    if (int rc = launch_carve(ctx, (uint16_t *)ctx->d_flood_rec, 0, ctx->V, 0, true)) return rc;
+    {
+        arvx::CarveParams g;
+        carve_geometry(ctx, g);
+        g.rec = (uint16_t *)ctx->d_flood_rec;
+        hipLaunchKernelGGL(arvx::rec_to_bytes_kernel,
+                           dim3((unsigned)((size_t)g.tilesX * g.tilesY * g.tilesZ)), dim3(256), 0,
+                           ctx->stream, g, d_tmp);
+        ARVX_HIP(hipGetLastError());
+    }
     if (fp.X % 32 == 0 && (((uintptr_t)d_tmp | (uintptr_t)ctx->d_state) & 15u) == 0) {
         ARVX_HIP(hipMemsetAsync(fp.reach, 0, nwords * sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(arvx::flood_pack_open32_kernel,
@@ -1358,7 +1478,9 @@ int arvx_fast_carve(arvx_ctx *ctx) {
         hipLaunchKernelGGL(arvx::flood_apply_kernel, dim3((unsigned)((ctx->nvox + 255) / 256)),
                            dim3(256), 0, ctx->stream, ctx->d_state, fp);
     ARVX_HIP(hipGetLastError());
-    ctx->fresh_pending = false;  // the plane now holds every voxel's state
+    ctx->fresh_pending = false;  // the byte plane now holds every voxel's state
+    ctx->bytes_valid = true;
+    ctx->rec_valid = false;
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
     return ARVX_OK;
 }

@@ -53,12 +53,23 @@ struct Ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
 
-    uint8_t *d_state = nullptr;  // planes ze0..ze1-1
+    // The state lives in one of two forms (csrc/arvx_device.h): sub-tile RECORDS, 2 bits per
+    // voxel -- what the carve kernels read and write --, and the one-byte-per-voxel plane of
+    // the C-ABI, allocated and converted on demand for the calls that exchange bytes.
+    uint16_t *d_rec = nullptr;   // records of planes ze0..ze1-1 (+ padding to whole coarse tiles)
+    size_t rec_bytes = 0;
+    bool rec_valid = false;      // d_rec holds the current state
+    uint8_t *d_state = nullptr;  // byte plane, planes ze0..ze1-1 (lazy)
+    bool bytes_valid = false;    // d_state holds the current state
     uint8_t *owned() const { return d_state + (size_t)(z0 - ze0) * X * Y; }
+    int carve_seq = 0;           // parity of the undecided-list counters (carve_coarse_kernel)
+    size_t carve_layout = 0;     // d_coarse layout those counters were zeroed for
     void *d_timeline = nullptr;  // ARVX_TIMELINE diagnostic builds only
     int64_t timeline_n = 0;
     int timeline_rec = 32;  // bytes per record
-    bool fresh_pending = false;  // arvx_state_reset is lazy (arvx_capi.hip: materialize)
+    bool fresh_pending = false;  // a fresh model that exists only as this flag (neither form valid)
+    void *d_flood_rec = nullptr;  // records of the "carvable" plane of arvx_fast_carve
+    size_t flood_rec_bytes = 0;
     void *d_coarse = nullptr;    // coarse pre-pass masks of the carve kernel
     size_t coarse_bytes = 0;
     unsigned long long *d_stats = nullptr;

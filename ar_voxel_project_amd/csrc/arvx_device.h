@@ -31,8 +31,18 @@ constexpr int kMaxChunks = 4;       // split launch handles up to 256 views (els
 
 enum : int { kClsOut = 0, kClsFg = 1, kClsCarved = 2, kClsMixed = 3, kFastDiv = 4 };
 
+// State of the grid on the device: one 256-byte RECORD per sub-tile (16 x 8 x 8 voxels, the
+// unit one wave works on): uint16 occ[64] then uint16 seen[64], entry r = (z & 7) * 8 + (y & 7),
+// bit x & 15.  Records are ordered coarse tile > tile > sub-tile, so that everything the carve
+// writes as a unit is contiguous: a sub-tile is 256 B, a tile (64 x 8 x 8) 1 KB, a coarse
+// tile (64 x 32 x 32; striped slabs 64 x 64 x 8) 16 KB / 8 KB.  Voxels of a record that lie
+// outside the grid are kept at (occ 0, seen 1) -- "finished" for every test in the kernels.
+// 2 bits per voxel: N / 4 bytes.  The one-byte-per-voxel plane of the C-ABI
+// (arvx_state_upload / _download / _device_ptr) is converted from / to this form on demand.
+constexpr int kRecU16 = 128;  // uint16 per record
+
 struct CarveParams {
-    uint8_t *state;         // slab state plane
+    uint16_t *rec;          // slab state records (see above)
     const float *M;         // V x 12
     const uint32_t *bg;     // V x bgWords, bit = 1 where the mask pixel is background
     const int *sat;         // V x satStride, summed-area table of foreground pixels
@@ -55,6 +65,9 @@ struct CarveParams {
     unsigned long long *coarseMixed;  // [ncoarse][nchunks] views to re-classify per sub-tile
     unsigned long long *coarseFg;     // [ncoarse][nchunks] views that see only foreground
     uint8_t *coarseCarved;            // [ncoarse] 0 undecided, 1 carved, 2 all seen, 3 none seen
+    int *undecidedList;               // [ncoarse] coarse tiles carve_classify_kernel walks
+    int *undecidedCount;              // its length (this launch) ...
+    int *undecidedCountNext;          // ... and the counter the next launch will use
     // work lists of the split launch (carve_classify_kernel -> carve_exact_kernel)
     int *workCount;                 // [kWorkLists * kCounterStride] items per list
     int *poolNext;                  // [kPoolCounters * kCounterStride] tickets of the shared pool
@@ -67,6 +80,24 @@ struct CarveParams {
 // global z of local plane lz
 __device__ __forceinline__ int global_z(const CarveParams &p, int lz) {
     return p.zoff + (((lz >> 3) * p.zstride + p.zphase) << 3) + (lz & 7);
+}
+
+// record of sub-tile `wave` (x / 16 inside the tile) of tile (tx, ty, tz)
+__host__ __device__ __forceinline__ size_t rec_index(const CarveParams &p, int tx, int ty, int tz,
+                                                     int wave) {
+    const int ct = tx + p.coarseX * ((ty >> p.cyShift) + p.coarseY * (tz >> p.czShift));
+    const int tl = (ty & ((1 << p.cyShift) - 1)) | ((tz & ((1 << p.czShift) - 1)) << p.cyShift);
+    return ((((size_t)ct << (p.cyShift + p.czShift)) + tl) << 2) + wave;
+}
+__host__ __device__ __forceinline__ size_t rec_count(const CarveParams &p) {
+    return ((size_t)p.coarseX * p.coarseY * p.coarseZ) << (p.cyShift + p.czShift + 2);
+}
+// 4 bits -> bit 0 of 4 bytes, and back
+__device__ __forceinline__ uint32_t nibble_to_bytes(uint32_t nib) {
+    return (nib * 0x00204081u) & 0x01010101u;
+}
+__device__ __forceinline__ uint32_t bytes_to_nibble(uint32_t b) {  // b & 0x01010101 only
+    return (b * 0x01020408u) >> 24;
 }
 
 // (int)std::round(u) for u > -0.5 in ONE instruction: v_cvt_rpi_i32_f32 is floor(u + 1/2)
@@ -108,10 +139,23 @@ __device__ __forceinline__ bool pixel_from_quotients(float u, float v, int W, fl
 // Checked against `/` on random and adversarial operands in tests/test_carve_gpu.py.
 __device__ __forceinline__ void divide2_shared_rcp(float a0, float a1, float b, float &u,
                                                    float &v) {
+    // both quotients go through the same five steps: two-wide (v_pk_mul_f32 / v_pk_fma_f32 do
+    // two fp32 operations per lane and issue slot); element-wise identical to the scalar form
+    typedef float f2 __attribute__((ext_vector_type(2)));
     float r = __builtin_amdgcn_rcpf(b);
     const float nb = -b;
     const float e = fmaf(nb, r, 1.0f);
     r = fmaf(e, r, r);
+#ifndef ARVX_DIV_SCALAR
+    const f2 a = {a0, a1}, rr = {r, r}, nbb = {nb, nb};
+    f2 q = a * rr;
+    f2 t = __builtin_elementwise_fma(nbb, q, a);
+    q = __builtin_elementwise_fma(t, rr, q);
+    t = __builtin_elementwise_fma(nbb, q, a);
+    q = __builtin_elementwise_fma(t, rr, q);
+    u = q.x;
+    v = q.y;
+#else  // A/B: one quotient after the other
     float q = a0 * r;
     float t = fmaf(nb, q, a0);
     q = fmaf(t, r, q);
@@ -122,6 +166,7 @@ __device__ __forceinline__ void divide2_shared_rcp(float a0, float a1, float b, 
     q = fmaf(t, r, q);
     t = fmaf(nb, q, a1);
     v = fmaf(t, r, q);
+#endif
 }
 
 // Rounded pixel of one projected voxel (IEEE divides); a0,a1,a2 = fp32 row results.

@@ -142,6 +142,9 @@ __global__ __launch_bounds__(256) void carve_coarse_kernel(const CarveParams p) 
     if (blockIdx.x == 0 && p.workCount)
         for (int i = threadIdx.x; i < (kWorkLists + kPoolCounters) * kCounterStride; i += 256)
             p.workCount[i] = 0;  // poolNext follows workCount in the same allocation
+    // the length of the undecided list alternates between two counters: this launch appends
+    // to one (zeroed by the launch before) and zeroes the other for the next carve
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.undecidedCountNext) *p.undecidedCountNext = 0;
     const int ct = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int ncoarse = p.coarseX * p.coarseY * p.coarseZ;
@@ -176,8 +179,69 @@ __global__ __launch_bounds__(256) void carve_coarse_kernel(const CarveParams p) 
     }
     // 1: some view carves the whole tile.  2 / 3: no view needs a closer look and none
     // carves -- every voxel keeps its occupancy and is seen (2) or not even seen (3).
-    if (lane == 0)
-        p.coarseCarved[ct] = any_carved ? 1 : (any_mixed ? 0 : (any_fg ? 2 : 3));
+    if (lane == 0) {
+        const int code = any_carved ? 1 : (any_mixed ? 0 : (any_fg ? 2 : 3));
+        p.coarseCarved[ct] = (uint8_t)code;
+        // what carve_fill_kernel cannot settle with a constant goes on the list of
+        // carve_classify_kernel: undecided tiles, and -- on a model that is not fresh --
+        // the ones whose voxels keep their occupancy
+        if (p.undecidedList && (code == 0 || (code >= 2 && !(p.flags & 4u))))
+            p.undecidedList[atomicAdd(p.undecidedCount, 1)] = ct;
+    }
+}
+
+// in-grid voxels of entry r of sub-tile `wave` of tile (tx, ty, tz)
+__device__ __forceinline__ uint32_t row_inmask(const CarveParams &p, int tx, int ty, int tz,
+                                               int wave, int r) {
+    const int x0 = tx * kTileX + wave * kSubX;
+    const int y = ty * kTileY + (r & 7), z = tz * kTileZ + (r >> 3);
+    if (y >= p.Y || z >= p.Z || x0 >= p.X) return 0u;
+    const int nx = min(kSubX, p.X - x0);
+    return 0xffffu >> (kSubX - nx);
+}
+
+// Coarse tiles that the pre-pass decided are constant: carved + seen (code 1), or, for a
+// fresh model, untouched occupancy with (2) / without (3) the seen bit.  One workgroup writes
+// the coarse tile's records -- 16 KB in one piece (8 KB on striped slabs).
+__global__ __launch_bounds__(256) void carve_fill_kernel(const CarveParams p) {
+    const int ct = blockIdx.x;
+    // (flags bit4: every coarse tile as "untouched, not seen" -- a fresh model as records)
+    const int code = (p.flags & 16u) ? 3 : p.coarseCarved[ct];
+    if (!(code == 1 || (code >= 2 && (p.flags & 4u)))) return;
+    const int cx = ct % p.coarseX, cy = (ct / p.coarseX) % p.coarseY, cz = ct / (p.coarseX * p.coarseY);
+    const int tshift = p.cyShift + p.czShift;
+    uint4 *dst = reinterpret_cast<uint4 *>(p.rec + (((size_t)ct << (tshift + 2)) * kRecU16));
+    const int n16 = (kRecU16 * 2 / 16) << (tshift + 2);  // 16-byte pieces of the coarse tile
+    const bool inside = (cx + 1) * kCoarseX <= p.X && ((cy + 1) << (3 + p.cyShift)) <= p.Y &&
+                        ((cz + 1) << (3 + p.czShift)) <= p.Z;
+    for (int i = threadIdx.x; i < n16; i += 256) {
+        // piece i: record i / 16, half (i / 8) & 1 (occ, seen), entries 8 * (i & 7) ..
+        const bool seen_half = (i >> 3) & 1;
+        uint32_t w[4];
+        if (code == 1 || (inside && !(code == 3 && seen_half))) {
+            const uint32_t v = (code == 1) ? (seen_half ? 0xffffffffu : 0u) : 0xffffffffu;
+            w[0] = w[1] = w[2] = w[3] = v;
+        } else if (inside) {  // code 3, seen half of an interior tile: nothing seen
+            w[0] = w[1] = w[2] = w[3] = 0u;
+        } else {
+            const int rec = i >> 4, tl = rec >> 2, wave = rec & 3;
+            const int ty = (cy << p.cyShift) + (tl & ((1 << p.cyShift) - 1));
+            const int tz = (cz << p.czShift) + (tl >> p.cyShift);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t pair = 0;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t in = row_inmask(p, cx, ty, tz, wave, 8 * (i & 7) + 2 * k + h);
+                    // voxels outside the grid: occ 0, seen 1
+                    const uint32_t v = seen_half ? (code == 2 ? 0xffffu : (~in & 0xffffu)) : in;
+                    pair |= v << (16 * h);
+                }
+                w[k] = pair;
+            }
+        }
+        dst[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
 }
 
 #ifdef ARVX_TIMELINE  // diagnostic build only (tools/timeline.py): per-workgroup start/end
@@ -241,16 +305,83 @@ struct WaveTimeline {
 };
 #endif
 
-template <bool kAligned4>
+struct SubTile {
+    int sx0, sy0, sz0, sx1, sy1, sz1;  // voxel box (slab-local z)
+    int x, y, zb;                      // this lane's 4 x-voxels, its y, its first z
+    bool lane_ok;
+};
+
+__device__ __forceinline__ SubTile subtile_of(const CarveParams &p, int tx, int ty, int tz,
+                                              int wave, int lane) {
+    SubTile t;
+    t.sx0 = tx * kTileX + wave * kSubX;
+    t.sy0 = ty * kTileY;
+    t.sz0 = tz * kTileZ;
+    t.sx1 = min(t.sx0 + kSubX - 1, p.X - 1);
+    t.sy1 = min(t.sy0 + kTileY - 1, p.Y - 1);
+    t.sz1 = min(t.sz0 + kTileZ - 1, p.Z - 1);
+    t.x = t.sx0 + 4 * (lane & 3);
+    t.y = t.sy0 + ((lane >> 2) & 7);
+    t.zb = t.sz0 + 4 * (lane >> 5);
+    t.lane_ok = (t.x < p.X) && (t.y < p.Y);
+    return t;
+}
+
+// A sub-tile's record <-> the row-wise register form of the fused / row-mapped kernels:
+// st[k] = the four x-voxels (4 q .. 4 q + 3, q = lane & 3) of row (y, zb + k) as four
+// bytes, bit0 occupied, bit1 seen.
+__device__ __forceinline__ void subtile_load(const CarveParams &p, const SubTile &t,
+                                             const uint16_t *__restrict__ rec, int lane,
+                                             uint32_t st[4]) {
+    const int q = lane & 3, ry = (lane >> 2) & 7, rz0 = 4 * (lane >> 5);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (p.flags & 4u) {  // fresh model: all occupied, none seen; no load
+            const int z = t.zb + k;
+            uint32_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                w |= (uint32_t)((t.lane_ok && z < p.Z && t.x + j < p.X) ? 1u : 2u) << (8 * j);
+            st[k] = w;
+        } else {
+            const int r = (rz0 + k) * 8 + ry;
+            const uint32_t o = rec[r], sn = rec[64 + r];
+            st[k] = nibble_to_bytes((o >> (4 * q)) & 15u) | (nibble_to_bytes((sn >> (4 * q)) & 15u) << 1);
+        }
+    }
+}
+
+__device__ __forceinline__ void subtile_store(uint16_t *__restrict__ rec, int lane,
+                                              const uint32_t st[4]) {
+    const int q = lane & 3, ry = (lane >> 2) & 7, rz0 = 4 * (lane >> 5);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t o = bytes_to_nibble(st[k] & 0x01010101u) << (4 * q);
+        uint32_t sn = bytes_to_nibble((st[k] >> 1) & 0x01010101u) << (4 * q);
+        uint32_t both = o | (sn << 16);  // the four lanes of a row sit next to each other
+        both |= __shfl_xor(both, 1);
+        both |= __shfl_xor(both, 2);
+        if (q == 0) {
+            const int r = (rz0 + k) * 8 + ry;
+            rec[r] = (uint16_t)both;
+            rec[64 + r] = (uint16_t)(both >> 16);
+        }
+    }
+}
+
+// carved + seen, the whole sub-tile
+__device__ __forceinline__ void subtile_store_done(uint16_t *__restrict__ rec, int lane) {
+    reinterpret_cast<uint32_t *>(rec)[lane] = lane < 32 ? 0u : 0xffffffffu;
+}
+
 __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p) {
 #ifdef ARVX_TIMELINE
     TimelineScope timeline_scope(p.timeline);
 #endif
-    // Blocks b, b+8, b+16.. share an XCD (and its L2).  A row of tiles along x (one
-    // 8x8 bundle of voxel rows) stays on one XCD, so neighbouring 64-byte runs meet
-    // in one L2; rows are dealt to the 8 XCDs cyclically, which spreads the
-    // expensive surface tiles evenly (contiguous z ranges per XCD left the XCDs that
-    // own the empty top and bottom of the grid idle: +40 % on the sphere scene).
+    // Rows of tiles along x are dealt to the 8 XCDs cyclically (blocks b, b+8, b+16.. share
+    // an XCD), which spreads the expensive surface tiles evenly: contiguous z ranges per XCD
+    // left the XCDs that own the empty top and bottom of the grid idle (+40 % on the sphere
+    // scene).
     const unsigned k = blockIdx.x >> 3;
     const unsigned trow = (k / p.tilesX) * 8u + (blockIdx.x & 7u);
     if (trow >= (unsigned)(p.tilesY * p.tilesZ)) return;
@@ -265,20 +396,19 @@ __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p
         cull ? tx + p.coarseX * ((ty >> p.cyShift) + p.coarseY * (tz >> p.czShift)) : 0;
     const int code = cull ? p.coarseCarved[ct] : 0;  // workgroup-uniform (scalar load)
     const bool coarse_carved = code == 1;
-    // Pure fill of a 64x8x8 tile that the pre-pass decided: carved+seen (code 1), or,
-    // for a fresh model, untouched occupancy with (2) / without (3) the seen bit.
-    if (kAligned4 && (coarse_carved || (code >= 2 && (p.flags & 4u))) && (p.X & 15) == 0 &&
-        (tx + 1) * kTileX <= p.X) {
-        // One 16-byte store per thread, 4 lanes per 64-byte row, instead of the
-        // per-sub-tile layout's four dword stores per lane.
-        const uint32_t v4 = code == 1 ? kDone4 : (code == 2 ? 0x03030303u : 0x01010101u);
-        const int yy = ty * kTileY + ((threadIdx.x >> 2) & 7);
-        const int zz = tz * kTileZ + (threadIdx.x >> 5);
-        if (yy < p.Y && zz < p.Z) {
-            uint8_t *dst = p.state + ((size_t)zz * p.Y + yy) * p.X + tx * kTileX +
-                           16 * (threadIdx.x & 3);
-            *reinterpret_cast<uint4 *>(dst) = make_uint4(v4, v4, v4, v4);
+    uint16_t *const rec = p.rec + rec_index(p, tx, ty, tz, wave) * kRecU16;
+    // Pure fill of a tile that the pre-pass decided: carved+seen (code 1), or, for a fresh
+    // model, untouched occupancy with (2) / without (3) the seen bit.
+    if (coarse_carved || (code >= 2 && (p.flags & 4u))) {
+        uint32_t pair = 0;  // entries 2 * (lane & 31), + 1 of the occ (lane < 32) / seen half
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t in = row_inmask(p, tx, ty, tz, wave, 2 * (lane & 31) + h);
+            const uint32_t v = code == 1 ? (lane < 32 ? 0u : 0xffffu)
+                                         : (lane < 32 ? in : (code == 2 ? 0xffffu : (~in & 0xffffu)));
+            pair |= v << (16 * h);
         }
+        reinterpret_cast<uint32_t *>(rec)[lane] = pair;
         if ((p.flags & 2u) && lane == 0) {
             atomicAdd(&p.stats[0], 1ull);
             if (coarse_carved) atomicAdd(&p.stats[1], 1ull);
@@ -296,7 +426,6 @@ __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p
     const int x = sx0 + 4 * (lane & 3);
     const int y = sy0 + ((lane >> 2) & 7);
     const int zb = sz0 + 4 * (lane >> 5);
-    const bool lane_ok = (x < p.X) && (y < p.Y);
 
     // per-lane world coordinates, reference src/Model.h:134-140
     const double dwy = (double)((float)y * p.s);
@@ -308,8 +437,6 @@ __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p
 
     uint32_t st[4] = {kDone4, kDone4, kDone4, kDone4};
     bool loaded = false, all_carved = false, all_done = false;
-    const size_t row = (size_t)p.X;
-    const size_t plane = (size_t)p.X * p.Y;
     if (coarse_carved) {
         all_carved = true;
         if ((p.flags & 2u) && lane == 0) {
@@ -355,28 +482,7 @@ __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p
         }
         if (!loaded) {
             loaded = true;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int z = zb + k;
-                if (lane_ok && z < p.Z) {
-                    const uint8_t *src = p.state + (size_t)z * plane + (size_t)y * row + x;
-                    if (p.flags & 4u) {  // fresh model: all occupied, none seen; no load
-                        uint32_t w = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            w |= (uint32_t)((x + j < p.X) ? 1u : 2u) << (8 * j);
-                        st[k] = w;
-                    } else if (kAligned4) {
-                        st[k] = *reinterpret_cast<const uint32_t *>(src);
-                    } else {
-                        uint32_t w = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            w |= (uint32_t)((x + j < p.X) ? src[j] : (uint8_t)2) << (8 * j);
-                        st[k] = w;
-                    }
-                }
-            }
+            subtile_load(p, subtile_of(p, tx, ty, tz, wave, lane), rec, lane, st);
         }
         if (infg) {
 #pragma unroll
@@ -457,24 +563,9 @@ __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p
     }
 
     if (all_carved) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) st[k] = kDone4;
-    } else if (!loaded) {
-        return;  // empty view range: nothing changed
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int z = zb + k;
-        if (lane_ok && z < p.Z) {
-            uint8_t *dst = p.state + (size_t)z * plane + (size_t)y * row + x;
-            if (kAligned4) {
-                *reinterpret_cast<uint32_t *>(dst) = st[k];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (x + j < p.X) dst[j] = (uint8_t)(st[k] >> (8 * j));
-            }
-        }
+        subtile_store_done(rec, lane);
+    } else if (loaded) {  // (else: empty view range, nothing changed)
+        subtile_store(rec, lane, st);
     }
 }
 
@@ -490,213 +581,133 @@ __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p
 // phases (profiles/r1_kernel_v5: 34 % VALU-active at 512^3).
 // ---------------------------------------------------------------------------------
 
-struct SubTile {
-    int sx0, sy0, sz0, sx1, sy1, sz1;  // voxel box (slab-local z)
-    int x, y, zb;                      // this lane's 4 x-voxels, its y, its first z
-    bool lane_ok;
-};
-
-__device__ __forceinline__ SubTile subtile_of(const CarveParams &p, int tx, int ty, int tz,
-                                              int wave, int lane) {
-    SubTile t;
-    t.sx0 = tx * kTileX + wave * kSubX;
-    t.sy0 = ty * kTileY;
-    t.sz0 = tz * kTileZ;
-    t.sx1 = min(t.sx0 + kSubX - 1, p.X - 1);
-    t.sy1 = min(t.sy0 + kTileY - 1, p.Y - 1);
-    t.sz1 = min(t.sz0 + kTileZ - 1, p.Z - 1);
-    t.x = t.sx0 + 4 * (lane & 3);
-    t.y = t.sy0 + ((lane >> 2) & 7);
-    t.zb = t.sz0 + 4 * (lane >> 5);
-    t.lane_ok = (t.x < p.X) && (t.y < p.Y);
-    return t;
-}
-
-template <bool kAligned4>
-__device__ __forceinline__ void subtile_load(const CarveParams &p, const SubTile &t,
-                                             uint32_t st[4]) {
-    const size_t row = (size_t)p.X, plane = (size_t)p.X * p.Y;
+// The whole record of a sub-tile from constants: occ = the voxels inside the grid (or none),
+// seen = all (voxels outside the grid always count as seen) or only those outside.
+__device__ __forceinline__ void subtile_store_const(const CarveParams &p, uint16_t *__restrict__ rec,
+                                                    int lane, int tx, int ty, int tz, int wave,
+                                                    bool occupied, bool seen) {
+    uint32_t pair = 0;  // entries 2 * (lane & 31), + 1 of the occ (lane < 32) / seen half
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        st[k] = kDone4;  // lanes / voxels outside the grid count as finished
-        const int z = t.zb + k;
-        if (t.lane_ok && z < p.Z) {
-            const uint8_t *src = p.state + (size_t)z * plane + (size_t)t.y * row + t.x;
-            if (p.flags & 4u) {  // fresh model: all occupied, none seen; no load
-                uint32_t w = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    w |= (uint32_t)((t.x + j < p.X) ? 1u : 2u) << (8 * j);
-                st[k] = w;
-            } else if (kAligned4) {
-                st[k] = *reinterpret_cast<const uint32_t *>(src);
-            } else {
-                uint32_t w = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    w |= (uint32_t)((t.x + j < p.X) ? src[j] : (uint8_t)2) << (8 * j);
-                st[k] = w;
-            }
-        }
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t in = row_inmask(p, tx, ty, tz, wave, 2 * (lane & 31) + h);
+        const uint32_t v = lane < 32 ? (occupied ? in : 0u) : (seen ? 0xffffu : (~in & 0xffffu));
+        pair |= v << (16 * h);
     }
+    reinterpret_cast<uint32_t *>(rec)[lane] = pair;
 }
 
-template <bool kAligned4>
-__device__ __forceinline__ void subtile_store(const CarveParams &p, const SubTile &t,
-                                              const uint32_t st[4]) {
-    const size_t row = (size_t)p.X, plane = (size_t)p.X * p.Y;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int z = t.zb + k;
-        if (t.lane_ok && z < p.Z) {
-            uint8_t *dst = p.state + (size_t)z * plane + (size_t)t.y * row + t.x;
-            if (kAligned4) {
-                *reinterpret_cast<uint32_t *>(dst) = st[k];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (t.x + j < p.X) dst[j] = (uint8_t)(st[k] >> (8 * j));
-            }
-        }
-    }
-}
-
-// (Tried and dropped, 1024^3: the pure fill as a kernel of its own with a few fat
-// workgroups -- alone it reaches twice the write rate of the fill branch below, but after
-// it the classification still takes 190 us by itself (it is bound by arithmetic, and the
-// branch's stores hide under it: 311 us together); run beside the classification on a
-// second stream, both slow down (388 us): the classification lives on memory latency too.
-// A fixed grid walking a compacted list of the undecided tiles classifies them in 127 us,
-// but fill (227 us as a row-walking kernel) + list + classification is still more than
-// the 311 us of this kernel, in which the stores hide under the classification.  Four tiles
-// along x per workgroup (a quarter of the launches, whole 256-byte lines per fill store):
-// 399 us -- the kernel is not bound by its launches but by the ~5 us chain of dependent reads
-// of every undecided sub-tile at 8 waves per SIMD, and fatter workgroups lengthen that chain.)
-template <bool kAligned4>
+// Sub-tile classification of the coarse tiles carve_fill_kernel could not settle, taken
+// from the list the pre-pass wrote: a fixed grid of workgroups, one tile (four sub-tiles,
+// one per wave) per turn.  46 VGPRs -> 8 waves per SIMD: the work is a chain of dependent
+// reads per sub-tile (coarse masks + matrix -> summed-area entries -> store).
+// (Round 1 launched one workgroup per tile of the whole grid and filled the decided tiles
+// from here, 16 bytes per thread into the byte plane: two million workgroups at 1024^3,
+// 297 us of which the fill stores were the larger part.)
 __global__ __launch_bounds__(256, 8) void carve_classify_kernel(const CarveParams p) {
-    // Rows of tiles (along x) are dealt to the XCDs as in carve_fused_kernel, but the tile
-    // comes straight from a 3-D block index: grid (8 * tilesX, ceil(tilesY / 8), tilesZ), the
-    // dispatcher walks x fastest and hands consecutive workgroups to consecutive XCDs, so
-    // blockIdx.x & 7 is the XCD and the eight rows ty = 8 * blockIdx.y + 0..7 run side by side.
-    // (With a flat index every wave spent ~100 scalar instructions on two integer divisions;
-    // a million one-store fill waves at 1024^3 kept the scalar units busy for longer than
-    // the stores take.)
-    const int tx = (int)(blockIdx.x >> 3);
-    const int ty = (int)(blockIdx.y * 8u + (blockIdx.x & 7u));
-    const int tz = (int)blockIdx.z;
-    if (ty >= p.tilesY) return;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    const int ct = tx + p.coarseX * ((ty >> p.cyShift) + p.coarseY * (tz >> p.czShift));
-    const int code = p.coarseCarved[ct];
-    if (kAligned4 && (code == 1 || (code >= 2 && (p.flags & 4u))) && (p.X & 15) == 0 &&
-        (tx + 1) * kTileX <= p.X) {  // pure fill, as in carve_fused_kernel
-        const uint32_t v4 = code == 1 ? kDone4 : (code == 2 ? 0x03030303u : 0x01010101u);
-        const int yy = ty * kTileY + ((threadIdx.x >> 2) & 7);
-        const int zz = tz * kTileZ + (threadIdx.x >> 5);
-        if (yy < p.Y && zz < p.Z) {
-            uint8_t *dst = p.state + ((size_t)zz * p.Y + yy) * p.X + tx * kTileX +
-                           16 * (threadIdx.x & 3);
-            *reinterpret_cast<uint4 *>(dst) = make_uint4(v4, v4, v4, v4);
+    const int tshift = p.cyShift + p.czShift;
+    const int ntiles = __builtin_amdgcn_readfirstlane(*p.undecidedCount) << tshift;
+    for (int i = blockIdx.x; i < ntiles; i += gridDim.x) {
+        const int ct = p.undecidedList[i >> tshift];
+        const int tl = i & ((1 << tshift) - 1);
+        const int tx = ct % p.coarseX;
+        const int ty = (((ct / p.coarseX) % p.coarseY) << p.cyShift) + (tl & ((1 << p.cyShift) - 1));
+        const int tz = ((ct / (p.coarseX * p.coarseY)) << p.czShift) + (tl >> p.cyShift);
+        // (tiles and sub-tiles of an edge coarse tile that lie outside the grid keep the
+        // "finished" records they were allocated with)
+        if (ty >= p.tilesY || tz >= p.tilesZ || tx * kTileX + wave * kSubX >= p.X) continue;
+        const SubTile t = subtile_of(p, tx, ty, tz, wave, lane);
+        uint16_t *const rec = p.rec + rec_index(p, tx, ty, tz, wave) * kRecU16;
+        const BoxW box = make_box(p.s, t.sx0, t.sx1, t.sy0, t.sy1, global_z(p, t.sz0),
+                                  global_z(p, t.sz1));
+        bool any_carved = false, any_fg = false, any_mixed = false;
+        unsigned long long mixed_c[kMaxChunks], fast_c[kMaxChunks];
+#pragma unroll
+        for (int chunk = 0; chunk < kMaxChunks; ++chunk) {  // unrolled: the arrays stay in SGPRs
+            mixed_c[chunk] = fast_c[chunk] = 0;
+            const int vc = p.v0 + 64 * chunk;
+            if (vc >= p.v1 || any_carved) continue;
+            const int myv = vc + lane;
+            int cls = kClsOut;
+            if (myv < p.v1) {
+                const unsigned long long cm = p.coarseMixed[(size_t)ct * p.nchunks + chunk];
+                const unsigned long long cf = p.coarseFg[(size_t)ct * p.nchunks + chunk];
+                // (one value from both words: their loads go out together, not one per branch)
+                unsigned sel =
+                    (unsigned)((cf >> lane) & 1ull) | ((unsigned)((cm >> lane) & 1ull) << 1);
+                // the lane's matrix is requested together with the masks, not after them
+                float Mr[12];
+                const float4 *Mp = reinterpret_cast<const float4 *>(p.M + 12 * myv);
+                float4 m0 = Mp[0], m1 = Mp[1], m2 = Mp[2];
+                // (or the compiler moves every load back behind the branch that needs it)
+                asm volatile("" : "+v"(sel), "+v"(m0.x), "+v"(m1.x), "+v"(m2.x));
+                Mr[0] = m0.x; Mr[1] = m0.y; Mr[2] = m0.z; Mr[3] = m0.w;
+                Mr[4] = m1.x; Mr[5] = m1.y; Mr[6] = m1.z; Mr[7] = m1.w;
+                Mr[8] = m2.x; Mr[9] = m2.y; Mr[10] = m2.z; Mr[11] = m2.w;
+                if (sel & 1u)
+                    cls = kClsFg;  // inherited: the coarse rectangle contains this one
+                else if (sel & 2u)
+                    cls = classify_box(Mr, box, p.W, p.H, p.sat + (size_t)myv * p.satStride);
+            }
+            fast_c[chunk] = __ballot((cls & kFastDiv) != 0);
+            cls &= 3;
+            mixed_c[chunk] = __ballot(cls == kClsMixed);
+            any_carved = __ballot(cls == kClsCarved) != 0;
+            any_fg = any_fg || __ballot(cls == kClsFg) != 0;
+            any_mixed = any_mixed || mixed_c[chunk] != 0;
+            if ((p.flags & 2u) && lane == 0) {
+                atomicAdd(&p.stats[2], (unsigned long long)__popcll(mixed_c[chunk]));
+                atomicAdd(&p.stats[3], (unsigned long long)min(64, p.v1 - vc));
+            }
         }
         if ((p.flags & 2u) && lane == 0) {
             atomicAdd(&p.stats[0], 1ull);
-            if (code == 1) atomicAdd(&p.stats[1], 1ull);
+            if (any_carved) atomicAdd(&p.stats[1], 1ull);
         }
-        return;
-    }
-    if (tx * kTileX + wave * kSubX >= p.X) return;  // wave-uniform
-    const SubTile t = subtile_of(p, tx, ty, tz, wave, lane);
-    const BoxW box = make_box(p.s, t.sx0, t.sx1, t.sy0, t.sy1, global_z(p, t.sz0),
-                              global_z(p, t.sz1));
-    bool any_carved = code == 1, any_fg = false, any_mixed = false;
-    unsigned long long mixed_c[kMaxChunks], fast_c[kMaxChunks];
-#pragma unroll
-    for (int chunk = 0; chunk < kMaxChunks; ++chunk) {  // unrolled: the arrays stay in SGPRs
-        mixed_c[chunk] = fast_c[chunk] = 0;
-        const int vc = p.v0 + 64 * chunk;
-        if (vc >= p.v1 || any_carved) continue;
-        const int myv = vc + lane;
-        int cls = kClsOut;
-        if (myv < p.v1) {
-            const unsigned long long cm = p.coarseMixed[(size_t)ct * p.nchunks + chunk];
-            const unsigned long long cf = p.coarseFg[(size_t)ct * p.nchunks + chunk];
-            // (one value from both words: their loads go out together, not one per branch)
-            unsigned sel = (unsigned)((cf >> lane) & 1ull) | ((unsigned)((cm >> lane) & 1ull) << 1);
-            // the lane's matrix is requested together with the masks, not after them
-            float Mr[12];
-            const float4 *Mp = reinterpret_cast<const float4 *>(p.M + 12 * myv);
-            float4 m0 = Mp[0], m1 = Mp[1], m2 = Mp[2];
-            // (or the compiler moves every load back behind the branch that needs it)
-            asm volatile("" : "+v"(sel), "+v"(m0.x), "+v"(m1.x), "+v"(m2.x));
-            Mr[0] = m0.x; Mr[1] = m0.y; Mr[2] = m0.z; Mr[3] = m0.w;
-            Mr[4] = m1.x; Mr[5] = m1.y; Mr[6] = m1.z; Mr[7] = m1.w;
-            Mr[8] = m2.x; Mr[9] = m2.y; Mr[10] = m2.z; Mr[11] = m2.w;
-            if (sel & 1u)
-                cls = kClsFg;  // inherited: the coarse rectangle contains this one
-            else if (sel & 2u)
-                cls = classify_box(Mr, box, p.W, p.H, p.sat + (size_t)myv * p.satStride);
+        const bool fresh = p.flags & 4u;
+        if (any_carved) {  // carved implies seen (src/VoxelCarving.cpp:50-54): no load needed
+            subtile_store_done(rec, lane);
+        } else if (!any_mixed) {
+            // no view needs a closer look and none carves: occupancy stays, and every voxel is
+            // seen if some view sees the whole box (src/VoxelCarving.cpp:54)
+            if (fresh)
+                subtile_store_const(p, rec, lane, tx, ty, tz, wave, true, any_fg);
+            else if (any_fg && lane >= 32)
+                reinterpret_cast<uint32_t *>(rec)[lane] = 0xffffffffu;  // the seen half
+        } else if ((p.flags & 12u) == 12u) {
+            // the exact kernel may hand this sub-tile to several waves that merge their
+            // results with atomics: the record must hold the sub-tile's initial state (a fresh
+            // model exists only as a flag until now)
+            subtile_store_const(p, rec, lane, tx, ty, tz, wave, true, false);
         }
-        fast_c[chunk] = __ballot((cls & kFastDiv) != 0);
-        cls &= 3;
-        mixed_c[chunk] = __ballot(cls == kClsMixed);
-        any_carved = __ballot(cls == kClsCarved) != 0;
-        any_fg = any_fg || __ballot(cls == kClsFg) != 0;
-        any_mixed = any_mixed || mixed_c[chunk] != 0;
-        if ((p.flags & 2u) && lane == 0) {
-            atomicAdd(&p.stats[2], (unsigned long long)__popcll(mixed_c[chunk]));
-            atomicAdd(&p.stats[3], (unsigned long long)min(64, p.v1 - vc));
+        if (!any_carved && any_mixed && lane == 0) {
+            // hand the sub-tile to the exact kernel: where it is, whether some view sees
+            // all of it, and per chunk of 64 views which ones to evaluate (and how to divide).
+            // Eight weight classes of eight lists, the longest items (most views to evaluate)
+            // first: the waves start on those, and what the kernel ends on are the short ones;
+            // consecutive sub-tiles go to consecutive lists of their class.
+            int nmixed = 0;
+#pragma unroll
+            for (int c = 0; c < kMaxChunks; ++c)
+                if (c < p.nchunks) nmixed += __popcll(mixed_c[c]);
+            const int wclass = 7 - min(7, nmixed * 8 / (p.v1 - p.v0 + 1));
+            // (numbered over the tiles of the grid, not over the list: the host sizes a list
+            // for every 8th sub-tile of the grid)
+            const int cls =
+                wclass * 8 + (((((tz * p.tilesY + ty) * p.tilesX + tx) << 2) + wave) & 7);
+            const int pos = atomicAdd(&p.workCount[cls * kCounterStride], 1);
+            const size_t it = (size_t)cls * p.workCap + pos;
+            p.itemInfo[it] = (unsigned long long)tx | ((unsigned long long)ty << 16) |
+                             ((unsigned long long)tz << 32) | ((unsigned long long)wave << 48) |
+                             ((unsigned long long)(any_fg ? 1 : 0) << 50);
+#pragma unroll
+            for (int c = 0; c < kMaxChunks; ++c)
+                if (c < p.nchunks) {
+                    p.itemMasks[(it * p.nchunks + c) * 2] = mixed_c[c];
+                    p.itemMasks[(it * p.nchunks + c) * 2 + 1] = fast_c[c];
+                }
         }
-    }
-    if ((p.flags & 2u) && lane == 0) {
-        atomicAdd(&p.stats[0], 1ull);
-        if (any_carved) atomicAdd(&p.stats[1], 1ull);
-    }
-    uint32_t st[4];
-    if (any_carved) {  // carved implies seen (src/VoxelCarving.cpp:50-54): no load needed
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) st[kk] = kDone4;
-        subtile_store<kAligned4>(p, t, st);
-    } else if (!any_mixed) {
-        subtile_load<kAligned4>(p, t, st);
-        if (any_fg) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) st[kk] |= kDone4;  // seen, src/VoxelCarving.cpp:54
-        }
-        subtile_store<kAligned4>(p, t, st);
-    } else if ((p.flags & 12u) == 12u) {
-        // the exact kernel may hand this sub-tile to several waves that merge their results
-        // with atomics: the plane must hold the sub-tile's initial state (a fresh model exists
-        // only as a flag until now)
-        subtile_load<kAligned4>(p, t, st);
-        subtile_store<kAligned4>(p, t, st);
-    }
-    if (!any_carved && any_mixed && lane == 0) {
-        // hand the sub-tile to carve_exact_kernel: where it is, whether some view sees
-        // all of it, and per chunk of 64 views which ones to evaluate (and how to divide)
-        // spread the sub-tiles evenly: with the list taken from the block index the lists
-        // of some tile rows hold most of the surface and the others are empty from the start
-        // (consecutive sub-tiles go to consecutive lists: no list can get more than its
-        // share of all sub-tiles, which is what the host sizes the lists for)
-        // Eight weight classes of eight lists, the longest items (most views to evaluate)
-        // first: the waves start on those, and what the kernel ends on are the short ones.
-        int nmixed = 0;
-#pragma unroll
-        for (int c = 0; c < kMaxChunks; ++c)
-            if (c < p.nchunks) nmixed += __popcll(mixed_c[c]);
-        const int wclass = 7 - min(7, nmixed * 8 / (p.v1 - p.v0 + 1));
-        const int cls = wclass * 8 + (((((tz * p.tilesY + ty) * p.tilesX + tx) << 2) + wave) & 7);
-        const int pos = atomicAdd(&p.workCount[cls * kCounterStride], 1);
-        const size_t it = (size_t)cls * p.workCap + pos;
-        p.itemInfo[it] = (unsigned long long)tx | ((unsigned long long)ty << 16) |
-                         ((unsigned long long)tz << 32) | ((unsigned long long)wave << 48) |
-                         ((unsigned long long)(any_fg ? 1 : 0) << 50);
-#pragma unroll
-        for (int c = 0; c < kMaxChunks; ++c)
-            if (c < p.nchunks) {
-                p.itemMasks[(it * p.nchunks + c) * 2] = mixed_c[c];
-                p.itemMasks[(it * p.nchunks + c) * 2 + 1] = fast_c[c];
-            }
     }
 }
 
@@ -894,7 +905,6 @@ __device__ __forceinline__ void for_each_work_item(const CarveParams &p, const i
     }
 }
 
-template <bool kAligned4>
 __global__ __launch_bounds__(256, 4) void carve_exact_kernel(const CarveParams p) {
 #ifdef ARVX_TIMELINE
     WaveTimeline wave_timeline(p.timeline);
@@ -913,8 +923,9 @@ __global__ __launch_bounds__(256, 4) void carve_exact_kernel(const CarveParams p
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 dwz[k] = (double)((float)(-global_z(p, t.zb + k)) * p.s);
+            uint16_t *const rec = p.rec + rec_index(p, tx, ty, tz, wave) * kRecU16;
             uint32_t st[4];
-            subtile_load<kAligned4>(p, t, st);
+            subtile_load(p, t, rec, lane, st);
             if ((info >> 50) & 1ull) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) st[k] |= kDone4;  // seen by an all-foreground view
@@ -936,7 +947,7 @@ __global__ __launch_bounds__(256, 4) void carve_exact_kernel(const CarveParams p
 #ifdef ARVX_TIMELINE
             wave_timeline.item_done();
 #endif
-            subtile_store<kAligned4>(p, t, st);
+            subtile_store(rec, lane, st);
     });
 }
 
@@ -951,6 +962,14 @@ __global__ __launch_bounds__(256, 4) void carve_exact_kernel(const CarveParams p
 // whole (512^3 sphere scene: 31 % fewer voxels go through the projection).
 // The state plane is still read and written with the row-wise map (4-byte accesses);
 // the bytes change lanes through 1 KB of LDS per wave, once per sub-tile each way.
+
+// bits 0, 4, 8, 12 <-> bit 0 of the four bytes
+__device__ __forceinline__ uint32_t spread4(uint32_t t) {
+    return (t & 1u) | ((t & 0x10u) << 4) | ((t & 0x100u) << 8) | ((t & 0x1000u) << 12);
+}
+__device__ __forceinline__ uint32_t gather4(uint32_t b) {
+    return (b & 1u) | ((b >> 4) & 0x10u) | ((b >> 8) & 0x100u) | ((b >> 12) & 0x1000u);
+}
 
 __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
@@ -1109,25 +1128,17 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
     return __all(st[0] == kDone4 && st[1] == kDone4 && st[2] == kDone4 && st[3] == kDone4);
 }
 
-template <bool kAligned4>
 __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveParams p) {
 #ifdef ARVX_TIMELINE
     WaveTimeline wave_timeline(p.timeline);
 #endif
-    __shared__ uint32_t xpose[4][256];  // one sub-tile of state bytes per wave, [z][y][x]
     const int lane = threadIdx.x & 63;
-    uint32_t *buf = xpose[threadIdx.x >> 6];
-    uint8_t *buf8 = reinterpret_cast<uint8_t *>(buf);
-    // row-wise map (subtile_of): 4 x-voxels, one y, 4 z per lane
-    const int rowSlot = ((4 * (lane >> 5)) * 8 + ((lane >> 2) & 7)) * 4 + (lane & 3);  // + 32 k
     // block map: one voxel per block
     const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
-    // every fourth workgroup starts with the fill and joins the exact work afterwards;
-    // the others end with whatever is left of the fill
     // (Tried and dropped: leaving the pure fill of the decided tiles to a quarter of these
     // workgroups so that it overlaps the exact work -- the fill saturates HBM and the
     // exact waves, which live on memory latency, slow down by more than the fill costs.)
-    for_each_work_item<kAligned4>(p, lane, blockIdx.x * 4 + (threadIdx.x >> 6), p.nwaves,
+    for_each_work_item<true>(p, lane, blockIdx.x * 4 + (threadIdx.x >> 6), p.nwaves,
                           [&](const size_t it, const int part, const int list, const int pshift) {
             // the kernel ends on its longest items (an item's views run one after the other):
             // the items of the heavy weight classes get the SIMD's issue slots first
@@ -1150,26 +1161,38 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
             const int tx = (int)(info & 0xffffu), ty = (int)((info >> 16) & 0xffffu);
             const int tz = (int)((info >> 32) & 0xffffu), wave = (int)((info >> 48) & 3u);
             const SubTile t = subtile_of(p, tx, ty, tz, wave, lane);
+            uint16_t *const rec = p.rec + rec_index(p, tx, ty, tz, wave) * kRecU16;
+            // record -> blocks.  st[byi * 2 + bzi] byte j = voxel (4 j + lx, 4 byi + ly,
+            // 4 bzi + lz) of the sub-tile, bit0 occupied, bit1 seen: the lane reads the two
+            // 16-bit entries of its four rows (y, z) and keeps bits lx, 4 + lx, 8 + lx, 12 + lx.
+            const bool fg_seen = (info >> 50) & 1ull;  // seen by an all-foreground view
             uint32_t st[4];
-            subtile_load<kAligned4>(p, t, st);
-            if ((info >> 50) & 1ull) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) st[k] |= kDone4;  // seen by an all-foreground view
-            }
-            // rows -> blocks
-#pragma unroll
-            for (int k = 0; k < 4; ++k) buf[rowSlot + 32 * k] = st[k];
-            wave_lds_sync();
 #pragma unroll
             for (int byi = 0; byi < 2; ++byi)
 #pragma unroll
                 for (int bzi = 0; bzi < 2; ++bzi) {
-                    uint32_t w = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        w |= (uint32_t)buf8[((4 * bzi + lz) * 8 + 4 * byi + ly) * 16 + 4 * j + lx]
-                             << (8 * j);
-                    st[2 * byi + bzi] = w;
+                    const int r = (4 * bzi + lz) * 8 + 4 * byi + ly;
+                    uint32_t o, sn;
+                    if (p.flags & 4u) {  // fresh model, never written: all occupied, none seen
+                        o = row_inmask(p, tx, ty, tz, wave, r);
+                        sn = ~o & 0xffffu;
+                    } else if (pshift) {
+                        // other parts of this item update the record with device-scope atomics
+                        // while this one reads it, possibly from another XCD: a plain load
+                        // would leave a copy of the line in this XCD's L2 for the atomics that
+                        // follow to hit (each XCD has its own L2) -- read it the same way
+                        const uint32_t *w32 = reinterpret_cast<const uint32_t *>(rec);
+                        const int sh = 16 * (r & 1);
+                        o = (__hip_atomic_load(w32 + (r >> 1), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT) >> sh) & 0xffffu;
+                        sn = (__hip_atomic_load(w32 + 32 + (r >> 1), __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT) >> sh) & 0xffffu;
+                    } else {
+                        o = rec[r];
+                        sn = rec[64 + r];
+                    }
+                    if (fg_seen) sn = 0xffffu;
+                    st[2 * byi + bzi] = spread4((o >> lx) & 0x1111u) | (spread4((sn >> lx) & 0x1111u) << 1);
                 }
             // world coordinates as the reference's toWord gives them (fp32); widened to
             // double where the products are formed
@@ -1206,39 +1229,35 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
             wave_timeline.item_done();
             wave_timeline.tick(2);
 #endif
-            // blocks -> rows
-            wave_lds_sync();
+            // blocks -> record: a row's 16 bits sit in the four neighbouring lanes lx = 0..3,
+            // four bits each; lane lx = 0 writes the row's two entries
 #pragma unroll
             for (int byi = 0; byi < 2; ++byi)
 #pragma unroll
-                for (int bzi = 0; bzi < 2; ++bzi)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        buf8[((4 * bzi + lz) * 8 + 4 * byi + ly) * 16 + 4 * j + lx] =
-                            (uint8_t)(st[2 * byi + bzi] >> (8 * j));
-            wave_lds_sync();
-#pragma unroll
-            for (int k = 0; k < 4; ++k) st[k] = buf[rowSlot + 32 * k];
-            wave_lds_sync();
-            if (kAligned4 && pshift) {
-                // the parts of an item carve (clear bit0) and see (set bit1) independently:
-                // both are monotone, so the order in which they reach the plane is irrelevant
-                const size_t row = (size_t)p.X, plane = (size_t)p.X * p.Y;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int z = t.zb + k;
-                    if (t.lane_ok && z < p.Z) {
-                        uint32_t *dst = reinterpret_cast<uint32_t *>(
-                            p.state + (size_t)z * plane + (size_t)t.y * row + t.x);
-                        (void)__hip_atomic_fetch_and(dst, st[k] | 0xfefefefeu, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-                        (void)__hip_atomic_fetch_or(dst, st[k] & 0x02020202u, __ATOMIC_RELAXED,
-                                                    __HIP_MEMORY_SCOPE_AGENT);
+                for (int bzi = 0; bzi < 2; ++bzi) {
+                    const uint32_t w = st[2 * byi + bzi];
+                    uint32_t both = (gather4(w & 0x01010101u) << lx) |
+                                    (gather4((w >> 1) & 0x01010101u) << (16 + lx));
+                    both |= __shfl_xor(both, 1);
+                    both |= __shfl_xor(both, 2);
+                    if (lx != 0) continue;
+                    const int r = (4 * bzi + lz) * 8 + 4 * byi + ly;
+                    if (pshift) {
+                        // the parts of an item carve (clear occ) and see (set seen)
+                        // independently: both are monotone, so the order in which they reach
+                        // the record is irrelevant
+                        uint32_t *w32 = reinterpret_cast<uint32_t *>(rec);
+                        const int sh = 16 * (r & 1);
+                        (void)__hip_atomic_fetch_and(w32 + (r >> 1),
+                                                     ((both & 0xffffu) << sh) | ~(0xffffu << sh),
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        (void)__hip_atomic_fetch_or(w32 + 32 + (r >> 1), (both >> 16) << sh,
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        rec[r] = (uint16_t)both;
+                        rec[64 + r] = (uint16_t)(both >> 16);
                     }
                 }
-            } else {
-                subtile_store<kAligned4>(p, t, st);
-            }
 #ifdef ARVX_TIMELINE
             wave_timeline.tick(3);
 #endif

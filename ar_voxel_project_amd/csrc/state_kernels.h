@@ -1,0 +1,91 @@
+// state_kernels.h -- conversions between the device's state records (arvx_device.h: 2 bits per
+// voxel, one 256-byte record per 16 x 8 x 8 sub-tile) and the forms the C-ABI and the other
+// stages exchange: the one-byte-per-voxel plane (bit0 occupied, bit1 seen; arvx_state_upload /
+// _download / _device_ptr) and the flat packed occupancy (voxel i -> bit i % 32 of word i / 32;
+// arvx_pack_occupancy[_global]).
+#pragma once
+
+#include "arvx_device.h"
+#include "carve_kernels.h"
+
+namespace arvx {
+
+// every record "finished" (occ 0, seen 1): what the voxels outside the grid keep for ever
+__global__ __launch_bounds__(256) void rec_init_kernel(uint32_t *__restrict__ rec32, size_t nwords) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += stride)
+        rec32[i] = (i & 32) ? 0xffffffffu : 0u;  // 32 words occ, 32 words seen
+}
+
+// one workgroup per tile, one wave per sub-tile, lane = entry r = (z & 7) * 8 + (y & 7)
+__global__ __launch_bounds__(256) void rec_from_bytes_kernel(const CarveParams p,
+                                                             const uint8_t *__restrict__ bytes) {
+    const int tx = blockIdx.x % p.tilesX, ty = (blockIdx.x / p.tilesX) % p.tilesY,
+              tz = blockIdx.x / (p.tilesX * p.tilesY);
+    const int wave = threadIdx.x >> 6, r = threadIdx.x & 63;
+    const int x0 = tx * kTileX + wave * kSubX, y = ty * kTileY + (r & 7), z = tz * kTileZ + (r >> 3);
+    uint32_t occ = 0, seen = 0xffffu;
+    if (x0 < p.X && y < p.Y && z < p.Z) {
+        const uint8_t *src = bytes + ((size_t)z * p.Y + y) * p.X + x0;
+        uint8_t b[16];
+        if ((p.X & 15) == 0 && ((uintptr_t)bytes & 15u) == 0) {
+            *reinterpret_cast<uint4 *>(b) = *reinterpret_cast<const uint4 *>(src);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) b[j] = (x0 + j < p.X) ? src[j] : (uint8_t)2;
+        }
+        seen = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            occ |= (uint32_t)(b[j] & 1u) << j;
+            seen |= (uint32_t)((b[j] >> 1) & 1u) << j;
+        }
+    }
+    uint16_t *rec = p.rec + rec_index(p, tx, ty, tz, wave) * kRecU16;
+    rec[r] = (uint16_t)occ;
+    rec[64 + r] = (uint16_t)seen;
+}
+
+__global__ __launch_bounds__(256) void rec_to_bytes_kernel(const CarveParams p,
+                                                           uint8_t *__restrict__ bytes) {
+    const int tx = blockIdx.x % p.tilesX, ty = (blockIdx.x / p.tilesX) % p.tilesY,
+              tz = blockIdx.x / (p.tilesX * p.tilesY);
+    const int wave = threadIdx.x >> 6, r = threadIdx.x & 63;
+    const int x0 = tx * kTileX + wave * kSubX, y = ty * kTileY + (r & 7), z = tz * kTileZ + (r >> 3);
+    if (x0 >= p.X || y >= p.Y || z >= p.Z) return;
+    const uint16_t *rec = p.rec + rec_index(p, tx, ty, tz, wave) * kRecU16;
+    const uint32_t occ = rec[r], seen = rec[64 + r];
+    uint8_t b[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) b[j] = (uint8_t)(((occ >> j) & 1u) | (((seen >> j) & 1u) << 1));
+    uint8_t *dst = bytes + ((size_t)z * p.Y + y) * p.X + x0;
+    if ((p.X & 15) == 0 && ((uintptr_t)bytes & 15u) == 0) {
+        *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(b);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (x0 + j < p.X) dst[j] = b[j];
+    }
+}
+
+// Flat packed occupancy of local planes [zl0, zl0 + nz) from the records; X % 32 == 0.
+// Output word (z, y, k) covers x = 32 k .. 32 k + 31: two neighbouring sub-tiles' entries.
+// global: the plane goes to its place in the WHOLE grid's word plane (global_z), else planes
+// are written back to back starting at word 0.
+__global__ __launch_bounds__(256) void pack_occupancy_rec_kernel(const CarveParams p, int zl0,
+                                                                 int nz, int global,
+                                                                 uint32_t *__restrict__ out) {
+    const int wpr = p.X >> 5;  // words per row
+    const size_t n = (size_t)wpr * p.Y * nz;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int k = (int)(i % wpr), y = (int)((i / wpr) % p.Y), zi = (int)(i / ((size_t)wpr * p.Y));
+    const int z = zl0 + zi;
+    const int r = (z & 7) * 8 + (y & 7);
+    const uint16_t *rec = p.rec + rec_index(p, k >> 1, y >> 3, z >> 3, (k & 1) * 2) * kRecU16;
+    const uint32_t w = (uint32_t)rec[r] | ((uint32_t)rec[kRecU16 + r] << 16);
+    const size_t zo = global ? (size_t)global_z(p, z) : (size_t)zi;
+    out[(zo * p.Y + y) * wpr + k] = w;
+}
+
+}  // namespace arvx

@@ -545,3 +545,24 @@ def test_view_preprocessing_paths(arvx, oracle, W, H, C):
             ctx.set_views_device(M, d_masks.data_ptr(), W, H, C)
             ctx.carve()
             assert_same(ctx.download_state(), want, f"{W}x{H}x{C} device masks")
+
+
+def test_view_by_view_on_random_states_many_seeds(arvx, oracle):
+    """One view at a time on random pre-carved states (every combination of occupied / seen),
+    re-synchronised with the oracle after every view: single-view launches have only a handful
+    of sub-tiles with exact work -- the regime in which items are shared between waves -- and a
+    ragged grid puts partial sub-tiles and padded tiles on the work lists.  (This is the test
+    that found work-list overflow when sub-tiles were numbered over the list instead of over
+    the grid.)"""
+    N, V = 40, 6
+    sc = scenes.small_sphere(N, V)
+    for seed in range(12):
+        rng = np.random.default_rng(seed)
+        cur = rng.choice(np.array([0, 1, 2, 3], np.uint8), size=(N, N, N))
+        with arvx.Context(N, N, N, sc.voxel_size) as ctx:
+            ctx.set_views(sc.M, sc.masks)
+            for i in range(V):
+                ctx.upload_state(cur)
+                ctx.carve_views(i, 1)
+                cur = oracle.carve_view(N, N, N, sc.voxel_size, sc.M[i], sc.masks[i], cur)
+                assert_same(ctx.download_state(), cur, f"seed {seed} view {i}")
