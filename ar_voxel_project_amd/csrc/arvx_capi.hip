@@ -276,7 +276,13 @@ static int views_common(Ctx *ctx, int V, const float *M, const float *campos, in
     // one word more than the pixels need: bit 32 * (bgWords - 1) is a background bit that is
     // always 0, which the block-mapped exact kernel reads for voxels outside the image
     ctx->bgWords = (int)(((size_t)W * H + 31) / 32) + 1;
-    ctx->satStride = (W + 1) * (H + 1);
+    // foreground counts per block of (1 << satShift)^2 pixels (views_kernels.h); 0 = per pixel
+    static const int shift_env = getenv("ARVX_SAT_SHIFT") ? atoi(getenv("ARVX_SAT_SHIFT")) : 0;
+    ctx->satShift = shift_env < 0 ? 0 : (shift_env > 3 ? 3 : shift_env);
+    const int blk = 1 << ctx->satShift;
+    ctx->satW = (W + blk - 1) / blk + 1;
+    ctx->satH = (H + blk - 1) / blk + 1;
+    ctx->satStride = ctx->satW * ctx->satH;
     ARVX_HIP(hipMalloc(&ctx->d_M, (size_t)V * 12 * sizeof(float)));
     ARVX_HIP(hipMalloc(&ctx->d_campos, (size_t)V * 3 * sizeof(float)));
     ARVX_HIP(hipMalloc(&ctx->d_bg, (size_t)V * ctx->bgWords * sizeof(uint32_t)));
@@ -296,41 +302,49 @@ static int views_common(Ctx *ctx, int V, const float *M, const float *campos, in
 
 static int views_preprocess(Ctx *ctx, const uint8_t *d_masks, int C) {
     const int npix = ctx->W * ctx->H;
-    dim3 g1((npix + 255) / 256, ctx->V);
     ARVX_HIP(hipGetLastError());  // anything stale would be blamed on the launches below
-    if (ctx->W % 64 == 0 && (C == 1 || C == 3)) {  // two launches: views_kernels.h
-        const dim3 gr((ctx->H + 3) / 4, ctx->V);
+    if (C == 1 || C == 3) {
+        const dim3 g1(((npix + 3) / 4 + 255) / 256, ctx->V);
         if (C == 1)
-            hipLaunchKernelGGL(arvx::views_rows_kernel<1>, gr, dim3(256), 0, ctx->stream, d_masks,
-                               ctx->W, ctx->H, ctx->d_bg, ctx->bgWords, ctx->d_sat, ctx->satStride);
+            hipLaunchKernelGGL(arvx::views_bits_kernel<1>, g1, dim3(256), 0, ctx->stream, d_masks,
+                               npix, ctx->d_bg, ctx->bgWords);
         else
-            hipLaunchKernelGGL(arvx::views_rows_kernel<3>, gr, dim3(256), 0, ctx->stream, d_masks,
-                               ctx->W, ctx->H, ctx->d_bg, ctx->bgWords, ctx->d_sat, ctx->satStride);
-        ARVX_HIP(hipGetLastError());
-        const dim3 gc((ctx->W + arvx::kColsPerWg) / arvx::kColsPerWg, ctx->V);
-        const dim3 bc(arvx::kColsPerWg * arvx::kColGroups);
-        if (ctx->H <= 16 * arvx::kColGroups)
-            hipLaunchKernelGGL(arvx::views_cols_kernel<false>, gc, bc, 0, ctx->stream, ctx->W, ctx->H,
-                               ctx->d_sat, ctx->satStride);
-        else
-            hipLaunchKernelGGL(arvx::views_cols_kernel<true>, gc, bc, 0, ctx->stream, ctx->W, ctx->H,
-                               ctx->d_sat, ctx->satStride);
+            hipLaunchKernelGGL(arvx::views_bits_kernel<3>, g1, dim3(256), 0, ctx->stream, d_masks,
+                               npix, ctx->d_bg, ctx->bgWords);
+    } else {
+        const dim3 g1((npix + 255) / 256, ctx->V);
+        hipLaunchKernelGGL(arvx::views_bits_generic_kernel, g1, dim3(256), 0, ctx->stream, d_masks,
+                           C, npix, ctx->d_bg, ctx->bgWords);
+    }
+    ARVX_HIP(hipGetLastError());
+    if (ctx->satShift == 0) {  // per-pixel table: written in one pass (views_kernels.h)
+        const int W = ctx->W, H = ctx->H, V = ctx->V;
+        const int TJ = (W + 63) / 64, TI = (H + arvx::kTileRows - 1) / arvx::kTileRows;
+        const size_t n_rs = (size_t)V * H * TJ, n_T = (size_t)V * TI * W, n_ts = (size_t)V * TI * TJ;
+        if (int rc = ensure_scratch(ctx, (n_rs + n_T + n_ts) * sizeof(int) + 64)) return rc;
+        int *d_rs = (int *)ctx->d_scratch, *d_T = d_rs + n_rs, *d_ts = d_T + n_T;
+        hipLaunchKernelGGL(arvx::views_tile_sums_kernel, dim3(TJ, TI, V), dim3(64), 0, ctx->stream,
+                           ctx->d_bg, ctx->bgWords, W, H, TJ, TI, d_rs, d_T, d_ts);
+        hipLaunchKernelGGL(arvx::views_table_kernel, dim3(TJ, TI, V), dim3(64), 0, ctx->stream,
+                           ctx->d_bg, ctx->bgWords, W, H, TJ, TI, d_rs, d_T, d_ts, ctx->d_sat,
+                           ctx->satStride);
         ARVX_HIP(hipGetLastError());
         ctx->views_ready = true;
         return ARVX_OK;
     }
-    ARVX_HIP(hipMemsetAsync(ctx->d_bg, 0, (size_t)ctx->V * ctx->bgWords * sizeof(uint32_t),
-                            ctx->stream));
-    hipLaunchKernelGGL(arvx::mask_to_bits_kernel, g1, dim3(256), 0, ctx->stream, d_masks, C, npix,
-                       ctx->d_bg, ctx->bgWords);
+    const int Hs = ctx->satH - 1;  // block rows
+    hipLaunchKernelGGL(arvx::views_rows_kernel, dim3(Hs, ctx->V), dim3(64), 0, ctx->stream,
+                       ctx->d_bg, ctx->bgWords, ctx->W, ctx->H, ctx->satShift, ctx->d_sat,
+                       ctx->satStride, ctx->satW);
     ARVX_HIP(hipGetLastError());
-    dim3 g2(ctx->H, ctx->V);
-    hipLaunchKernelGGL(arvx::sat_rows_kernel, g2, dim3(64), 0, ctx->stream, ctx->d_bg,
-                       ctx->bgWords, ctx->W, ctx->H, ctx->d_sat, ctx->satStride);
-    ARVX_HIP(hipGetLastError());
-    dim3 g3((ctx->W + 1 + 255) / 256, ctx->V);
-    hipLaunchKernelGGL(arvx::sat_cols_kernel, g3, dim3(256), 0, ctx->stream, ctx->W, ctx->H,
-                       ctx->d_sat, ctx->satStride);
+    const dim3 gc((ctx->satW + arvx::kColsPerWg - 1) / arvx::kColsPerWg, ctx->V);
+    const dim3 bc(arvx::kColsPerWg * arvx::kColGroups);
+    if (Hs <= 16 * arvx::kColGroups)
+        hipLaunchKernelGGL(arvx::views_cols_kernel<false>, gc, bc, 0, ctx->stream, ctx->satW, Hs,
+                           ctx->d_sat, ctx->satStride);
+    else
+        hipLaunchKernelGGL(arvx::views_cols_kernel<true>, gc, bc, 0, ctx->stream, ctx->satW, Hs,
+                           ctx->d_sat, ctx->satStride);
     ARVX_HIP(hipGetLastError());
     ctx->views_ready = true;
     return ARVX_OK;
@@ -696,6 +710,8 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
     p.H = ctx->H;
     p.bgWords = ctx->bgWords;
     p.satStride = ctx->satStride;
+    p.satShift = ctx->satShift;
+    p.satW = ctx->satW;
     p.v0 = first;
     p.v1 = first + count;
     p.flags = (flags & 3u) | (fresh ? 4u : 0u);

@@ -65,8 +65,10 @@ __device__ __forceinline__ BoxW make_box(float s, int x0, int x1, int y0, int y1
 // plus the roundings of the exact path's divide (1u|u|), of rcp+mul here (<3u|u|)
 // and of the bound arithmetic below (<2u|u|): 2^-20|u| = 16u|u| and an absolute
 // 2^-12 cover them.  roundf(t) lies in [t-0.5, t+0.5].
+// sat: the view's table of foreground counts per block of (1 << satShift)^2 pixels, satW
+// entries per row (views_kernels.h); the pixel rectangle is rounded outwards to whole blocks.
 __device__ inline int classify_box(const float *__restrict__ M, const BoxW b, int W, int H,
-                                   const int *__restrict__ sat) {
+                                   const int *__restrict__ sat, int satShift, int satW) {
     const float dy = b.wy1 - b.wy0, dx = b.wx1 - b.wx0, dz = b.wz1 - b.wz0;
     const float ay = fmaxf(fabsf(b.wy0), fabsf(b.wy1));
     const float ax = fmaxf(fabsf(b.wx0), fabsf(b.wx1));
@@ -122,11 +124,14 @@ __device__ inline int classify_box(const float *__restrict__ M, const BoxW b, in
     const int pyhi = (int)floorf(vmax + mv + 0.5f);
     if (pxhi < 0 || pxlo >= W || pyhi < 0 || pylo >= H) return kClsOut;
     if (pxlo < 0 || pxhi >= W || pylo < 0 || pyhi >= H) return kClsMixed | fast;
-    const int S = W + 1;
-    const int cnt = sat[(pyhi + 1) * S + pxhi + 1] - sat[pylo * S + pxhi + 1] -
-                    sat[(pyhi + 1) * S + pxlo] + sat[pylo * S + pxlo];
-    if (cnt == 0) return kClsCarved;
-    const int area = (pxhi - pxlo + 1) * (pyhi - pylo + 1);
+    const int X0 = pxlo >> satShift, X1 = (pxhi >> satShift) + 1;
+    const int Y0 = pylo >> satShift, Y1 = (pyhi >> satShift) + 1;
+    const int cnt = sat[Y1 * satW + X1] - sat[Y0 * satW + X1] - sat[Y1 * satW + X0] +
+                    sat[Y0 * satW + X0];
+    if (cnt == 0) return kClsCarved;  // no foreground in the enlarged rectangle, so none inside
+    // pixels of the enlarged rectangle that exist (the last block may overhang the image)
+    const int area = (min(X1 << satShift, W) - (X0 << satShift)) *
+                     (min(Y1 << satShift, H) - (Y0 << satShift));
     return (cnt == area) ? kClsFg : (kClsMixed | fast);
 }
 
@@ -164,7 +169,8 @@ __global__ __launch_bounds__(256) void carve_coarse_kernel(const CarveParams p) 
         const int myv = vc + lane;
         int cls = kClsOut;
         if (myv < p.v1)
-            cls = classify_box(p.M + 12 * myv, box, p.W, p.H, p.sat + (size_t)myv * p.satStride) &
+            cls = classify_box(p.M + 12 * myv, box, p.W, p.H, p.sat + (size_t)myv * p.satStride,
+                               p.satShift, p.satW) &
                   3;
         const unsigned long long carved = __ballot(cls == kClsCarved);
         const unsigned long long mixed = __ballot(cls == kClsMixed);
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p
                     cls = kClsFg;  // inherited: the coarse rectangle contains this one
                 else if ((cm >> lane) & 1ull)
                     cls = classify_box(p.M + 12 * myv, box, p.W, p.H,
-                                       p.sat + (size_t)myv * p.satStride);
+                                       p.sat + (size_t)myv * p.satStride, p.satShift, p.satW);
             }
         }
         const unsigned long long fastdiv = __ballot((cls & kFastDiv) != 0);
@@ -648,7 +654,8 @@ __global__ __launch_bounds__(256, 8) void carve_classify_kernel(const CarveParam
                 if (sel & 1u)
                     cls = kClsFg;  // inherited: the coarse rectangle contains this one
                 else if (sel & 2u)
-                    cls = classify_box(Mr, box, p.W, p.H, p.sat + (size_t)myv * p.satStride);
+                    cls = classify_box(Mr, box, p.W, p.H, p.sat + (size_t)myv * p.satStride,
+                                       p.satShift, p.satW);
             }
             fast_c[chunk] = __ballot((cls & kFastDiv) != 0);
             cls &= 3;
@@ -1288,84 +1295,6 @@ __global__ __launch_bounds__(256) void selftest_divide_kernel(const float *__res
     out[4 * i + 1] = v;
     out[4 * i + 2] = a0[i] / b[i];
     out[4 * i + 3] = a1[i] / b[i];
-}
-
-// ---- view pre-processing ---------------------------------------------------
-
-// bit i of plane v = 1 iff all C channel bytes of pixel i are zero
-// (reference src/VoxelCarving.cpp:49-50).
-__global__ __launch_bounds__(256) void mask_to_bits_kernel(const uint8_t *__restrict__ masks,
-                                                           int C, int npix,
-                                                           uint32_t *__restrict__ bg,
-                                                           int bgWords) {
-    const int v = blockIdx.y;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    bool isbg = false;
-    if (pix < npix) {
-        const uint8_t *q = masks + ((size_t)v * npix + pix) * C;
-        isbg = true;
-        for (int c = 0; c < C; ++c) isbg = isbg && (q[c] == 0);
-    }
-    const unsigned long long b = __ballot(isbg);
-    if ((threadIdx.x & 63) == 0) {
-        const int w0 = pix >> 5;
-        uint32_t *dst = bg + (size_t)v * bgWords;
-        if (w0 < bgWords) dst[w0] = (uint32_t)b;
-        if (w0 + 1 < bgWords) dst[w0 + 1] = (uint32_t)(b >> 32);
-    }
-}
-
-// Summed-area table of FOREGROUND pixels, (H+1) x (W+1) ints per view.
-// One wave per image row: 64-wide inclusive scans with a running carry.
-__global__ __launch_bounds__(64) void sat_rows_kernel(const uint32_t *__restrict__ bg,
-                                                      int bgWords, int W, int H,
-                                                      int *__restrict__ sat, int satStride) {
-    const int v = blockIdx.y;
-    const int yrow = blockIdx.x;  // 0..H-1
-    const int lane = threadIdx.x;
-    const uint32_t *b = bg + (size_t)v * bgWords;
-    int *out = sat + (size_t)v * satStride + (size_t)(yrow + 1) * (W + 1);
-    if (lane == 0) out[0] = 0;
-    int carry = 0;
-    for (int x0 = 0; x0 < W; x0 += 64) {
-        const int xx = x0 + lane;
-        int fg = 0;
-        if (xx < W) {
-            const int pix = yrow * W + xx;
-            fg = 1 - (int)((b[pix >> 5] >> (pix & 31)) & 1u);
-        }
-        int sc = fg;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(sc, d);
-            if (lane >= d) sc += t;
-        }
-        if (xx < W) out[xx + 1] = carry + sc;
-        carry += __shfl(sc, 63);
-    }
-}
-
-__global__ __launch_bounds__(256) void sat_cols_kernel(int W, int H, int *__restrict__ sat,
-                                                       int satStride) {
-    const int v = blockIdx.y;
-    const int xcol = blockIdx.x * 256 + threadIdx.x;  // 0..W
-    if (xcol > W) return;
-    int *s = sat + (size_t)v * satStride + xcol;
-    const size_t ld = (size_t)(W + 1);
-    int acc = 0;
-    s[0] = 0;
-    // 16 rows at a time: the loads of a chunk are independent of each other, so their
-    // latency overlaps (a load-add-store chain per row was 120 us for 36 views)
-    for (int y0 = 1; y0 <= H; y0 += 16) {
-        int t[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t[k] = (y0 + k <= H) ? s[(size_t)(y0 + k) * ld] : 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            acc += t[k];
-            if (y0 + k <= H) s[(size_t)(y0 + k) * ld] = acc;
-        }
-    }
 }
 
 // occupancy bit-plane: voxel i -> bit i%32 of word i/32

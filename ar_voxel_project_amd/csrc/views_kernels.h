@@ -1,77 +1,260 @@
 // views_kernels.h -- what arvx_set_views[_device] derives from the undistorted u8 masks:
 // per view a 1-bit background plane (bit = all channel bytes zero, reference
 // src/VoxelCarving.cpp:49-50) and the summed-area table of FOREGROUND pixels that the
-// rectangle tests of the carve kernels query ((H+1) x (W+1) ints).
+// rectangle tests of the carve kernels query.
 //
-// Two launches for all views (images whose width is a multiple of 64; other widths take
-// the general kernels in carve_kernels.h):
-//   views_rows_kernel  one wave per image row: mask bytes -> background bits (ballot) and
-//                      the row's running foreground count (popcount of the ballot below the
-//                      lane -- no shuffles), written as the row of the table
-//   views_cols_kernel  column sums: 16 columns x 32 row groups per workgroup; every thread
-//                      loads its <= 16 rows once, the groups exchange their totals through
-//                      LDS, offsets are added in registers and the rows written back -- one
-//                      load round trip instead of a chain of H dependent adds
-// HBM: W*H*C bytes in, W*H/8 + 4 (W+1)(H+1) bytes out per view, the table re-read once from
-// L2.  (Round 1: memset + mask_to_bits + sat_rows + sat_cols, 79 us for 36 views of 640x480.)
+// Per pixel by default (satShift = 0): three launches for all views (below: "summed-area
+// table, per pixel") --
+//   views_bits_kernel        mask bytes -> background bits, four pixels per lane
+//   views_tile_sums_kernel   per-tile row and column sums from the bit plane (small arrays)
+//   views_table_kernel       the table, written once: per row a popcount, two adds, a store
+// (Round 1: memset + mask_to_bits + sat_rows + sat_cols, 79 us for 36 views of 640 x 480: the
+// row pass wrote the table, the column pass read and rewrote it -- 132 MB for a 44 MB table.)
+//
+// ARVX_SAT_SHIFT=s keeps the table per BLOCK of b x b pixels (b = 1 << s) instead: entry
+// (Y, X) counts the foreground of image rows < b Y and columns < b X, and a rectangle test
+// rounds its rectangle outwards to whole blocks (classify_box) -- conservative, b^2 times
+// smaller and cheaper to derive, but the one-pixel rim of extra "mixed" answers costs the
+// exact kernel more than the derivation saves (s = 1: 512^3 exact +11 %, 1024^3 +29 %; kept
+// for A/B runs; views_rows_kernel + views_cols_kernel build it).
 #pragma once
 
 #include "arvx_device.h"
 
 namespace arvx {
 
+// bit i of plane v = 1 iff all C channel bytes of pixel i are zero; the word behind the last
+// pixel word stays zero (voxels outside the image read it).  npix4 = ceil(npix / 4).
 template <int C>
-__global__ __launch_bounds__(256) void views_rows_kernel(const uint8_t *__restrict__ masks, int W,
-                                                         int H, uint32_t *__restrict__ bg,
-                                                         int bgWords, int *__restrict__ sat,
-                                                         int satStride) {
+__global__ __launch_bounds__(256) void views_bits_kernel(const uint8_t *__restrict__ masks,
+                                                         int npix, uint32_t *__restrict__ bg,
+                                                         int bgWords) {
     const int v = blockIdx.y;
-    const int yrow = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    uint32_t *b = bg + (size_t)v * bgWords;
-    if (blockIdx.x == 0 && threadIdx.x == 0) b[bgWords - 1] = 0;  // the always-zero word
-    if (yrow >= H) return;
-    const uint8_t *row = masks + ((size_t)v * H + yrow) * (size_t)W * C;
-    int *out = sat + (size_t)v * satStride + (size_t)(yrow + 1) * (W + 1);
-    if (lane == 0) out[0] = 0;
-    int carry = 0;
-    for (int x0 = 0; x0 < W; x0 += 64) {  // W % 64 == 0
-        const uint8_t *q = row + (size_t)(x0 + lane) * C;
-        bool isbg = true;
+    const int q = blockIdx.x * 256 + threadIdx.x;  // pixels 4 q .. 4 q + 3
+    uint32_t *dst = bg + (size_t)v * bgWords;
+    if (q == 0) dst[bgWords - 1] = 0;
+    const uint8_t *src = masks + ((size_t)v * npix + 4 * (size_t)q) * C;
+    uint32_t nib = 0;
+    if (4 * q + 3 < npix && (((uintptr_t)src) & 3u) == 0) {
+        uint32_t w[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) isbg = isbg && (q[c] == 0);
-        const unsigned long long bgm = __ballot(isbg);
-        const unsigned long long fgm = ~bgm;
-        const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fgm >> 32),
-                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)fgm, 0u));
-        out[x0 + lane + 1] = carry + below + (isbg ? 0 : 1);
-        carry += __popcll(fgm);
-        if (lane == 0) {
-            const size_t w0 = ((size_t)yrow * W + x0) >> 5;
-            b[w0] = (uint32_t)bgm;
-            b[w0 + 1] = (uint32_t)(bgm >> 32);
+        for (int c = 0; c < C; ++c) w[c] = reinterpret_cast<const uint32_t *>(src)[c];
+        const uint8_t *b = reinterpret_cast<const uint8_t *>(w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool isbg = true;
+#pragma unroll
+            for (int c = 0; c < C; ++c) isbg = isbg && (b[j * C + c] == 0);
+            nib |= (isbg ? 1u : 0u) << j;
         }
+    } else {
+        for (int j = 0; j < 4; ++j) {
+            if (4 * q + j >= npix) break;
+            bool isbg = true;
+            for (int c = 0; c < C; ++c) isbg = isbg && (src[j * C + c] == 0);
+            nib |= (isbg ? 1u : 0u) << j;
+        }
+    }
+    // eight neighbouring lanes make one 32-bit word
+    uint32_t word = nib << (4 * (threadIdx.x & 7));
+    word |= __shfl_xor(word, 1);
+    word |= __shfl_xor(word, 2);
+    word |= __shfl_xor(word, 4);
+    const int w0 = q >> 3;
+    if ((threadIdx.x & 7) == 0 && w0 < bgWords - 1) dst[w0] = word;
+}
+
+// any channel count (the reference's masks have 3, the bench's 1)
+__global__ __launch_bounds__(256) void views_bits_generic_kernel(const uint8_t *__restrict__ masks,
+                                                                 int C, int npix,
+                                                                 uint32_t *__restrict__ bg,
+                                                                 int bgWords) {
+    const int v = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    uint32_t *dst = bg + (size_t)v * bgWords;
+    if (pix == 0) dst[bgWords - 1] = 0;
+    bool isbg = false;
+    if (pix < npix) {
+        const uint8_t *q = masks + ((size_t)v * npix + pix) * C;
+        isbg = true;
+        for (int c = 0; c < C; ++c) isbg = isbg && (q[c] == 0);
+    }
+    const unsigned long long b = __ballot(isbg);
+    if ((threadIdx.x & 63) == 0) {
+        const int w0 = pix >> 5;
+        if (w0 < bgWords - 1) dst[w0] = (uint32_t)b;
+        if (w0 + 1 < bgWords - 1) dst[w0 + 1] = (uint32_t)(b >> 32);
     }
 }
 
-// Column sums.  A workgroup takes 16 columns x kColGroups row groups; a thread holds its
-// (at most 16) rows in registers: ONE load round trip, the group totals meet in LDS, the
-// offsets are added and the rows written back.  Images taller than 16 * kColGroups rows walk
-// their rows twice (kTall).
+// ---- summed-area table, per pixel (satShift == 0), in one pass over the output --------------
+//
+// table[y + 1][x + 1] = sum of fg over rows <= y, columns <= x.  With the image cut into tiles
+// of 64 columns x 64 rows (tile (I, J)):
+//   table[y + 1][x + 1] = LT(I, J) + Lin(y, J) + A(I, x) + sum over the tile's rows y' <= y of
+//                         inrow(y', x)
+//   inrow(y', x) = fg pixels of row y' in columns 64 J .. x        (popcount below the lane)
+//   Lin(y, J)    = fg pixels of the tile's rows <= y in the columns left of tile column J
+//   LT(I, J)     = fg pixels above tile row I and left of tile column J
+//   A(I, x)      = fg pixels of the rows above tile row I in columns 64 J .. x
+// views_tile_sums_kernel takes three small arrays from the bit plane (per row and tile column
+// the row's count, per tile row and column x the running count along x, per tile its total);
+// views_table_kernel sums what it needs of them (a few independent loads per lane) and writes
+// the table: per row two scalar reads of the row's bits, a popcount, two adds and the store.
+// The 4 (W+1)(H+1) bytes per view are written once and never read back.  In both kernels lane
+// r first LOADS row r's 64 bits (one round trip for the whole tile) and the rows are then
+// taken from the lanes one by one.
+constexpr int kTileRows = 64;
+
+// 64 foreground bits of row y starting at column x0 (bit j = pixel x0 + j; 0 outside the image)
+__device__ __forceinline__ unsigned long long row_fg64(const uint32_t *__restrict__ bits,
+                                                       int bgWords, int W, int H, int y, int x0) {
+    if (y >= H) return 0ull;
+    const long long pos = (long long)y * W + x0;
+    const int w = (int)(pos >> 5), sh = (int)(pos & 31);
+    const int last = bgWords - 1;  // the always-zero word
+    const unsigned long long lo = bits[min(w, last)], mid = bits[min(w + 1, last)],
+                             hi = bits[min(w + 2, last)];
+    unsigned long long bg = ((lo | (mid << 32)) >> sh);
+    if (sh) bg |= hi << (64 - sh);
+    const int n = min(64, W - x0);  // valid columns
+    const unsigned long long valid = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    return ~bg & valid;
+}
+
+__device__ __forceinline__ unsigned long long lane_value64(unsigned long long v, int srcLane) {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, srcLane);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), srcLane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// one wave per tile: rowsum[v][y][J] = fg of row y inside tile column J; T[v][I][x] = fg of
+// tile row I in columns 64 J .. x; tilesum[v][I][J] = fg of the tile
+__global__ __launch_bounds__(64) void views_tile_sums_kernel(const uint32_t *__restrict__ bg,
+                                                             int bgWords, int W, int H, int TJ,
+                                                             int TI, int *__restrict__ rowsum,
+                                                             int *__restrict__ T,
+                                                             int *__restrict__ tilesum) {
+    const int J = blockIdx.x, I = blockIdx.y, v = blockIdx.z, lane = threadIdx.x;
+    const uint32_t *bits = bg + (size_t)v * bgWords;
+    const int yr = I * kTileRows + lane;
+    const unsigned long long mine = row_fg64(bits, bgWords, W, H, yr, 64 * J);  // row `lane`
+    if (yr < H) rowsum[((size_t)v * H + yr) * TJ + J] = __popcll(mine);
+    int col = 0;
+#pragma unroll
+    for (int r = 0; r < kTileRows; ++r) col += (int)((lane_value64(mine, r) >> lane) & 1ull);
+    int sc = col;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(sc, d);
+        if (lane >= d) sc += t;
+    }
+    const int x = 64 * J + lane;
+    if (x < W) T[((size_t)v * TI + I) * W + x] = sc;
+    if (lane == 63) tilesum[((size_t)v * TI + I) * TJ + J] = sc;
+}
+
+// one wave per tile: the table entries of its 64 columns x 64 rows
+__global__ __launch_bounds__(64) void views_table_kernel(const uint32_t *__restrict__ bg,
+                                                         int bgWords, int W, int H, int TJ, int TI,
+                                                         const int *__restrict__ rowsum,
+                                                         const int *__restrict__ T,
+                                                         const int *__restrict__ tilesum,
+                                                         int *__restrict__ sat, int satStride) {
+    const int J = blockIdx.x, I = blockIdx.y, v = blockIdx.z, lane = threadIdx.x;
+    const uint32_t *bits = bg + (size_t)v * bgWords;
+    int *tab = sat + (size_t)v * satStride;
+    const int x = 64 * J + lane, yr = I * kTileRows + lane;
+    const size_t ld = (size_t)W + 1;
+    const unsigned long long mine = row_fg64(bits, bgWords, W, H, yr, 64 * J);  // row `lane`
+    // Lin: running sum over this tile's rows of the row sums of the tile columns to the left
+    int left = 0;
+    if (yr < H)
+        for (int k = 0; k < J; ++k) left += rowsum[((size_t)v * H + yr) * TJ + k];
+    // LT: the tiles above and to the left, a few per lane
+    int lt = 0;
+    for (int e = lane; e < I * J; e += 64) lt += tilesum[((size_t)v * TI + e / J) * TJ + e % J];
+    // A: the tile rows above, this lane's column
+    int acc = 0;
+    if (x < W)
+        for (int k = 0; k < I; ++k) acc += T[((size_t)v * TI + k) * W + x];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(left, d);
+        if (lane >= d) left += t;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) lt += __shfl_xor(lt, d);
+    if (I == 0) {  // row 0 of the table
+        if (x < W) tab[x + 1] = 0;
+        if (J == 0 && lane == 0) tab[0] = 0;
+    }
+    if (J == 0 && yr < H) tab[(size_t)(yr + 1) * ld] = 0;  // column 0
+    const int nrows = min(kTileRows, H - I * kTileRows);
+    acc += lt;
+    for (int r = 0; r < nrows; ++r) {
+        const unsigned long long fg = lane_value64(mine, r);
+        const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fg >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)fg, 0u));
+        acc += below + (int)((fg >> lane) & 1ull);
+        const int lin = __builtin_amdgcn_readlane(left, r);
+        if (x < W) tab[(size_t)(I * kTileRows + r + 1) * ld + x + 1] = acc + lin;
+    }
+}
+
+// Block row Y of the table: entry (Y + 1, X + 1) = foreground pixels of the block row's
+// columns < b (X + 1) -- the column pass turns that into the sum over all rows above.
+__global__ __launch_bounds__(64) void views_rows_kernel(const uint32_t *__restrict__ bg,
+                                                        int bgWords, int W, int H, int shift,
+                                                        int *__restrict__ sat, int satStride,
+                                                        int satW) {
+    const int v = blockIdx.y, Y = blockIdx.x, lane = threadIdx.x;
+    const int b = 1 << shift;
+    const uint32_t *bits = bg + (size_t)v * bgWords;
+    int *out = sat + (size_t)v * satStride + (size_t)(Y + 1) * satW;
+    if (lane == 0) out[0] = 0;
+    int carry = 0;
+    for (int X0 = 0; X0 < satW - 1; X0 += 64) {
+        const int X = X0 + lane;
+        int cnt = 0;
+        if (X < satW - 1) {
+            for (int dy = 0; dy < b; ++dy) {
+                const int y = (Y << shift) + dy;
+                if (y >= H) break;
+                for (int dx = 0; dx < b; ++dx) {
+                    const int x = (X << shift) + dx;
+                    if (x >= W) break;
+                    const int pix = y * W + x;
+                    cnt += 1 - (int)((bits[pix >> 5] >> (pix & 31)) & 1u);
+                }
+            }
+        }
+        int sc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(sc, d);
+            if (lane >= d) sc += t;
+        }
+        if (X < satW - 1) out[X + 1] = carry + sc;
+        carry += __shfl(sc, 63);
+    }
+}
+
+// Column sums over the table's rows 1 .. Hs (Hs = block rows), row 0 = zeros.
 constexpr int kColGroups = 32, kColsPerWg = 16;
 
 template <bool kTall>
-__global__ __launch_bounds__(kColsPerWg * kColGroups) void views_cols_kernel(int W, int H,
+__global__ __launch_bounds__(kColsPerWg * kColGroups) void views_cols_kernel(int satW, int Hs,
                                                                              int *__restrict__ sat,
                                                                              int satStride) {
     __shared__ int part[kColGroups][kColsPerWg];
     const int v = blockIdx.y;
     const int c = threadIdx.x % kColsPerWg, g = threadIdx.x / kColsPerWg;
-    const int col = blockIdx.x * kColsPerWg + c;  // 0..W
-    const int R = (H + kColGroups - 1) / kColGroups;  // rows per group (<= 16 unless kTall)
-    const int r0 = 1 + g * R, r1 = min(H + 1, r0 + R);  // table rows [r0, r1)
-    const bool ok = col <= W;
-    const size_t ld = (size_t)(W + 1);
+    const int col = blockIdx.x * kColsPerWg + c;  // 0 .. satW - 1
+    const int R = (Hs + kColGroups - 1) / kColGroups;  // rows per group (<= 16 unless kTall)
+    const int r0 = 1 + g * R, r1 = min(Hs + 1, r0 + R);  // table rows [r0, r1)
+    const bool ok = col < satW;
+    const size_t ld = (size_t)satW;
     int *s = sat + (size_t)v * satStride + (ok ? col : 0);
     int t[16];
     int sum = 0;

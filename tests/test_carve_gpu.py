@@ -525,12 +525,13 @@ def test_fuzz_against_oracle(arvx, oracle):
 
 
 @pytest.mark.parametrize("W,H,C", [(64, 3, 1), (128, 50, 3), (192, 117, 1), (640, 480, 3),
-                                   (96, 64, 3), (65, 64, 1)])
+                                   (96, 64, 3), (65, 64, 1), (64, 600, 1), (130, 129, 4)])
 def test_view_preprocessing_paths(arvx, oracle, W, H, C):
-    """Image widths that are a multiple of 64 derive bit planes and summed-area tables with
-    the two-launch kernels of csrc/views_kernels.h (1 and 3 channels), the others with the
-    general ones: same planes, same tables -- checked through the carve they drive, from host
-    masks and from masks already on the device (re-derived twice)."""
+    """Bit planes and summed-area tables (csrc/views_kernels.h) for image widths that are and
+    are not multiples of 64 (tile columns of the table kernels), heights above and below one
+    tile row, 1 and 3 channels: checked through the carve they drive, from host masks and from
+    masks already on the device (re-derived twice).  (ARVX_SAT_SHIFT=1,2 runs the same tests
+    on the per-block tables.)"""
     import torch
     N, V = 40, 5
     s = np.float32(0.512 / N)
