@@ -787,6 +787,8 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
     // to several waves (decided in the kernel from the length of the work lists)
     static const bool no_item_split = getenv("ARVX_NO_ITEM_SPLIT") != nullptr;
     if (blocks && !no_item_split && (size_t)p.X * p.Y * p.Z <= ((size_t)1 << 26)) p.flags |= 8u;
+    static const bool no_block_tests = getenv("ARVX_NO_BLOCK_TESTS") != nullptr;  // A/B
+    if (no_block_tests) p.flags |= 32u;
     if (split) {
         // decided coarse tiles: constant records, one workgroup each
         hipLaunchKernelGGL(arvx::carve_fill_kernel, dim3((unsigned)ncoarse), dim3(256), 0,

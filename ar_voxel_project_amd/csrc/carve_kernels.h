@@ -995,10 +995,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 // projected -- no faster, and the extra live registers spill inside the loop;
 // handing out half sub-tiles (eight blocks) as the unit of work -- the tail gets shorter
 // but the per-view set-up is paid twice: 27 % more view evaluations, 4 % slower.)
+// need: bit 4 m + j set = block j of group m = 2 byi + bzi may be cut by this view's silhouette
+// (block_tests below); the other blocks are not projected.
 __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const int view,
                                                   const bool fast, const float (&wy)[2],
                                                   const float (&wx)[4], const float (&wz)[2],
-                                                  uint32_t (&st)[4]) {
+                                                  uint32_t (&st)[4], const unsigned need) {
     const uint32_t *__restrict__ bgv = p.bg + (size_t)view * p.bgWords;
     // The matrix of a view is the same for every lane and never written by a kernel:
     // it is fetched through the scalar cache into scalar registers (the compiler itself
@@ -1059,6 +1061,7 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
         for (int r = 0; r < 3; ++r) p0[byi][r] = (double)mf[r][0] * (double)wy[byi];
 #pragma unroll
     for (int bzi = 0; bzi < 2; ++bzi) {
+        if (!(need & (0x0f0fu << (4 * bzi)))) continue;  // groups m = bzi and 2 + bzi
         if (!__any(st[bzi] != kDone4 || st[2 + bzi] != kDone4)) continue;
         double q[3][4];
         {
@@ -1075,9 +1078,10 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
         for (int byi = 0; byi < 2; ++byi) {
             const int m = 2 * byi + bzi;
             const uint32_t w = st[m];
-            if (!__any(w != kDone4)) continue;  // these four blocks are finished
+            if (!((need >> (4 * m)) & 15u) || !__any(w != kDone4)) continue;  // nothing to do here
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                if (!((need >> (4 * m + j)) & 1u)) continue;  // decided by its rectangle
                 if (!__any(((w >> (8 * j)) & 0xffu) != 2u)) continue;  // block j is finished
                 project(m, j, p0[byi][0] + q[0][j], p0[byi][1] + q[1][j], p0[byi][2] + q[2][j]);
             }
@@ -1087,6 +1091,7 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
     // a_r = ((p0[y] + p1[x]) + p2[z]) + p3: the inner sum depends on y and x
 #pragma unroll
     for (int byi = 0; byi < 2; ++byi) {
+        if (!((need >> (8 * byi)) & 0xffu)) continue;
         if (!__any(st[2 * byi] != kDone4 || st[2 * byi + 1] != kDone4)) continue;
         double p01[3][4];
         {
@@ -1103,12 +1108,13 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
         for (int bzi = 0; bzi < 2; ++bzi) {
             const int m = 2 * byi + bzi;
             const uint32_t w = st[m];
-            if (!__any(w != kDone4)) continue;  // these four blocks are finished
+            if (!((need >> (4 * m)) & 15u) || !__any(w != kDone4)) continue;  // nothing to do here
             const double dwz = (double)wz[bzi];
             const double p20 = (double)mf[0][2] * dwz, p21 = (double)mf[1][2] * dwz,
                          p22 = (double)mf[2][2] * dwz;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                if (!((need >> (4 * m + j)) & 1u)) continue;  // decided by its rectangle
                 if (!__any(((w >> (8 * j)) & 0xffu) != 2u)) continue;  // block j is finished
                 project(m, j, (p01[0][j] + p20) + p3[0], (p01[1][j] + p21) + p3[1],
                         (p01[2][j] + p22) + p3[2]);
@@ -1133,6 +1139,64 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
         st[m] = w;
     }
     return __all(st[0] == kDone4 && st[1] == kDone4 && st[2] == kDone4 && st[3] == kDone4);
+}
+
+// Rectangle tests per 4 x 4 x 4 BLOCK, for the views of one chunk that are "mixed" for the
+// sub-tile: the silhouette's edge crosses the sub-tile's pixel rectangle, but most of its
+// sixteen blocks lie on one side of it.  Four views at a time, lane = (view q = lane >> 4,
+// block lane & 15), the same conservative classify_box as for sub-tiles and coarse tiles:
+//   block all background in some view   -> carved and seen, finished for every view
+//   block all foreground in some view   -> seen
+//   only what is left ("mixed")         -> projected voxel by voxel in that view
+// Returns, lane s = the s-th view of `views` (ascending bit order), the 16-bit mask of the
+// blocks to project in it (bit 4 m + j, m = 2 byi + bzi); carved / seen get the blocks some
+// view settled.  `part`/`pshift`: only every 2^pshift-th view belongs to this wave.
+__device__ __forceinline__ unsigned block_tests(const CarveParams &p, const SubTile &t, int vbase,
+                                                unsigned long long views, int part, int pshift,
+                                                int lane, unsigned &carved, unsigned &seen) {
+    const int blk = lane & 15, q = lane >> 4;
+    const int j = blk & 3, m = blk >> 2, byi = m >> 1, bzi = m & 1;
+    const int x0 = t.sx0 + 4 * j, y0 = t.sy0 + 4 * byi, z0 = t.sz0 + 4 * bzi;
+    const bool inside = x0 < p.X && y0 < p.Y && z0 < p.Z;
+    const BoxW box = make_box(p.s, x0, min(x0 + 3, p.X - 1), y0, min(y0 + 3, p.Y - 1),
+                              global_z(p, z0), global_z(p, min(z0 + 3, p.Z - 1)));
+    unsigned needLanes = 0;  // lane s: blocks to project in the s-th view
+    int slot = 0;
+    for (int nth = 0; views;) {
+        int vb[4];
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // the next four views of this wave (scalar)
+            vb[k] = 0;
+            while (views && n == k) {
+                const int b = __ffsll((long long)views) - 1;
+                views &= views - 1;
+                if ((nth++ & ((1 << pshift) - 1)) != part) continue;
+                vb[k] = b;
+                n = k + 1;
+            }
+        }
+        if (!n) break;
+        const int myb = q == 0 ? vb[0] : (q == 1 ? vb[1] : (q == 2 ? vb[2] : vb[3]));
+        int cls = kClsOut;
+        if (q < n && inside) {
+            const int view = vbase + myb;
+            cls = classify_box(p.M + 12 * view, box, p.W, p.H, p.sat + (size_t)view * p.satStride,
+                               p.satShift, p.satW) & 3;
+        }
+        const unsigned long long c = __ballot(cls == kClsCarved), f = __ballot(cls == kClsFg),
+                                 x = __ballot(cls == kClsMixed);
+        carved |= (unsigned)((c | (c >> 16) | (c >> 32) | (c >> 48)) & 0xffffu);
+        seen |= (unsigned)((f | (f >> 16) | (f >> 32) | (f >> 48)) & 0xffffu);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < n) {
+                const unsigned need16 = (unsigned)((x >> (16 * k)) & 0xffffu);
+                if (lane == slot) needLanes = need16;
+                ++slot;
+            }
+    }
+    return needLanes;
 }
 
 __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveParams p) {
@@ -1221,12 +1285,37 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
                     uniform64(c ? p.itemMasks[(it * p.nchunks + c) * 2] : mixed0);
                 const unsigned long long fastdiv =
                     uniform64(c ? p.itemMasks[(it * p.nchunks + c) * 2 + 1] : fast0);
+                // block-level rectangle tests first: what they settle is applied at once
+                unsigned bcarved = 0, bseen = 0;
+                const unsigned needLanes = (p.flags & 32u)
+                                               ? 0xffffu
+                                               : block_tests(p, t, p.v0 + 64 * c, mixed, part, pshift,
+                                                             lane, bcarved, bseen);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    uint32_t w = st[m];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if ((bseen >> (4 * m + j)) & 1u) w |= 2u << (8 * j);
+                        if ((bcarved >> (4 * m + j)) & 1u)
+                            w = (w & ~(0xffu << (8 * j))) | (2u << (8 * j));
+                    }
+                    st[m] = w;
+                }
+                done = __all(st[0] == kDone4 && st[1] == kDone4 && st[2] == kDone4 &&
+                             st[3] == kDone4);
+                int slot = 0;
                 for (int nth = 0; mixed && !done; ++nth) {
                     const int b = __ffsll((long long)mixed) - 1;
                     mixed &= mixed - 1;
                     if ((nth & ((1 << pshift) - 1)) != part) continue;  // another part's view
+                    const unsigned need = (p.flags & 32u)
+                                              ? 0xffffu
+                                              : (unsigned)__builtin_amdgcn_readlane(needLanes, slot);
+                    ++slot;
+                    if (!need) continue;  // every block settled by its rectangle
                     done = exact_view_blocks(p, __builtin_amdgcn_readfirstlane(p.v0 + 64 * c + b),
-                                             (fastdiv >> b) & 1ull, wy, wx, wz, st);
+                                             (fastdiv >> b) & 1ull, wy, wx, wz, st, need);
 #ifdef ARVX_TIMELINE
                     wave_timeline.view_done();
 #endif
