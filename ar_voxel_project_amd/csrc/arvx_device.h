@@ -130,6 +130,16 @@ __device__ __forceinline__ bool pixel_from_quotients(float u, float v, int W, fl
     return in;
 }
 
+// The same as ONE value: bit 31 = inside the image, bits 0..30 = the pixel's bit index in the
+// view's background plane (outside: `outside_pix`, an always-zero bit).  Sixteen of these stay
+// live across the table read of a view; as sixteen lane masks + sixteen ints they spilled.
+__device__ __forceinline__ uint32_t pixel_tagged(float u, float v, int W, float wlim, float hlim,
+                                                 int outside_pix) {
+    const bool in = (u > -0.5f) & (u < wlim) & (v > -0.5f) & (v < hlim);
+    const int at = __mul24(round_pixel(v), W) + round_pixel(u);
+    return in ? ((uint32_t)at | 0x80000000u) : (uint32_t)outside_pix;
+}
+
 // a0/a2 and a1/a2, correctly rounded, with ONE reciprocal: the unscaled core of
 // the gfx9 fp32 division expansion (rcp, one Newton step, quotient, two residual
 // corrections).  Bit-identical to the IEEE quotient whenever the hardware's

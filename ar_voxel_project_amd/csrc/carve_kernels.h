@@ -1028,15 +1028,11 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
     // All sixteen blocks are projected before the table is read: ONE wait per view.  (The
     // sub-tiles that stay fully occupied pay every wait in every view, and they are what
     // the kernel ends on.)
-    int pix[4][4];
-    bool in[4][4];
+    uint32_t pix[4][4];  // pixel_tagged
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            in[m][j] = false;
-            pix[m][j] = zero_pix;
-        }
+        for (int j = 0; j < 4; ++j) pix[m][j] = (uint32_t)zero_pix;
     auto project = [&](const int m, const int j, const double s0, const double s1,
                        const double s2) {
         const float a0 = (float)s0, a1 = (float)s1, a2 = (float)s2;
@@ -1047,7 +1043,7 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
             u = a0 / a2;
             v = a1 / a2;
         }
-        in[m][j] = pixel_from_quotients(u, v, p.W, wlim, hlim, pix[m][j], zero_pix);
+        pix[m][j] = pixel_tagged(u, v, p.W, wlim, hlim, zero_pix);
     };
 #ifndef ARVX_ASSOC_LEFT
     // a_r = p0[y] + ((p1[x] + p2[z]) + p3) (row_sum): the inner sum q depends on x and z
@@ -1126,14 +1122,14 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) word[m][j] = bgv[(unsigned)pix[m][j] >> 5];  // pix = 0 if skipped
+        for (int j = 0; j < 4; ++j) word[m][j] = bgv[(pix[m][j] & 0x7fffffffu) >> 5];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         uint32_t w = st[m];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t isbg = __builtin_amdgcn_ubfe(word[m][j], (uint32_t)pix[m][j], 1u);
-            const uint32_t seen = in[m][j] ? (2u << (8 * j)) : 0u;
+            const uint32_t isbg = __builtin_amdgcn_ubfe(word[m][j], pix[m][j], 1u);  // bit pix & 31
+            const uint32_t seen = (pix[m][j] >> 31) << (8 * j + 1);
             w = (w | seen) & ~(isbg << (8 * j));
         }
         st[m] = w;

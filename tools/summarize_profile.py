@@ -14,12 +14,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kernel_key(name):
-    for k in ("coarse", "classify", "exact", "fused"):
+    for k in ("coarse", "classify", "exact", "fused", "fill"):
         if "carve_" + k in name:
             return k
-    for k in ("mask_to_bits", "sat_rows", "sat_cols", "views_"):  # arvx_set_views_device
+    # arvx_set_views_device (round 1 names, then csrc/views_kernels.h)
+    for k in ("mask_to_bits", "sat_rows", "sat_cols", "views_bits", "views_tile_sums",
+              "views_table", "views_rows", "views_cols"):
         if k in name:
-            return k.rstrip("_")
+            return k
     return None
 
 
