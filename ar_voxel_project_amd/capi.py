@@ -32,6 +32,8 @@ SYMBOLS = [
     "arvx_compose_projection", "arvx_set_views", "arvx_set_views_device",
     "arvx_set_images", "arvx_state_reset", "arvx_state_upload",
     "arvx_state_download", "arvx_state_device_ptr", "arvx_state_upload_halo",
+    "arvx_state_upload_planes", "arvx_state_download_planes", "arvx_host_register",
+    "arvx_host_unregister", "arvx_handle_unseen",
     "arvx_pack_occupancy", "arvx_pack_occupancy_global", "arvx_carve", "arvx_carve_views", "arvx_fast_carve",
     "arvx_color", "arvx_surface_count", "arvx_surface_download",
     "arvx_surface_depth_download",
@@ -109,6 +111,12 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.arvx_state_upload.argtypes = [p, u8p]
     lib.arvx_state_download.argtypes = [p, u8p]
     lib.arvx_state_device_ptr.argtypes = [p, C.POINTER(p), C.POINTER(C.c_size_t)]
+    if hasattr(lib, "arvx_state_upload_planes"):
+        lib.arvx_state_upload_planes.argtypes = [p, C.c_void_p, C.c_void_p]
+        lib.arvx_state_download_planes.argtypes = [p, C.c_void_p, C.c_void_p]
+        lib.arvx_host_register.argtypes = [C.c_void_p, C.c_size_t]
+        lib.arvx_host_unregister.argtypes = [C.c_void_p]
+        lib.arvx_handle_unseen.argtypes = [p]
     lib.arvx_state_upload_halo.argtypes = [p, u8p, u8p]
     lib.arvx_pack_occupancy.argtypes = [p, p]
     lib.arvx_pack_occupancy_global.argtypes = [p, p]
@@ -289,6 +297,25 @@ class Context:
         out = np.empty(self.nvox, np.uint8)
         self._ck(self._lib.arvx_state_download(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out.reshape(self.shape)
+
+    def plane_words(self) -> int:
+        return ((self.X + 31) // 32) * self.Y * len(self.planes)
+
+    def download_planes(self):
+        """(occ, seen) bit planes, uint32, rows padded to 32-bit words."""
+        n = self.plane_words()
+        occ, seen = np.empty(n, np.uint32), np.empty(n, np.uint32)
+        self._ck(self._lib.arvx_state_download_planes(self._h, occ.ctypes.data, seen.ctypes.data))
+        return occ, seen
+
+    def upload_planes(self, occ, seen) -> None:
+        occ = np.ascontiguousarray(occ, np.uint32)
+        seen = np.ascontiguousarray(seen, np.uint32)
+        assert occ.size == seen.size == self.plane_words()
+        self._ck(self._lib.arvx_state_upload_planes(self._h, occ.ctypes.data, seen.ctypes.data))
+
+    def handle_unseen(self) -> None:
+        self._ck(self._lib.arvx_handle_unseen(self._h))
 
     def state_device_ptr(self) -> int:
         ptr = C.c_void_p()

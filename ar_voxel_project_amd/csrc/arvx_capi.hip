@@ -544,6 +544,75 @@ int arvx_state_download(arvx_ctx *ctx, uint8_t *state) {
     return ARVX_OK;
 }
 
+int arvx_state_upload_planes(arvx_ctx *ctx, const uint32_t *occ, const uint32_t *seen) {
+    ARVX_CHECK_CTX(ctx);
+    if (!occ || !seen) return fail(ARVX_ERR_INVALID, "null plane");
+    if (int mrc = need_rec(ctx)) return mrc;  // (halo planes keep what they hold)
+    ctx->color_ready = false;
+    ctx->closure_ready = false;
+    const int nz = ctx->z1 - ctx->z0;
+    const size_t nwords = (size_t)((ctx->X + 31) / 32) * ctx->Y * nz;
+    if (int rc = ensure_scratch(ctx, 2 * nwords * sizeof(uint32_t) + 64)) return rc;
+    uint32_t *d_occ = (uint32_t *)ctx->d_scratch, *d_seen = d_occ + nwords;
+    ARVX_HIP(hipMemcpyAsync(d_occ, occ, nwords * 4, hipMemcpyHostToDevice, ctx->stream));
+    ARVX_HIP(hipMemcpyAsync(d_seen, seen, nwords * 4, hipMemcpyHostToDevice, ctx->stream));
+    arvx::CarveParams g;
+    carve_geometry(ctx, g);
+    g.rec = ctx->d_rec;
+    hipLaunchKernelGGL(arvx::rec_from_planes_kernel, dim3((unsigned)((nwords + 255) / 256)),
+                       dim3(256), 0, ctx->stream, g, ctx->z0 - ctx->ze0, nz, d_occ, d_seen);
+    ARVX_HIP(hipGetLastError());
+    ctx->bytes_valid = false;
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));  // the host planes may go away
+    return ARVX_OK;
+}
+
+int arvx_state_download_planes(arvx_ctx *ctx, uint32_t *occ, uint32_t *seen) {
+    ARVX_CHECK_CTX(ctx);
+    if (!occ || !seen) return fail(ARVX_ERR_INVALID, "null plane");
+    if (int mrc = need_rec(ctx)) return mrc;
+    const int nz = ctx->z1 - ctx->z0;
+    const size_t nwords = (size_t)((ctx->X + 31) / 32) * ctx->Y * nz;
+    if (int rc = ensure_scratch(ctx, 2 * nwords * sizeof(uint32_t) + 64)) return rc;
+    uint32_t *d_occ = (uint32_t *)ctx->d_scratch, *d_seen = d_occ + nwords;
+    arvx::CarveParams g;
+    carve_geometry(ctx, g);
+    g.rec = ctx->d_rec;
+    hipLaunchKernelGGL(arvx::planes_from_rec_kernel, dim3((unsigned)((nwords + 255) / 256)),
+                       dim3(256), 0, ctx->stream, g, ctx->z0 - ctx->ze0, nz, d_occ, d_seen);
+    ARVX_HIP(hipGetLastError());
+    ARVX_HIP(hipMemcpyAsync(occ, d_occ, nwords * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ARVX_HIP(hipMemcpyAsync(seen, d_seen, nwords * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    return ARVX_OK;
+}
+
+int arvx_handle_unseen(arvx_ctx *ctx) {
+    ARVX_CHECK_CTX(ctx);
+    if (int mrc = need_rec(ctx)) return mrc;
+    ctx->closure_ready = false;
+    arvx::CarveParams g;
+    carve_geometry(ctx, g);
+    const size_t nrec = arvx::rec_count(g);
+    hipLaunchKernelGGL(arvx::rec_handle_unseen_kernel, dim3((unsigned)((nrec * 32 + 255) / 256)),
+                       dim3(256), 0, ctx->stream, (uint32_t *)ctx->d_rec, nrec);
+    ARVX_HIP(hipGetLastError());
+    ctx->bytes_valid = false;
+    return ARVX_OK;
+}
+
+int arvx_host_register(void *ptr, size_t bytes) {
+    if (!ptr || !bytes) return fail(ARVX_ERR_INVALID, "null host range");
+    ARVX_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return ARVX_OK;
+}
+
+int arvx_host_unregister(void *ptr) {
+    if (!ptr) return fail(ARVX_ERR_INVALID, "null host pointer");
+    ARVX_HIP(hipHostUnregister(ptr));
+    return ARVX_OK;
+}
+
 int arvx_state_device_ptr(arvx_ctx *ctx, void **ptr, size_t *bytes) {
     if (!ctx || !ptr) return fail(ARVX_ERR_INVALID, "null argument");
     ARVX_HIP(hipSetDevice(ctx->device));

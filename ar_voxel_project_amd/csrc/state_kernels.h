@@ -88,4 +88,59 @@ __global__ __launch_bounds__(256) void pack_occupancy_rec_kernel(const CarvePara
     out[(zo * p.Y + y) * wpr + k] = w;
 }
 
+// Model::handleUnseen on records: occ |= ~seen (voxels outside the grid are kept "seen")
+__global__ __launch_bounds__(256) void rec_handle_unseen_kernel(uint32_t *__restrict__ rec32,
+                                                                size_t nrec) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;  // record t / 32, word t % 32
+    if (t >= nrec * 32) return;
+    uint32_t *r = rec32 + (t >> 5) * 64 + (t & 31);
+    r[0] |= ~r[32];
+}
+
+// Bit planes with rows padded to whole 32-bit words (wpr = ceil(X / 32) words per row; word
+// (z, y, k) bit j = voxel x = 32 k + j): the form a host Model keeps (include/arvx/model.hpp).
+// Planes [zl0, zl0 + nz) of the records <-> plane words starting at word 0.
+__global__ __launch_bounds__(256) void planes_from_rec_kernel(const CarveParams p, int zl0, int nz,
+                                                              uint32_t *__restrict__ occ,
+                                                              uint32_t *__restrict__ seen) {
+    const int wpr = (p.X + 31) >> 5;
+    const size_t n = (size_t)wpr * p.Y * nz;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int k = (int)(i % wpr), y = (int)((i / wpr) % p.Y), zi = (int)(i / ((size_t)wpr * p.Y));
+    const int z = zl0 + zi, r = (z & 7) * 8 + (y & 7);
+    const uint16_t *rec = p.rec + rec_index(p, k >> 1, y >> 3, z >> 3, (k & 1) * 2) * kRecU16;
+    uint32_t o = rec[r], sn = rec[64 + r];
+    if (32 * k + 16 < p.X) {  // the word's upper half lies in the next sub-tile
+        o |= (uint32_t)rec[kRecU16 + r] << 16;
+        sn |= (uint32_t)rec[kRecU16 + 64 + r] << 16;
+    }
+    // voxels behind the end of the row: records hold (occ 0, seen 1) there, the planes zeros
+    const int nx = p.X - 32 * k;
+    const uint32_t valid = nx >= 32 ? 0xffffffffu : ((1u << nx) - 1u);
+    occ[i] = o & valid;
+    seen[i] = sn & valid;
+}
+
+__global__ __launch_bounds__(256) void rec_from_planes_kernel(const CarveParams p, int zl0, int nz,
+                                                              const uint32_t *__restrict__ occ,
+                                                              const uint32_t *__restrict__ seen) {
+    const int wpr = (p.X + 31) >> 5;
+    const size_t n = (size_t)wpr * p.Y * nz;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int k = (int)(i % wpr), y = (int)((i / wpr) % p.Y), zi = (int)(i / ((size_t)wpr * p.Y));
+    const int z = zl0 + zi, r = (z & 7) * 8 + (y & 7);
+    uint16_t *rec = p.rec + rec_index(p, k >> 1, y >> 3, z >> 3, (k & 1) * 2) * kRecU16;
+    const int nx = p.X - 32 * k;
+    const uint32_t valid = nx >= 32 ? 0xffffffffu : ((1u << nx) - 1u);
+    const uint32_t o = occ[i] & valid, sn = seen[i] | ~valid;  // outside the grid: occ 0, seen 1
+    rec[r] = (uint16_t)o;
+    rec[64 + r] = (uint16_t)sn;
+    if (32 * k + 16 < p.X) {
+        rec[kRecU16 + r] = (uint16_t)(o >> 16);
+        rec[kRecU16 + 64 + r] = (uint16_t)(sn >> 16);
+    }
+}
+
 }  // namespace arvx

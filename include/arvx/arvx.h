@@ -134,6 +134,21 @@ int arvx_set_images(arvx_ctx *ctx, const uint8_t *const *images, size_t stride);
 int arvx_state_reset(arvx_ctx *ctx);
 int arvx_state_upload(arvx_ctx *ctx, const uint8_t *state);
 int arvx_state_download(arvx_ctx *ctx, uint8_t *state);
+/* The same state as two bit planes, 8x smaller than the byte plane each: occupied and seen,
+ * rows padded to whole 32-bit words -- word (z, y, k) holds voxels x = 32 k .. 32 k + 31 of row
+ * (y, z), bit x % 32; ceil(X / 32) * Y * (owned planes) words per plane (for X % 32 == 0 this
+ * is the flat packing of arvx_pack_occupancy).  This is the form the device keeps (2 bits per
+ * voxel) and the host-side arvx::Model mirrors, so a carve result crosses PCIe as N / 4 bytes. */
+int arvx_state_upload_planes(arvx_ctx *ctx, const uint32_t *occ, const uint32_t *seen);
+int arvx_state_download_planes(arvx_ctx *ctx, uint32_t *occ, uint32_t *seen);
+/* Model::handleUnseen() on the device state (reference src/Model.cpp:36-47): every voxel that
+ * no view saw becomes occupied (the reference paints it UNSEEN_COLOR, w = 1); seen bits stay. */
+int arvx_handle_unseen(arvx_ctx *ctx);
+/* Page-lock caller memory (hipHostRegister) so that uploads / downloads into it run at full
+ * PCIe rate instead of through the runtime's staging buffers; optional.  Plain wrappers, so
+ * that host code needs no HIP headers. */
+int arvx_host_register(void *ptr, size_t bytes);
+int arvx_host_unregister(void *ptr);
 /* Device address of the owned part of the state plane, for zero-copy consumers. */
 int arvx_state_device_ptr(arvx_ctx *ctx, void **ptr, size_t *bytes);
 /* Slab contexts keep one halo plane on each side that lies inside the grid

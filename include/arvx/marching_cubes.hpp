@@ -101,21 +101,28 @@ struct McCell {
 // The cells marchingCubes() triangulates, in its visiting order, found on the GPU.
 // A corner counts as outside when its w < threshold (:481); the reference's own pipeline only
 // ever holds w in {0, 1} and passes 0.5.
-inline std::vector<McCell> marchingCubesCells(const Model &model, float threshold = 0.5f,
-                                              int device = 0) {
+inline std::vector<McCell> marchingCubesCells(Model &model, float threshold = 0.5f) {
     static_assert(sizeof(McCell) == 4 * sizeof(int32_t), "McCell is the C-ABI's 4-int record");
     // w >= 0 everywhere the grid is, and 0 outside it: with threshold <= 0 no corner is outside
     if (!(threshold > 0.f)) return {};
+    bool on_device = false;
+    const std::vector<uint8_t> inside = model.inside_state(threshold, on_device);
     arvx_ctx *ctx = nullptr;
-    detail::check(arvx_ctx_create(&ctx, device, model.getX(), model.getY(), model.getZ(),
-                                  model.getSize()),
-                  "arvx_ctx_create");
     struct Guard {
         arvx_ctx *c;
-        ~Guard() { arvx_ctx_destroy(c); }
-    } guard{ctx};
-    const std::vector<uint8_t> inside = model.inside_state(threshold);
-    detail::check(arvx_state_upload(ctx, inside.data()), "arvx_state_upload");
+        ~Guard() {
+            if (c) arvx_ctx_destroy(c);
+        }
+    } guard{nullptr};
+    if (on_device) {  // "inside" is the occupancy the model's context already holds
+        ctx = model.device_for_reading();
+    } else {  // fractional w: a thresholded plane of its own, in a context of its own
+        detail::check(arvx_ctx_create(&ctx, 0, model.getX(), model.getY(), model.getZ(),
+                                      model.getSize()),
+                      "arvx_ctx_create");
+        guard.c = ctx;
+        detail::check(arvx_state_upload(ctx, inside.data()), "arvx_state_upload");
+    }
     int64_t n = 0;
     detail::check(arvx_mc_cells(ctx, &n), "arvx_mc_cells");
     std::vector<McCell> cells((size_t)n);

@@ -1,13 +1,21 @@
 // model.hpp -- host-side voxel model with the reference's Model API
-// (reference src/Model.h:93-163, src/Model.cpp:9-47), header only.
+// (reference src/Model.h:93-163, src/Model.cpp:9-47), header only, over libarvx.so.
 //
-// Same public methods, same results, different storage: the reference keeps
-// 16 B of RGBA floats + a 24 B std::vector header + 1 bit per voxel (40 GiB at
-// 1024^3).  Here a voxel is ONE byte -- bit0 occupied (w != 0), bit1 seen,
-// bit2 "painted with UNSEEN_COLOR" -- which is exactly the state plane the
-// GPU library works on (include/arvx/arvx.h); colours and colour lists are
-// sparse, because only surface voxels ever get one.  get() reconstructs the
-// Vector4f the reference would hold.
+// Same public methods, same results, different storage.  The reference keeps 16 B of RGBA
+// floats + a 24 B std::vector header + 1 bit per voxel (40 GiB at 1024^3).  Here a voxel is
+// TWO BITS -- occupied (w != 0) and seen -- in two bit planes whose rows are padded to 32-bit
+// words: exactly the form the GPU library exchanges (arvx_state_upload_planes /
+// _download_planes, include/arvx/arvx.h), so a carve result crosses PCIe as N / 4 bytes.  A third
+// plane marks voxels painted UNSEEN_COLOR by handleUnseen(); colours are sparse (a sorted list,
+// as the colour pass and the closure deliver them, plus a small map for single set() calls),
+// because only surface voxels ever get one.  get() reconstructs the Vector4f the reference
+// would hold.
+//
+// The model owns ONE device context, created on first use (carve, colour, closure, marching
+// cubes) and kept until the model dies: state, masks, summed-area tables and the colour list
+// stay on the GPU between the stages of src/main.cpp:262-303.  Host and device copies of the
+// state are synchronised lazily: a stage leaves its result on the device, and the first host
+// accessor that needs it (get, isInner, visited, ...) downloads the two bit planes.
 //
 // Vec4f/Vec3i below stand in for Eigen::Vector4f / cv::Vec3i so that this header
 // needs neither library; include/arvx/opencv_dropin.hpp maps them when the real
@@ -19,10 +27,14 @@
 #include <cstdint>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
+
+#include "arvx/arvx.h"
 
 namespace arvx {
 
@@ -60,24 +72,77 @@ struct DCLR {  // reference src/Model.h:70-73
 inline Vec4f model_color() { return Vec4f(50, 168, 141, 1); }  // MODEL_COLOR, src/Model.h:90
 inline Vec4f unseen_color() { return Vec4f(204, 0, 0, 1); }    // UNSEEN_COLOR, src/Model.h:91
 
+class Error : public std::runtime_error {
+   public:
+    Error(int code, const std::string &what) : std::runtime_error(what), code(code) {}
+    int code;
+};
+
+namespace detail {
+
+inline void check(int rc, const char *what) {
+    if (rc != ARVX_OK) {
+        std::string msg = std::string(what) + ": " + arvx_last_error();
+        std::cerr << "LOG(ERR) - GPU: " << msg << std::endl;
+        throw Error(rc, msg);
+    }
+}
+
+// the model's GPU context and what is known about its contents
+struct DeviceLink {
+    arvx_ctx *ctx = nullptr;
+    std::vector<void *> registered;  // host ranges page-locked for the transfers
+    ~DeviceLink() {
+        for (void *p : registered) (void)arvx_host_unregister(p);
+        if (ctx) arvx_ctx_destroy(ctx);
+    }
+};
+
+}  // namespace detail
+
 class Model {
    public:
-    static constexpr uint8_t kOcc = 1, kSeen = 2, kUnseenPaint = 4;
-
     // reference src/Model.cpp:9-14: every voxel MODEL_COLOR, nothing seen
     Model(int x, int y, int z, float size)
-        : size_x(x), size_y(y), size_z(z), voxel_size(size),
-          state_((size_t)x * y * z, kOcc) {}
+        : size_x(x), size_y(y), size_z(z), voxel_size(size), wpr_((x + 31) / 32),
+          occ_((size_t)wpr_ * y * z), seen_((size_t)wpr_ * y * z, 0u) {
+        const uint32_t last = (x & 31) ? ((1u << (x & 31)) - 1u) : 0xffffffffu;
+        for (size_t i = 0; i < occ_.size(); ++i) occ_[i] = ((int)(i % wpr_) == wpr_ - 1) ? last : 0xffffffffu;
+    }
+    // a copy is an independent model: host data only, its own device context when it needs one
+    Model(const Model &o)
+        : size_x(o.size_x), size_y(o.size_y), size_z(o.size_z), voxel_size(o.voxel_size),
+          wpr_(o.wpr_) {
+        o.sync_host();
+        occ_ = o.occ_;
+        seen_ = o.seen_;
+        paint_ = o.paint_;
+        pristine_ = o.pristine_;
+        paint_is_unseen_ = o.paint_is_unseen_;
+        cidx_ = o.cidx_;
+        cval_ = o.cval_;
+        overlay_ = o.overlay_;
+        color_lists_ = o.color_lists_;
+    }
+    Model &operator=(const Model &) = delete;  // (the reference's has const members too)
 
     void set(int x, int y, int z, const Vec4f &v) {  // src/Model.cpp:16-18
+        sync_host();
+        const size_t w = word(x, y, z);
+        const uint32_t b = 1u << (x & 31);
+        if (v.w() != 0) occ_[w] |= b;
+        else occ_[w] &= ~b;
+        if (!paint_.empty()) paint_[w] &= ~b;
         const int i = flatten(x, y, z);
-        pristine_ = false;
-        uint8_t &s = state_[i];
-        s = (uint8_t)((s & kSeen) | (v.w() != 0 ? kOcc : 0));
-        if (v == model_color() || (v.w() == 0 && v.x() == 0 && v.y() == 0 && v.z() == 0))
-            colors_.erase(i);  // the two values the state byte alone encodes
+        const bool by_state = v == model_color() ||
+                              (v.w() == 0 && v.x() == 0 && v.y() == 0 && v.z() == 0);
+        // the two values the bits alone encode need no entry -- unless an explicit colour
+        // of this voxel has to be hidden
+        if (by_state && (cidx_.empty() || !std::binary_search(cidx_.begin(), cidx_.end(), i)))
+            overlay_.erase(i);
         else
-            colors_[i] = v;
+            overlay_[i] = v;
+        host_changed();
     }
     void set(Vec3i voxel, const Vec4f &value) { set(voxel(0), voxel(1), voxel(2), value); }
 
@@ -89,12 +154,21 @@ class Model {
     Vec4f get(int x, int y, int z) const {  // src/Model.h:119-124: zero outside the grid
         if (x < 0 || x >= size_x || y < 0 || y >= size_y || z < 0 || z >= size_z)
             return Vec4f(0, 0, 0, 0);
+        sync_host();
         const int i = flatten(x, y, z);
-        auto it = colors_.find(i);
-        if (it != colors_.end()) return it->second;
-        const uint8_t s = state_[i];
-        if (s & kUnseenPaint) return unseen_color();
-        return (s & kOcc) ? model_color() : Vec4f(0, 0, 0, 0);
+        if (!overlay_.empty()) {  // what set() stored, exactly
+            auto it = overlay_.find(i);
+            if (it != overlay_.end()) return it->second;
+        }
+        const size_t w = word(x, y, z);
+        const uint32_t b = 1u << (x & 31);
+        if (!(occ_[w] & b)) return Vec4f(0, 0, 0, 0);  // carved (src/VoxelCarving.cpp:52)
+        if (!paint_.empty() && (paint_[w] & b)) return unseen_color();
+        if (!cidx_.empty()) {
+            auto it = std::lower_bound(cidx_.begin(), cidx_.end(), i);
+            if (it != cidx_.end() && *it == i) return cval_[(size_t)(it - cidx_.begin())];
+        }
+        return model_color();
     }
 
     bool isInner(int x, int y, int z) const {  // src/Model.h:126-132
@@ -117,21 +191,30 @@ class Model {
     }
 
     void see(int x, int y, int z) {  // src/Model.h:151
-        pristine_ = false;
-        state_[flatten(x, y, z)] |= kSeen;
+        sync_host();
+        seen_[word(x, y, z)] |= 1u << (x & 31);
+        host_changed();
     }
-    void visit(Vec3i v) { see(v(0), v(1), v(2)); }                        // :154-156
-    bool visited(Vec3i v) const { return state_[flatten(v(0), v(1), v(2))] & kSeen; }  // :158-160
+    void visit(Vec3i v) { see(v(0), v(1), v(2)); }  // :154-156
+    bool visited(Vec3i v) const {                   // :158-160
+        sync_host();
+        return (seen_[word(v(0), v(1), v(2))] >> (v(0) & 31)) & 1u;
+    }
 
-    void handleUnseen() {  // src/Model.cpp:36-47
+    // src/Model.cpp:36-47: every voxel that no view saw becomes UNSEEN_COLOR (204, 0, 0, 1) --
+    // occupied, whatever it was.  When the current state lives on the device the bit operation
+    // runs there (arvx_handle_unseen) and the paint plane is derived at the next download.
+    void handleUnseen() {
         std::cout << "LOG - PP: marking unseen voxels from model." << std::endl;
         pristine_ = false;
-        painted_ = true;
-        for (size_t i = 0; i < state_.size(); ++i)
-            if (!(state_[i] & kSeen)) {
-                state_[i] = (uint8_t)(kOcc | kUnseenPaint);
-                colors_.erase((int)i);
-            }
+        if (host_stale_) {
+            detail::check(arvx_handle_unseen(link_->ctx), "arvx_handle_unseen");
+            paint_pending_ = true;
+        } else {
+            paint_unseen_host();
+            device_stale_ = true;
+        }
+        paint_is_unseen_ = true;
     }
 
     std::string to_string() const {  // src/Model.cpp:20-34
@@ -150,85 +233,271 @@ class Model {
         return ss.str();
     }
 
-    // ---- access for the GPU path (not in the reference) ----
-    size_t voxels() const { return state_.size(); }
-    // still exactly as constructed (every voxel MODEL_COLOR, nothing seen): the GPU
-    // side can start from arvx_state_reset instead of an N-byte upload
+    // ---- the GPU side (not in the reference; used by voxel_carving.hpp and friends) ----
+
+    size_t voxels() const { return (size_t)size_x * size_y * size_z; }
+    // still exactly as constructed (every voxel MODEL_COLOR, nothing seen)
     bool pristine() const { return pristine_; }
-    // no explicit colours and no UNSEEN paint: the state bytes are the whole model, so
-    // a device plane can be downloaded straight into state_data()
-    bool plain() const { return !painted_ && colors_.empty(); }
-    uint8_t *state_data() {
-        pristine_ = false;  // the caller may write through the pointer
-        return state_.data();
+    // the paint plane is exactly "not seen" (handleUnseen ran and nothing was seen since): the
+    // device can derive it itself (apply_unseen of arvx_closure / arvx_export_model)
+    bool paint_is_unseen() const { return paint_is_unseen_; }
+    bool painted() const { return paint_is_unseen_ || !paint_.empty(); }
+
+    // The model's device context with the model's CURRENT state in it.
+    arvx_ctx *device(int device_index = 0) {
+        if (!link_) {
+            link_ = std::make_shared<detail::DeviceLink>();
+            detail::check(arvx_ctx_create(&link_->ctx, device_index, size_x, size_y, size_z,
+                                          voxel_size),
+                          "arvx_ctx_create");
+            // page-lock the planes: the transfers then run at PCIe rate (best effort)
+            for (void *p : {(void *)occ_.data(), (void *)seen_.data()})
+                if (arvx_host_register(p, occ_.size() * sizeof(uint32_t)) == ARVX_OK)
+                    link_->registered.push_back(p);
+            device_stale_ = true;
+        }
+        if (closure_on_device_ && !mc_only_) {  // see closure_applied()
+            sync_host();
+            device_stale_ = true;
+            closure_on_device_ = false;
+        }
+        if (device_stale_) {
+            if (pristine_) {
+                detail::check(arvx_state_reset(link_->ctx), "arvx_state_reset");
+            } else {
+                detail::check(arvx_state_upload_planes(link_->ctx, occ_.data(), seen_.data()),
+                              "arvx_state_upload_planes");
+            }
+            device_stale_ = false;
+        }
+        return link_->ctx;
     }
-    const uint8_t *state_data() const { return state_.data(); }
-    // state bytes as the C-ABI wants them (bit2 is host-only)
-    std::vector<uint8_t> device_state() const {
-        std::vector<uint8_t> s(state_);
-        for (auto &b : s) b &= (uint8_t)(kOcc | kSeen);
-        return s;
+    // the device context for a stage that only READS the occupancy (marching-cubes cells)
+    arvx_ctx *device_for_reading(int device_index = 0) {
+        mc_only_ = true;
+        arvx_ctx *c = device(device_index);
+        mc_only_ = false;
+        return c;
     }
-    // one byte per voxel, 1 where marching cubes counts the voxel as inside (w >= threshold,
-    // the complement of src/MarchingCubes.h:481): the occupancy the cell walk runs on
-    std::vector<uint8_t> inside_state(float threshold) const {
-        std::vector<uint8_t> s(state_.size());
-        const uint8_t one = (1.0f >= threshold) ? kOcc : 0;  // MODEL / UNSEEN colour: w = 1
-        for (size_t i = 0; i < s.size(); ++i) s[i] = (state_[i] & kOcc) ? one : 0;
-        for (const auto &kv : colors_) s[(size_t)kv.first] = (kv.second.w() >= threshold) ? kOcc : 0;
-        return s;
-    }
-    // take the carve result back: occupancy and seen from the device plane.  The
-    // device plane started from this model's bits, so it already holds them; a
-    // voxel that is still occupied keeps its UNSEEN paint bit, a carved one loses
-    // it and its explicit colour (set(x,y,z,(0,0,0,0)), src/VoxelCarving.cpp:52).
-    void absorb_state(const uint8_t *dev_state) {
+    // a stage changed occupancy / seen on the device: the host planes are out of date
+    void device_changed() {
         pristine_ = false;
-        for (auto it = colors_.begin(); it != colors_.end();) {  // sparse: surface voxels only
-            const size_t i = (size_t)it->first;
-            if ((state_[i] & kOcc) && !(dev_state[i] & kOcc)) it = colors_.erase(it);
-            else ++it;
-        }
-        uint8_t *st = state_.data();
-        const size_t n = state_.size();
-        for (size_t i = 0; i < n; ++i) {  // branch-free, vectorises
-            const uint8_t now = (uint8_t)(dev_state[i] & (kOcc | kSeen));
-            st[i] = (uint8_t)(now | (st[i] & kUnseenPaint & (uint8_t)((now & kOcc) << 2)));
-        }
+        host_stale_ = true;
+        paint_is_unseen_ = false;  // (carving sees voxels; closure adds some)
+        colors_on_device_ = false;  // (arvx_carve* drops the context's colour list)
     }
-    void set_flat(int i, const Vec4f &v) {
-        const int x = i % size_x, y = (i / size_x) % size_y, z = i / (size_x * size_y);
-        set(x, y, z, v);
+    // the closure's result is in the context (filled voxels marked occupied): marching cubes can
+    // run on it, but anything else that changes the state has to start from an upload again
+    void closure_applied() { closure_on_device_ = true; }
+    // the context's sparse colour list equals this model's explicit colours (set by the colour
+    // pass, consumed by the closure without another upload)
+    bool colors_on_device() const { return colors_on_device_; }
+    void set_colors_on_device(bool v) { colors_on_device_ = v; }
+    // a stage that only ADDS occupied voxels that are painted / coloured explicitly afterwards
+    void device_changed_keep_paint() {
+        pristine_ = false;
+        host_stale_ = true;
     }
-    size_t colored_voxels() const { return colors_.size(); }
-    // explicit colours of occupied voxels, ascending flat index (for arvx_colors_upload)
-    std::vector<std::pair<int, Vec4f>> sorted_colors() const {
-        std::vector<std::pair<int, Vec4f>> v;
-        v.reserve(colors_.size());
-        for (const auto &kv : colors_)
-            if (kv.second.w() != 0) v.push_back(kv);
-        std::sort(v.begin(), v.end(),
+
+    // Colours of many voxels at once, ascending flat index (what arvx_surface_download and
+    // arvx_closure_download deliver): model.set(x, y, z, (r, g, b, a)) for each, without the
+    // per-voxel cost.  `occupy`: the voxels become occupied (closure).
+    void set_sorted(const std::vector<int64_t> &index, const float *rgba, int channels,
+                    bool occupy) {
+        if (index.empty()) return;
+        // (the planes are only touched to occupy voxels or to clear paint)
+        const bool touch = occupy || !paint_.empty() || paint_pending_;
+        if (touch) sync_host();
+        std::vector<int> idx(index.size());
+        std::vector<Vec4f> val(index.size());
+        for (size_t k = 0; k < index.size(); ++k) {
+            idx[k] = (int)index[k];
+            const float *c = rgba + (size_t)channels * k;
+            val[k] = Vec4f(c[0], c[1], c[2], channels == 4 ? c[3] : 1.f);
+            const int x = idx[k] % size_x, y = (idx[k] / size_x) % size_y,
+                      z = idx[k] / (size_x * size_y);
+            if (touch) {
+                const size_t w = word(x, y, z);
+                const uint32_t b = 1u << (x & 31);
+                if (occupy && val[k].w() != 0) occ_[w] |= b;
+                if (!paint_.empty()) paint_[w] &= ~b;
+            }
+            if (!overlay_.empty()) overlay_.erase(idx[k]);
+        }
+        if (cidx_.empty()) {
+            cidx_.swap(idx);
+            cval_.swap(val);
+        } else {  // merge, the new values win
+            std::vector<int> mi;
+            std::vector<Vec4f> mv;
+            mi.reserve(cidx_.size() + idx.size());
+            mv.reserve(cidx_.size() + idx.size());
+            size_t a = 0, b = 0;
+            while (a < cidx_.size() || b < idx.size()) {
+                if (b == idx.size() || (a < cidx_.size() && cidx_[a] < idx[b])) {
+                    mi.push_back(cidx_[a]);
+                    mv.push_back(cval_[a++]);
+                } else {
+                    if (a < cidx_.size() && cidx_[a] == idx[b]) ++a;
+                    mi.push_back(idx[b]);
+                    mv.push_back(val[b++]);
+                }
+            }
+            cidx_.swap(mi);
+            cval_.swap(mv);
+        }
+        pristine_ = false;
+    }
+
+    // explicit colours of occupied, unpainted voxels, ascending flat index
+    // (for arvx_colors_upload); false if one of them has w != 1 (the device list holds RGB only)
+    bool sorted_colors(std::vector<int64_t> &index, std::vector<float> &rgb) const {
+        sync_host();
+        std::vector<std::pair<int, Vec4f>> extra(overlay_.begin(), overlay_.end());
+        std::sort(extra.begin(), extra.end(),
                   [](const std::pair<int, Vec4f> &a, const std::pair<int, Vec4f> &b) {
                       return a.first < b.first;
                   });
-        return v;
+        index.clear();
+        rgb.clear();
+        bool plain = true;
+        auto emit = [&](int i, const Vec4f &v) {
+            const int x = i % size_x, y = (i / size_x) % size_y, z = i / (size_x * size_y);
+            const size_t w = word(x, y, z);
+            const uint32_t b = 1u << (x & 31);
+            if (!(occ_[w] & b) || (!paint_.empty() && (paint_[w] & b))) return;
+            if (v == model_color()) return;  // what the state alone says
+            if (v.w() != 1.f) plain = false;
+            index.push_back(i);
+            rgb.push_back(v.x());
+            rgb.push_back(v.y());
+            rgb.push_back(v.z());
+        };
+        size_t a = 0, b = 0;
+        while (a < cidx_.size() || b < extra.size()) {
+            if (b == extra.size() || (a < cidx_.size() && cidx_[a] < extra[b].first)) {
+                emit(cidx_[a], cval_[a]);
+                ++a;
+            } else {
+                if (a < cidx_.size() && cidx_[a] == extra[b].first) ++a;
+                emit(extra[b].first, extra[b].second);
+                ++b;
+            }
+        }
+        return plain;
+    }
+
+    // one byte per voxel as the C-ABI's byte plane wants it: bit0 occupied, bit1 seen,
+    // bit2 painted UNSEEN_COLOR (arvx_closure) -- the slow path for models whose paint is not
+    // simply "not seen"
+    std::vector<uint8_t> byte_state() const {
+        sync_host();
+        std::vector<uint8_t> s(voxels());
+        for (int z = 0; z < size_z; ++z)
+            for (int y = 0; y < size_y; ++y)
+                for (int x = 0; x < size_x; ++x) {
+                    const size_t w = word(x, y, z);
+                    const int sh = x & 31;
+                    s[(size_t)flatten(x, y, z)] =
+                        (uint8_t)(((occ_[w] >> sh) & 1u) | (((seen_[w] >> sh) & 1u) << 1) |
+                                  ((!paint_.empty() ? (paint_[w] >> sh) & 1u : 0u) << 2));
+                }
+        return s;
+    }
+    // one byte per voxel, 1 where marching cubes counts the voxel as inside (w >= threshold,
+    // the complement of src/MarchingCubes.h:481); `same_as_occupancy` tells the caller that the
+    // occupancy on the device already is that plane (every w is 0 or 1, 0 < threshold <= 1)
+    std::vector<uint8_t> inside_state(float threshold, bool &same_as_occupancy) const {
+        sync_host();
+        same_as_occupancy = threshold > 0.f && threshold <= 1.f;
+        auto odd = [&](const Vec4f &v) { return v.w() != 0.f && v.w() != 1.f; };
+        for (const auto &kv : overlay_) same_as_occupancy = same_as_occupancy && !odd(kv.second);
+        for (const Vec4f &v : cval_) same_as_occupancy = same_as_occupancy && !odd(v);
+        if (same_as_occupancy) return {};
+        std::vector<uint8_t> s(voxels());
+        for (int z = 0; z < size_z; ++z)
+            for (int y = 0; y < size_y; ++y)
+                for (int x = 0; x < size_x; ++x)
+                    s[(size_t)flatten(x, y, z)] = get(x, y, z).w() >= threshold ? 1 : 0;
+        return s;
+    }
+    size_t colored_voxels() const { return cidx_.size() + overlay_.size(); }
+
+    // bring the host planes up to date with the device (no-op when they are)
+    void sync_host() const {
+        if (!host_stale_) return;
+        host_stale_ = false;
+        detail::check(arvx_state_download_planes(link_->ctx, occ_.data(), seen_.data()),
+                      "arvx_state_download_planes");
+        Model *self = const_cast<Model *>(this);
+        if (paint_pending_) {
+            paint_pending_ = false;
+            self->paint_unseen_host();
+        }
+        // what set() stored for a voxel that the device has carved since is gone
+        // (src/VoxelCarving.cpp:52 overwrites the voxel with zeros)
+        for (auto it = self->overlay_.begin(); it != self->overlay_.end();) {
+            const int i = it->first;
+            const int x = i % size_x, y = (i / size_x) % size_y, z = i / (size_x * size_y);
+            const bool o = (occ_[word(x, y, z)] >> (x & 31)) & 1u;
+            if (it->second.w() != 0 && !o) it = self->overlay_.erase(it);
+            else ++it;
+        }
     }
 
    private:
     const int size_x, size_y, size_z;
     const float voxel_size;
-    std::vector<uint8_t> state_;
+    const int wpr_;  // 32-bit words per voxel row
+    mutable std::vector<uint32_t> occ_, seen_;  // bit planes, rows padded to words
+    mutable std::vector<uint32_t> paint_;       // painted UNSEEN_COLOR (empty: none)
     bool pristine_ = true;
-    bool painted_ = false;  // handleUnseen() ran: some bytes may carry kUnseenPaint
-    std::unordered_map<int, Vec4f> colors_;
+    bool paint_is_unseen_ = false;
+    mutable bool paint_pending_ = false;  // handleUnseen ran on the device: derive paint_ at sync
+    mutable bool host_stale_ = false;     // the device holds a newer occupancy / seen
+    bool device_stale_ = true;            // the host planes changed since the device saw them
+    bool colors_on_device_ = false;
+    bool closure_on_device_ = false, mc_only_ = false;
+    std::vector<int> cidx_;               // explicit colours, ascending flat index ...
+    std::vector<Vec4f> cval_;
+    std::unordered_map<int, Vec4f> overlay_;  // ... and what single set() calls stored since
     std::unordered_map<int, std::vector<DCLR>> color_lists_;
+    std::shared_ptr<detail::DeviceLink> link_;
 
     int flatten(int x, int y, int z) const {  // src/Model.h:104-106
         return x + getX() * (y + getY() * z);
     }
+    size_t word(int x, int y, int z) const {
+        return ((size_t)z * size_y + y) * wpr_ + (size_t)(x >> 5);
+    }
     bool occ(int x, int y, int z) const {
         if (x < 0 || x >= size_x || y < 0 || y >= size_y || z < 0 || z >= size_z) return false;
-        return state_[flatten(x, y, z)] & kOcc;
+        sync_host();
+        return (occ_[word(x, y, z)] >> (x & 31)) & 1u;
+    }
+    void host_changed() {
+        pristine_ = false;
+        device_stale_ = true;
+        closure_on_device_ = false;
+        paint_is_unseen_ = false;
+        colors_on_device_ = false;
+    }
+    // occ |= ~seen, paint |= ~seen (inside the grid); explicit colours of those voxels go
+    void paint_unseen_host() {
+        if (paint_.empty()) paint_.assign(occ_.size(), 0u);
+        const uint32_t last = (size_x & 31) ? ((1u << (size_x & 31)) - 1u) : 0xffffffffu;
+        for (size_t i = 0; i < occ_.size(); ++i) {
+            const uint32_t valid = ((int)(i % wpr_) == wpr_ - 1) ? last : 0xffffffffu;
+            const uint32_t u = ~seen_[i] & valid;
+            occ_[i] |= u;
+            paint_[i] |= u;
+        }
+        for (auto it = overlay_.begin(); it != overlay_.end();) {
+            const int i = it->first;
+            const int x = i % size_x, y = (i / size_x) % size_y, z = i / (size_x * size_y);
+            if (!((seen_[word(x, y, z)] >> (x & 31)) & 1u)) it = overlay_.erase(it);
+            else ++it;
+        }
     }
 };
 

@@ -5,7 +5,8 @@
 // result is one dilation with a kernelSize^3 box (its erosion half tests w < 0
 // and never fires); new voxels get the mean RGBA of their occupied
 // neighbours.  Limitation: explicit colours must have w == 1 (every colour the
-// reference's own pipeline produces has).
+// reference's own pipeline produces has).  Runs on the model's own device context: state and
+// the colour list of the colour pass are already there (src/main.cpp:282-299).
 #ifndef ARVX_POSTPROCESSING_HPP
 #define ARVX_POSTPROCESSING_HPP
 
@@ -20,29 +21,29 @@ inline int applyClosure(Model *model, int kernelSize) {
         return -1;
     }
     detail::timing(kStagePostProcessing, true);
-    arvx_ctx *ctx = nullptr;
-    detail::check(arvx_ctx_create(&ctx, 0, model->getX(), model->getY(), model->getZ(),
-                                  model->getSize()),
-                  "arvx_ctx_create");
-    struct Guard {
-        arvx_ctx *c;
-        ~Guard() { arvx_ctx_destroy(c); }
-    } guard{ctx};
-    // bit2 of the host state = painted UNSEEN_COLOR by handleUnseen(): keep it
-    detail::check(arvx_state_upload(ctx, model->state_data()), "arvx_state_upload");
-    const auto cols = model->sorted_colors();
-    std::vector<int64_t> idx(cols.size());
-    std::vector<float> rgb(cols.size() * 3);
-    for (size_t k = 0; k < cols.size(); ++k) {
-        idx[k] = cols[k].first;
-        rgb[3 * k] = cols[k].second.x();
-        rgb[3 * k + 1] = cols[k].second.y();
-        rgb[3 * k + 2] = cols[k].second.z();
+    arvx_ctx *ctx = model->device();
+    // painted voxels: when the paint is exactly "not seen" (handleUnseen was the last thing that
+    // touched the state) the device derives it itself; otherwise the byte plane carries it (bit2)
+    const bool painted = model->painted();
+    if (painted && !model->paint_is_unseen()) {
+        const std::vector<uint8_t> st = model->byte_state();
+        detail::check(arvx_state_upload(ctx, st.data()), "arvx_state_upload");
+        model->set_colors_on_device(false);
     }
-    detail::check(arvx_colors_upload(ctx, (int64_t)idx.size(), idx.data(), rgb.data()),
-                  "arvx_colors_upload");
+    if (!model->colors_on_device()) {
+        std::vector<int64_t> idx;
+        std::vector<float> rgb;
+        if (!model->sorted_colors(idx, rgb)) {
+            std::cerr << "LOG(ERR) - GPU: applyClosure needs explicit colours with w == 1"
+                      << std::endl;
+            throw Error(ARVX_ERR_INVALID, "explicit colour with w != 1");
+        }
+        detail::check(arvx_colors_upload(ctx, (int64_t)idx.size(), idx.data(), rgb.data()),
+                      "arvx_colors_upload");
+    }
     std::cout << "LOG - PP: starting dilution." << std::endl;
-    detail::check(arvx_closure(ctx, kernelSize, 0), "arvx_closure");
+    detail::check(arvx_closure(ctx, kernelSize, (painted && model->paint_is_unseen()) ? 1 : 0),
+                  "arvx_closure");
     int64_t n = 0;
     detail::check(arvx_closure_count(ctx, &n), "arvx_closure_count");
     std::vector<int64_t> fidx((size_t)n);
@@ -50,9 +51,12 @@ inline int applyClosure(Model *model, int kernelSize) {
     if (n) detail::check(arvx_closure_download(ctx, fidx.data(), frgba.data()),
                          "arvx_closure_download");
     std::cout << "LOG - PP: starting erosion." << std::endl;  // a no-op in the reference too
-    for (int64_t k = 0; k < n; ++k)
-        model->set_flat((int)fidx[k], Vec4f(frgba[4 * k], frgba[4 * k + 1], frgba[4 * k + 2],
-                                            frgba[4 * k + 3]));
+    // the filled voxels: occupied on the device already, with their colours on the host now;
+    // the context keeps its closure result, so the model goes back to "host is current" and a
+    // second closure starts from a fresh upload
+    model->device_changed_keep_paint();
+    model->set_sorted(fidx, frgba.data(), 4, true);
+    model->closure_applied();
     detail::timing(kStagePostProcessing, false);
     std::cout << "LOG - PP: postprocessing completed." << std::endl;
     return 0;

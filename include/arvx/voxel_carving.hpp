@@ -18,7 +18,6 @@
 
 #include <functional>
 #include <iostream>
-#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -46,12 +45,6 @@ struct View {
 
 struct Intrinsics {
     float K[9];  // cameraMatrix converted to CV_32F (src/VoxelCarving.cpp:29-30)
-};
-
-class Error : public std::runtime_error {
-   public:
-    Error(int code, const std::string &what) : std::runtime_error(what), code(code) {}
-    int code;
 };
 
 // called after each view when intermediateMeshes is set (the reference writes
@@ -83,118 +76,85 @@ inline IntermediateHook &defaultIntermediateHook() {
     return hook;
 }
 
-inline void check(int rc, const char *what) {
-    if (rc != ARVX_OK) {
-        std::string msg = std::string(what) + ": " + arvx_last_error();
+// the views of one call on the model's device context: matrices, camera positions, masks
+// (and colour images for the colour pass)
+inline arvx_ctx *bind_views(const Intrinsics &intr, Model &model, const std::vector<View> &views,
+                            bool with_images) {
+    auto fail = [](const char *msg) {
         std::cerr << "LOG(ERR) - GPU: " << msg << std::endl;
-        throw Error(rc, msg);
-    }
-}
-
-// one context for the duration of a call: views + the model's state on the GPU
-class Session {
-   public:
-    Session(const Intrinsics &intr, Model &model, const std::vector<View> &views, int device = 0)
-        : model_(model) {
-        if (views.empty()) throw Error(ARVX_ERR_INVALID, "no views");
-        check(arvx_ctx_create(&ctx_, device, model.getX(), model.getY(), model.getZ(),
-                              model.getSize()),
-              "arvx_ctx_create");
-        const int V = (int)views.size();
-        std::vector<float> M((size_t)V * 12), cam((size_t)V * 3);
-        std::vector<const uint8_t *> masks(V);
-        for (int i = 0; i < V; ++i) {
-            if (views[i].has_M)
-                for (int k = 0; k < 12; ++k) M[12 * (size_t)i + k] = views[i].M[k];
-            else
-                check(arvx_compose_projection(intr.K, views[i].pose, &M[12 * (size_t)i]),
-                      "arvx_compose_projection");
-            // cameras[i] = (pose(0,3), pose(1,3), pose(2,3), 1), src/ColorReconstruction.h:21
-            cam[3 * (size_t)i] = views[i].pose[3];
-            cam[3 * (size_t)i + 1] = views[i].pose[7];
-            cam[3 * (size_t)i + 2] = views[i].pose[11];
-            masks[i] = views[i].mask.data;
-            if (views[i].mask.width != views[0].mask.width ||
-                views[i].mask.height != views[0].mask.height ||
-                views[i].mask.channels != views[0].mask.channels ||
-                views[i].mask.stride != views[0].mask.stride)
-                fail("all masks must share one size and layout");
-        }
-        const Image &m0 = views[0].mask;
-        check(arvx_set_views(ctx_, V, M.data(), cam.data(), masks.data(), m0.width, m0.height,
-                             m0.channels, m0.stride),
-              "arvx_set_views");
-        if (model.pristine()) {  // a new Model: nothing to send
-            check(arvx_state_reset(ctx_), "arvx_state_reset");
-        } else {
-            const std::vector<uint8_t> st = model.device_state();
-            check(arvx_state_upload(ctx_, st.data()), "arvx_state_upload");
-        }
-    }
-    ~Session() { arvx_ctx_destroy(ctx_); }
-    Session(const Session &) = delete;
-    Session &operator=(const Session &) = delete;
-
-    arvx_ctx *ctx() { return ctx_; }
-
-    void set_images(const std::vector<View> &views) {
-        std::vector<const uint8_t *> imgs(views.size());
-        for (size_t i = 0; i < views.size(); ++i) {
+        throw Error(ARVX_ERR_INVALID, msg);
+    };
+    if (views.empty()) fail("no views");
+    arvx_ctx *ctx = model.device();
+    const int V = (int)views.size();
+    std::vector<float> M((size_t)V * 12), cam((size_t)V * 3);
+    std::vector<const uint8_t *> masks(V), imgs(V);
+    for (int i = 0; i < V; ++i) {
+        if (views[i].has_M)
+            for (int k = 0; k < 12; ++k) M[12 * (size_t)i + k] = views[i].M[k];
+        else
+            check(arvx_compose_projection(intr.K, views[i].pose, &M[12 * (size_t)i]),
+                  "arvx_compose_projection");
+        // cameras[i] = (pose(0,3), pose(1,3), pose(2,3), 1), src/ColorReconstruction.h:21
+        cam[3 * (size_t)i] = views[i].pose[3];
+        cam[3 * (size_t)i + 1] = views[i].pose[7];
+        cam[3 * (size_t)i + 2] = views[i].pose[11];
+        masks[i] = views[i].mask.data;
+        if (views[i].mask.width != views[0].mask.width ||
+            views[i].mask.height != views[0].mask.height ||
+            views[i].mask.channels != views[0].mask.channels ||
+            views[i].mask.stride != views[0].mask.stride)
+            fail("all masks must share one size and layout");
+        if (with_images) {
             const Image &im = views[i].image;
             if (!im.data || im.channels != 3 || im.width != views[0].mask.width ||
                 im.height != views[0].mask.height || im.stride != views[0].image.stride)
                 fail("colour images must be BGR u8 with the masks' size");
             imgs[i] = im.data;
         }
-        check(arvx_set_images(ctx_, imgs.data(), views[0].image.stride), "arvx_set_images");
     }
+    const Image &m0 = views[0].mask;
+    check(arvx_set_views(ctx, V, M.data(), cam.data(), masks.data(), m0.width, m0.height,
+                         m0.channels, m0.stride),
+          "arvx_set_views");
+    if (with_images)
+        check(arvx_set_images(ctx, imgs.data(), views[0].image.stride), "arvx_set_images");
+    return ctx;
+}
 
-    void pull_state() {
-        if (model_.plain()) {  // nothing but occupied/seen bits on either side
-            check(arvx_state_download(ctx_, model_.state_data()), "arvx_state_download");
-            return;
-        }
-        std::vector<uint8_t> st(model_.voxels());
-        check(arvx_state_download(ctx_, st.data()), "arvx_state_download");
-        model_.absorb_state(st.data());
-    }
-
-    void color(int mode) {
-        check(arvx_color(ctx_, mode), "arvx_color");
-        int64_t n = 0;
-        check(arvx_surface_count(ctx_, &n), "arvx_surface_count");
-        std::vector<int64_t> idx((size_t)n);
-        std::vector<float> rgb((size_t)n * 3);
-        if (n) check(arvx_surface_download(ctx_, idx.data(), rgb.data()), "arvx_surface_download");
-        for (int64_t k = 0; k < n; ++k)  // model.set(x,y,z,(R,G,B,1)), ColorReconstruction.cpp:41/65
-            model_.set_flat((int)idx[k], Vec4f(rgb[3 * k], rgb[3 * k + 1], rgb[3 * k + 2], 1.f));
-    }
-
-   private:
-    [[noreturn]] static void fail(const char *msg) {
-        std::cerr << "LOG(ERR) - GPU: " << msg << std::endl;
-        throw Error(ARVX_ERR_INVALID, msg);
-    }
-    Model &model_;
-    arvx_ctx *ctx_ = nullptr;
-};
+// colour vote on the device, result into the model (model.set(x, y, z, (R, G, B, 1)) for every
+// voxel that received a sample, src/ColorReconstruction.cpp:41/65)
+inline void color_pass(const Intrinsics &intr, Model &model, const std::vector<View> &views,
+                       int mode) {
+    arvx_ctx *ctx = bind_views(intr, model, views, true);
+    const bool had_colors = model.colored_voxels() != 0;
+    check(arvx_color(ctx, mode), "arvx_color");
+    int64_t n = 0;
+    check(arvx_surface_count(ctx, &n), "arvx_surface_count");
+    std::vector<int64_t> idx((size_t)n);
+    std::vector<float> rgb((size_t)n * 3);
+    if (n) check(arvx_surface_download(ctx, idx.data(), rgb.data()), "arvx_surface_download");
+    model.set_sorted(idx, rgb.data(), 3, false);
+    model.set_colors_on_device(!had_colors);
+}
 
 }  // namespace detail
 
-// reference carve(): every view carves the model; `model` may already be carved.
+// reference carve(): every view carves the model; `model` may already be carved.  The result
+// stays on the device until somebody reads the model on the host.
 inline void carve(const Intrinsics &intr, Model &model, const std::vector<View> &views,
                   bool intermediateMeshes = false, const IntermediateHook &hook = nullptr) {
     std::cout << "LOG - VC: starting carving process (version 1)." << std::endl;
     detail::timing(kStageCarving, true);
-    detail::Session s(intr, model, views);
+    arvx_ctx *ctx = detail::bind_views(intr, model, views, false);
     const IntermediateHook &each = hook ? hook : detail::defaultIntermediateHook();
     if (!intermediateMeshes) {
-        detail::check(arvx_carve(s.ctx(), 0), "arvx_carve");
-        s.pull_state();
+        detail::check(arvx_carve(ctx, 0), "arvx_carve");
+        model.device_changed();
     } else {
         for (int i = 0; i < (int)views.size(); ++i) {  // one view at a time, :63-69
-            detail::check(arvx_carve_views(s.ctx(), i, 1, 0), "arvx_carve_views");
-            s.pull_state();
+            detail::check(arvx_carve_views(ctx, i, 1, 0), "arvx_carve_views");
+            model.device_changed();
             std::cout << "LOG - VC: completed carving of a single image." << std::endl;
             if (each) {
                 std::cout << "LOG - VC: generating intermediate mesh for image " << i << std::endl;
@@ -202,6 +162,7 @@ inline void carve(const Intrinsics &intr, Model &model, const std::vector<View> 
             }
         }
     }
+    detail::check(arvx_ctx_synchronize(ctx), "arvx_ctx_synchronize");
     detail::timing(kStageCarving, false);
     std::cout << "LOG - VC: carving complete." << std::endl;
 }
@@ -210,9 +171,9 @@ inline void carve(const Intrinsics &intr, Model &model, const std::vector<View> 
 inline void fastCarve(const Intrinsics &intr, Model &model, const std::vector<View> &views) {
     std::cout << "LOG - VC: starting carving process (version 2)." << std::endl;
     detail::timing(kStageCarving, true);
-    detail::Session s(intr, model, views);
-    detail::check(arvx_fast_carve(s.ctx()), "arvx_fast_carve");
-    s.pull_state();
+    arvx_ctx *ctx = detail::bind_views(intr, model, views, false);
+    detail::check(arvx_fast_carve(ctx), "arvx_fast_carve");
+    model.device_changed();
     detail::timing(kStageCarving, false);
     std::cout << "LOG - VC: carving complete." << std::endl;
 }
@@ -221,9 +182,7 @@ inline void reconstructClosestColor(const Intrinsics &intr, Model &model,
                                     const std::vector<View> &views) {
     std::cout << "LOG - CR: starting color reconstruction (closest color)." << std::endl;
     detail::timing(kStageColoring, true);
-    detail::Session s(intr, model, views);
-    s.set_images(views);
-    s.color(ARVX_COLOR_CLOSEST);
+    detail::color_pass(intr, model, views, ARVX_COLOR_CLOSEST);
     detail::timing(kStageColoring, false);
     std::cout << "LOG - CR: color reconstruction finished." << std::endl;
 }
@@ -232,9 +191,7 @@ inline void reconstructAvgColor(const Intrinsics &intr, Model &model,
                                 const std::vector<View> &views) {
     std::cout << "LOG - CR: starting color reconstruction (average color)." << std::endl;
     detail::timing(kStageColoring, true);
-    detail::Session s(intr, model, views);
-    s.set_images(views);
-    s.color(ARVX_COLOR_AVERAGE);
+    detail::color_pass(intr, model, views, ARVX_COLOR_AVERAGE);
     detail::timing(kStageColoring, false);
     std::cout << "LOG - CR: color reconstruction finished." << std::endl;
 }

@@ -115,7 +115,7 @@ static int run_carve(const char *scene, const char *out, const char *mode) {
             arvx::reconstructClosestColor(intr, model, views);
         } else if (!std::strcmp(mode, "recarve_colored")) {
             // a coloured, painted model goes through the carve again: state comes back
-            // through Model::absorb_state, colours and paint stay where voxels survive
+            // as bit planes; colours and paint stay where voxels survive
             arvx::carve(intr, model, views);
             arvx::reconstructClosestColor(intr, model, views);
             model.handleUnseen();

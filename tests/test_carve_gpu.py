@@ -567,3 +567,43 @@ def test_view_by_view_on_random_states_many_seeds(arvx, oracle):
                 ctx.carve_views(i, 1)
                 cur = oracle.carve_view(N, N, N, sc.voxel_size, sc.M[i], sc.masks[i], cur)
                 assert_same(ctx.download_state(), cur, f"seed {seed} view {i}")
+
+
+def planes_of(state):
+    """(occ, seen) uint32 bit planes of a (Z, Y, X) state array, rows padded to 32-bit words."""
+    Z, Y, X = state.shape
+    wpr = (X + 31) // 32
+    out = []
+    for bit in (1, 2):
+        b = np.zeros((Z, Y, wpr * 32), np.uint8)
+        b[:, :, :X] = (state & bit) != 0
+        out.append(np.packbits(b, axis=2, bitorder="little").view(np.uint32).reshape(-1))
+    return out
+
+
+@pytest.mark.parametrize("dims,zr", [((64, 8, 8), None), ((100, 100, 50), None), ((33, 17, 9), None),
+                                     ((40, 24, 40), (9, 31)), ((128, 64, 32), (8, 16))])
+def test_bit_plane_transfers(arvx, oracle, dims, zr):
+    """arvx_state_download_planes / _upload_planes (the 2-bit form a host Model keeps) against
+    the byte plane: after a carve, and for random planes, on whole grids and slabs."""
+    X, Y, Z = dims
+    sc = scenes.small_sphere(32, 5)
+    s = np.float32(0.512 / max(dims))
+    want = oracle.carve(X, Y, Z, s, sc.M, sc.masks)
+    rng = np.random.default_rng(X + Y)
+    with arvx.Context(X, Y, Z, s, z_range=zr) as ctx:
+        ctx.set_views(sc.M, sc.masks)
+        ctx.carve()
+        mine = want if zr is None else want[zr[0]:zr[1]]
+        occ, seen = ctx.download_planes()
+        wocc, wseen = planes_of(mine)
+        assert np.array_equal(occ, wocc) and np.array_equal(seen, wseen)
+        assert_same(ctx.download_state(), mine, "bytes after planes")
+        st = rng.choice(np.array([0, 1, 2, 3], np.uint8), size=mine.shape)
+        ctx.upload_planes(*planes_of(st))
+        assert_same(ctx.download_state(), st, "uploaded planes")
+        o2, s2 = ctx.download_planes()
+        assert np.array_equal(o2, planes_of(st)[0]) and np.array_equal(s2, planes_of(st)[1])
+        ctx.carve()  # and the carve continues from them
+        again = oracle.carve_planes(X, Y, s, sc.M, sc.masks, ctx.planes, state=st)
+        assert_same(ctx.download_state(), again, "carve after uploaded planes")
