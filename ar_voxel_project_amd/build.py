@@ -31,7 +31,7 @@ def build_host_tests() -> str:
     """g++ -> tests/cpp/test_host: the C++ host layer (include/arvx/*.hpp) over libarvx.so"""
     build_library()
     _make("tests/cpp")
-    _make("tools/cpp")  # arvx_bench6: the reference's -c=6 table over the C++ layer
+    _make("tools/cpp", "all")  # arvx_bench6 (the reference's -c=6 table), arvx_dropin_time
     return os.path.join(ROOT, "tests", "cpp", "test_host")
 
 

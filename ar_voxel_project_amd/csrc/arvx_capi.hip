@@ -268,8 +268,16 @@ static int views_common(Ctx *ctx, int V, const float *M, const float *campos, in
     if (W < 1 || H < 1 || W > arvx::kMaxImageDim || H > arvx::kMaxImageDim)
         return fail(ARVX_ERR_INVALID, "image size %dx%d out of range", W, H);
     if (C < 1 || C > 4) return fail(ARVX_ERR_INVALID, "channels=%d out of range [1,4]", C);
-    ctx->free_views();
-    ctx->free_color();
+    // the same number and size of views as before: keep every buffer (a pipeline sends its
+    // views once per stage, src/main.cpp:262-284)
+    const bool same = ctx->d_M && ctx->V == V && ctx->W == W && ctx->H == H;
+    ctx->views_ready = false;
+    ctx->free_surface();  // colour results belong to the previous views
+    if (!same) {
+        ctx->free_views();
+        ctx->free_color();
+    }
+    ctx->images_ready = false;
     ctx->V = V;
     ctx->W = W;
     ctx->H = H;
@@ -283,10 +291,16 @@ static int views_common(Ctx *ctx, int V, const float *M, const float *campos, in
     ctx->satW = (W + blk - 1) / blk + 1;
     ctx->satH = (H + blk - 1) / blk + 1;
     ctx->satStride = ctx->satW * ctx->satH;
-    ARVX_HIP(hipMalloc(&ctx->d_M, (size_t)V * 12 * sizeof(float)));
-    ARVX_HIP(hipMalloc(&ctx->d_campos, (size_t)V * 3 * sizeof(float)));
-    ARVX_HIP(hipMalloc(&ctx->d_bg, (size_t)V * ctx->bgWords * sizeof(uint32_t)));
-    ARVX_HIP(hipMalloc(&ctx->d_sat, (size_t)V * ctx->satStride * sizeof(int)));
+    if (!same) {
+        hipError_t e = hipMalloc(&ctx->d_M, (size_t)V * 12 * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&ctx->d_campos, (size_t)V * 3 * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&ctx->d_bg, (size_t)V * ctx->bgWords * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&ctx->d_sat, (size_t)V * ctx->satStride * sizeof(int));
+        if (e != hipSuccess) {
+            ctx->free_views();  // whatever was allocated before the failure
+            return arvx::fail_hip(e, "hipMalloc(views)", __FILE__, __LINE__);
+        }
+    }
     ctx->h_M.assign(M, M + (size_t)V * 12);
     ARVX_HIP(hipMemcpyAsync(ctx->d_M, ctx->h_M.data(), (size_t)V * 12 * sizeof(float),
                             hipMemcpyHostToDevice, ctx->stream));
@@ -361,21 +375,20 @@ int arvx_set_views(arvx_ctx *ctx, int V, const float *M, const float *campos,
     int rc = views_common(ctx, V, M, campos, W, H, C);
     if (rc) return rc;
     const size_t img = (size_t)W * H * C;
-    uint8_t *d_raw = nullptr;
-    ARVX_HIP(hipMalloc(&d_raw, img * V));
-    for (int i = 0; i < V; ++i) {
-        hipError_t e = hipMemcpy2DAsync(d_raw + img * i, (size_t)W * C, masks[i], stride,
-                                        (size_t)W * C, H, hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) {
-            (void)hipFree(d_raw);
-            return arvx::fail_hip(e, "hipMemcpy2DAsync(mask)", __FILE__, __LINE__);
-        }
+    ARVX_HIP(ctx->pool_raw_masks.reserve(img * V));
+    uint8_t *d_raw = (uint8_t *)ctx->pool_raw_masks.p;
+    bool packed = stride == (size_t)W * C;  // all views back to back in host memory: one copy
+    for (int i = 1; i < V && packed; ++i) packed = masks[i] == masks[i - 1] + img;
+    if (packed) {
+        ARVX_HIP(hipMemcpyAsync(d_raw, masks[0], img * V, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        for (int i = 0; i < V; ++i)
+            ARVX_HIP(hipMemcpy2DAsync(d_raw + img * i, (size_t)W * C, masks[i], stride,
+                                      (size_t)W * C, H, hipMemcpyHostToDevice, ctx->stream));
     }
     rc = views_preprocess(ctx, d_raw, C);
-    hipError_t e = hipStreamSynchronize(ctx->stream);  // host buffers may go away
-    (void)hipFree(d_raw);
     if (rc) return rc;
-    if (e != hipSuccess) return arvx::fail_hip(e, "hipStreamSynchronize", __FILE__, __LINE__);
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));  // host buffers may go away
     return ARVX_OK;
 }
 
@@ -383,24 +396,7 @@ int arvx_set_views_device(arvx_ctx *ctx, int V, const float *M, const float *cam
                           const void *dev_masks, int W, int H, int C) {
     ARVX_CHECK_CTX(ctx);
     if (!dev_masks) return fail(ARVX_ERR_INVALID, "null dev_masks");
-    const bool same = ctx->views_ready && ctx->V == V && ctx->W == W && ctx->H == H;
-    if (same) {
-        // keep the allocations: refresh matrices and re-derive the planes, all async
-        if (!M) return fail(ARVX_ERR_INVALID, "null M");
-        ctx->h_M.assign(M, M + (size_t)V * 12);
-        ARVX_HIP(hipMemcpyAsync(ctx->d_M, ctx->h_M.data(), (size_t)V * 12 * sizeof(float),
-                                hipMemcpyHostToDevice, ctx->stream));
-        ctx->has_campos = campos != nullptr;
-        if (campos) {
-            ctx->h_campos.assign(campos, campos + (size_t)V * 3);
-            ARVX_HIP(hipMemcpyAsync(ctx->d_campos, ctx->h_campos.data(),
-                                    (size_t)V * 3 * sizeof(float), hipMemcpyHostToDevice,
-                                    ctx->stream));
-        }
-    } else {
-        int rc = views_common(ctx, V, M, campos, W, H, C);
-        if (rc) return rc;
-    }
+    if (int rc = views_common(ctx, V, M, campos, W, H, C)) return rc;
     return views_preprocess(ctx, (const uint8_t *)dev_masks, C);
 }
 
@@ -958,9 +954,16 @@ int arvx_set_images(arvx_ctx *ctx, const uint8_t *const *images, size_t stride) 
         if (!images[i]) return fail(ARVX_ERR_INVALID, "null image %d", i);
     const size_t img = rowb * ctx->H;
     if (!ctx->d_images) ARVX_HIP(hipMalloc(&ctx->d_images, img * ctx->V));
-    for (int i = 0; i < ctx->V; ++i)
-        ARVX_HIP(hipMemcpy2DAsync(ctx->d_images + img * i, rowb, images[i], stride, rowb, ctx->H,
-                                  hipMemcpyHostToDevice, ctx->stream));
+    bool packed = stride == rowb;
+    for (int i = 1; i < ctx->V && packed; ++i) packed = images[i] == images[i - 1] + img;
+    if (packed) {
+        ARVX_HIP(hipMemcpyAsync(ctx->d_images, images[0], img * ctx->V, hipMemcpyHostToDevice,
+                                ctx->stream));
+    } else {
+        for (int i = 0; i < ctx->V; ++i)
+            ARVX_HIP(hipMemcpy2DAsync(ctx->d_images + img * i, rowb, images[i], stride, rowb,
+                                      ctx->H, hipMemcpyHostToDevice, ctx->stream));
+    }
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
     ctx->images_ready = true;
     ctx->color_ready = false;

@@ -116,7 +116,7 @@ struct Ctx {
     bool mc_ready = false;
     // storage behind the d_surf_* / d_clo_* / d_mc_cells views (kept until destroy)
     DevPool pool_surf_index, pool_surf_rgb, pool_surf_depth, pool_surf_has, pool_clo_index,
-        pool_clo_rgba, pool_mc_cells;
+        pool_clo_rgba, pool_mc_cells, pool_raw_masks;
     void release_pools() {
         pool_surf_index.release();
         pool_surf_rgb.release();
@@ -125,6 +125,7 @@ struct Ctx {
         pool_clo_index.release();
         pool_clo_rgba.release();
         pool_mc_cells.release();
+        pool_raw_masks.release();
     }
     void free_mc() {
         d_mc_cells = nullptr;

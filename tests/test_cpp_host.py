@@ -134,9 +134,10 @@ def test_bench6_table(host_bin, oracle, tmp_path):
     Rt[:, :, 3] *= np.float32(scale)
     scene = str(tmp_path / "scene.bin")
     write_scene(scene, 1, 1, 1, 1.0, sc.K, Rt, sc.masks, sc.images, np.ones(1, np.uint8))
-    r = subprocess.run([exe, scene], capture_output=True, text=True)
+    r = subprocess.run([exe, scene], capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr + r.stdout[-2000:]
     assert "Benchmark (all times in milliseconds)" in r.stdout
+    assert "n/a" not in r.stdout  # the marching-cubes column is measured
     rows = [ln for ln in r.stdout.splitlines() if "coloring\t|" in ln]
     assert len(rows) == 8 and rows[3].startswith("Large, V1, avg. coloring") and "100x100x50" in rows[3]
     occ = [int(ln.split()[1]) for ln in r.stdout.splitlines() if ln.startswith("occupied ")]
@@ -151,4 +152,9 @@ def test_bench6_table(host_bin, oracle, tmp_path):
                              oracle.model_from_state(st))
         closed = oracle.closure(X, Y, Z, oracle.handle_unseen(st, model))
         assert got == int((closed[:, 3] != 0).sum()), (dims, ver)
+        if dims == (100, 100, 50):  # and the mesh file the run wrote (src/main.cpp:391,435)
+            verts, rgb = oracle.mc_mesh(X, Y, Z, closed)
+            want = oracle.off_text(verts, rgb, np.float32(1.0) * np.float32(s))
+            name = f"out/bench/mesh_large_{ver}_avg.off"
+            assert open(os.path.join(str(tmp_path), name), "rb").read() == want.encode()
     print(r.stdout[r.stdout.index("Benchmark (all"):])
