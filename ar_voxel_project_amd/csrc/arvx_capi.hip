@@ -272,6 +272,7 @@ static int views_common(Ctx *ctx, int V, const float *M, const float *campos, in
     // views once per stage, src/main.cpp:262-284)
     const bool same = ctx->d_M && ctx->V == V && ctx->W == W && ctx->H == H;
     ctx->views_ready = false;
+    ctx->cameras_ready = false;
     ctx->free_surface();  // colour results belong to the previous views
     if (!same) {
         ctx->free_views();
@@ -344,6 +345,7 @@ static int views_preprocess(Ctx *ctx, const uint8_t *d_masks, int C) {
                            ctx->satStride);
         ARVX_HIP(hipGetLastError());
         ctx->views_ready = true;
+        ctx->cameras_ready = true;
         return ARVX_OK;
     }
     const int Hs = ctx->satH - 1;  // block rows
@@ -361,13 +363,19 @@ static int views_preprocess(Ctx *ctx, const uint8_t *d_masks, int C) {
                            ctx->d_sat, ctx->satStride);
     ARVX_HIP(hipGetLastError());
     ctx->views_ready = true;
+    ctx->cameras_ready = true;
     return ARVX_OK;
 }
 
 int arvx_set_views(arvx_ctx *ctx, int V, const float *M, const float *campos,
                    const uint8_t *const *masks, int W, int H, int C, size_t stride) {
     ARVX_CHECK_CTX(ctx);
-    if (!masks) return fail(ARVX_ERR_INVALID, "null masks");
+    if (!masks) {  // cameras only: enough for arvx_color
+        if (int rc0 = views_common(ctx, V, M, campos, W, H, C > 0 ? C : 1)) return rc0;
+        ctx->cameras_ready = true;
+        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+        return ARVX_OK;
+    }
     if (W >= 1 && C >= 1 && stride < (size_t)W * C)
         return fail(ARVX_ERR_INVALID, "stride %zu < W*C", stride);
     for (int i = 0; i < V; ++i)
@@ -946,7 +954,7 @@ int arvx_get_stats(arvx_ctx *ctx, arvx_stats *out) {
 
 int arvx_set_images(arvx_ctx *ctx, const uint8_t *const *images, size_t stride) {
     ARVX_CHECK_CTX(ctx);
-    if (!ctx->views_ready) return fail(ARVX_ERR_STATE, "arvx_set_views must come first");
+    if (!ctx->cameras_ready) return fail(ARVX_ERR_STATE, "arvx_set_views must come first");
     if (!images) return fail(ARVX_ERR_INVALID, "null images");
     const size_t rowb = (size_t)ctx->W * 3;
     if (stride < rowb) return fail(ARVX_ERR_INVALID, "stride %zu < W*3", stride);
@@ -974,7 +982,7 @@ int arvx_set_images(arvx_ctx *ctx, const uint8_t *const *images, size_t stride) 
 int arvx_color(arvx_ctx *ctx, int mode) {
     ARVX_CHECK_CTX(ctx);
     if (int mrc = need_bytes(ctx)) return mrc;
-    if (!ctx->views_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
+    if (!ctx->cameras_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
     if (!ctx->images_ready) return fail(ARVX_ERR_STATE, "arvx_set_images has not been called");
     if (!ctx->has_campos) return fail(ARVX_ERR_STATE, "arvx_set_views was given no campos");
     if (mode != ARVX_COLOR_CLOSEST && mode != ARVX_COLOR_AVERAGE)

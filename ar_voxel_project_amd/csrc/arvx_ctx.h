@@ -79,7 +79,8 @@ struct Ctx {
     size_t flood_bytes = 0;
 
     // views
-    bool views_ready = false;
+    bool views_ready = false;    // matrices + bit planes + tables: the carve can run
+    bool cameras_ready = false;  // matrices (+ camera positions): enough for the colour pass
     bool has_campos = false;
     int V = 0, W = 0, H = 0;
     int bgWords = 0, satStride = 0;
@@ -150,6 +151,7 @@ struct Ctx {
         d_bg = nullptr;
         d_sat = nullptr;
         views_ready = false;
+        cameras_ready = false;
     }
     void free_surface() {
         free_closure();

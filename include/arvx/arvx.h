@@ -115,7 +115,11 @@ int arvx_compose_projection(const float K[9], const float Rt[12], float M[12]);
  *   masks  V host pointers; each an undistorted mask, H rows of `stride`
  *          bytes, C interleaved u8 channels (reference: 3, BGR); a pixel is
  *          background iff all C bytes are 0 (src/VoxelCarving.cpp:49-50)
- * Copies everything to the device; the host buffers may be freed on return. */
+ * Copies everything to the device; the host buffers may be freed on return.
+ * masks == NULL: cameras only (M, campos, W, H) for a colour pass that follows -- arvx_color
+ * never looks at the masks (the reference undistorts them there and drops them,
+ * src/ColorReconstruction.h:25-28); arvx_carve / arvx_fast_carve then need a full
+ * arvx_set_views first. */
 int arvx_set_views(arvx_ctx *ctx, int V, const float *M, const float *campos,
                    const uint8_t *const *masks, int W, int H, int C,
                    size_t stride);

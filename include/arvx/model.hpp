@@ -423,6 +423,15 @@ class Model {
     }
     size_t colored_voxels() const { return cidx_.size() + overlay_.size(); }
 
+    // the two host planes themselves (ceil(X / 32) * Y * Z words each), for stages that fill
+    // them from elsewhere (include/arvx/multi_gpu.hpp); call planes_replaced() afterwards
+    size_t plane_words() const { return occ_.size(); }
+    const uint32_t *occ_plane() const { sync_host(); return occ_.data(); }
+    const uint32_t *seen_plane() const { sync_host(); return seen_.data(); }
+    uint32_t *occ_plane_for_writing() { sync_host(); return occ_.data(); }
+    uint32_t *seen_plane_for_writing() { return seen_.data(); }
+    void planes_replaced() { host_changed(); }
+
     // bring the host planes up to date with the device (no-op when they are)
     void sync_host() const {
         if (!host_stale_) return;

@@ -114,8 +114,9 @@ inline arvx_ctx *bind_views(const Intrinsics &intr, Model &model, const std::vec
         }
     }
     const Image &m0 = views[0].mask;
-    check(arvx_set_views(ctx, V, M.data(), cam.data(), masks.data(), m0.width, m0.height,
-                         m0.channels, m0.stride),
+    // (the colour pass never looks at the masks: cameras only)
+    check(arvx_set_views(ctx, V, M.data(), cam.data(), with_images ? nullptr : masks.data(),
+                         m0.width, m0.height, m0.channels, m0.stride),
           "arvx_set_views");
     if (with_images)
         check(arvx_set_images(ctx, imgs.data(), views[0].image.stride), "arvx_set_images");

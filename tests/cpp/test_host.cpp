@@ -13,6 +13,7 @@
 
 #include "arvx/calibration.hpp"
 #include "arvx/marching_cubes.hpp"
+#include "arvx/multi_gpu.hpp"
 #include "arvx/postprocessing.hpp"
 #include "arvx/voxel_carving.hpp"
 
@@ -109,6 +110,8 @@ static int run_carve(const char *scene, const char *out, const char *mode) {
         if (!std::strcmp(mode, "carve")) arvx::carve(intr, model, views);
         else if (!std::strcmp(mode, "carve_steps"))
             arvx::carve(intr, model, views, true, [&](int, Model &) { ++hooks; });
+        else if (!std::strcmp(mode, "carve_devices"))  // one process, a list of devices + RCCL
+            arvx::carve(intr, model, views, std::vector<int>{0}, ARVX_MERGE_COMPRESSED);
         else if (!std::strcmp(mode, "fast")) arvx::fastCarve(intr, model, views);
         else if (!std::strcmp(mode, "closest")) {
             arvx::carve(intr, model, views);

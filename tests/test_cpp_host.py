@@ -122,6 +122,27 @@ def test_cpp_entry_points_on_a_new_model(host_bin, oracle, tmp_path, mode):
 
 
 @pytest.mark.gpu
+def test_cpp_carve_over_a_device_list(host_bin, oracle, tmp_path):
+    """arvx::carve(intr, model, views, devices) (include/arvx/multi_gpu.hpp): one process,
+    striped contexts, RCCL merge -- with the one device of this box; Z must be a multiple
+    of 8 and X*Y of 64."""
+    X, Y, Z, V = 32, 16, 24, 5
+    sc = scenes.syn.sphere_scene(32, V, W=96, H=72, with_images=True)
+    s = np.float32(0.512 / 32)
+    rng = np.random.default_rng(4)
+    st0 = np.where(rng.random((Z, Y, X)) < 0.05, 0, 1).astype(np.uint8)
+    scene, out = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
+    write_scene(scene, X, Y, Z, s, sc.K, sc.Rt, sc.masks, sc.images, st0)
+    r = subprocess.run([host_bin, "carve", scene, out, "carve_devices"], capture_output=True,
+                       text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    rgba, seen = read_result(out, X * Y * Z)
+    st = oracle.carve(X, Y, Z, s, oracle.compose(sc.K, sc.Rt), sc.masks, state=st0)
+    assert np.array_equal(seen, (st.reshape(-1) & 2) == 2)
+    assert np.array_equal(rgba, oracle.model_from_state(st))
+
+
+@pytest.mark.gpu
 def test_bench6_table(host_bin, oracle, tmp_path):
     """The reference's -c=6 benchmark sequence (src/main.cpp:306-440) through the C++
     layer: eight runs, reference table layout, occupancy equal to the oracle's."""
