@@ -37,7 +37,7 @@ def test_host_model_under_asan_ubsan(tmp_path):
     libdir = os.path.dirname(capi.LIB_PATH)
     r = run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined",
              "-fno-sanitize-recover=all", "-I" + os.path.join(ROOT, "include"), "-o", exe,
-             os.path.join(ROOT, "tests", "cpp", "test_host.cpp"), "-L" + libdir, "-larvx",
+             os.path.join(ROOT, "tests", "cpp", "test_host.cpp"), "-L" + libdir, "-larvx_mgpu", "-larvx",
              "-Wl,-rpath," + libdir])
     assert r.returncode == 0, r.stderr
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")  # the HIP runtime keeps globals
