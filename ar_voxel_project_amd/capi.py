@@ -33,7 +33,7 @@ SYMBOLS = [
     "arvx_set_images", "arvx_state_reset", "arvx_state_upload",
     "arvx_state_download", "arvx_state_device_ptr", "arvx_state_upload_halo",
     "arvx_state_upload_planes", "arvx_state_download_planes", "arvx_host_register",
-    "arvx_host_unregister", "arvx_handle_unseen",
+    "arvx_host_unregister", "arvx_handle_unseen", "arvx_undistort", "arvx_undistort_device",
     "arvx_pack_occupancy", "arvx_pack_occupancy_global", "arvx_carve", "arvx_carve_views", "arvx_fast_carve",
     "arvx_color", "arvx_surface_count", "arvx_surface_download",
     "arvx_surface_depth_download",
@@ -313,6 +313,25 @@ class Context:
         seen = np.ascontiguousarray(seen, np.uint32)
         assert occ.size == seen.size == self.plane_words()
         self._ck(self._lib.arvx_state_upload_planes(self._h, occ.ctypes.data, seen.ctypes.data))
+
+    def undistort(self, images, K, dist) -> np.ndarray:
+        """cv::undistort on (V,H,W[,C]) uint8 images; returns the same shape."""
+        im = np.ascontiguousarray(images, np.uint8)
+        shape = im.shape
+        if im.ndim == 3:
+            im = im[..., None]
+        V, H, W, Cn = im.shape
+        out = np.empty_like(im)
+        K = np.ascontiguousarray(K, np.float64).reshape(9)
+        dist = np.ascontiguousarray(dist, np.float64).reshape(-1)
+        sp = (C.c_void_p * V)(*[im[i].ctypes.data for i in range(V)])
+        dp = (C.c_void_p * V)(*[out[i].ctypes.data for i in range(V)])
+        self._lib.arvx_undistort.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int,
+                                             C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.POINTER(C.c_void_p)]
+        self._ck(self._lib.arvx_undistort(self._h, V, sp, W, H, Cn, W * Cn, K.ctypes.data,
+                                          dist.ctypes.data if dist.size else None, dist.size, dp))
+        return out.reshape(shape)
 
     def handle_unseen(self) -> None:
         self._ck(self._lib.arvx_handle_unseen(self._h))

@@ -18,6 +18,7 @@
 #include "carve_kernels.h"
 #include "views_kernels.h"
 #include "state_kernels.h"
+#include "undistort_kernels.h"
 #include "color_kernels.h"
 #include "closure_kernels.h"
 #include "bitplane_kernels.h"
@@ -406,6 +407,77 @@ int arvx_set_views_device(arvx_ctx *ctx, int V, const float *M, const float *cam
     if (!dev_masks) return fail(ARVX_ERR_INVALID, "null dev_masks");
     if (int rc = views_common(ctx, V, M, campos, W, H, C)) return rc;
     return views_preprocess(ctx, (const uint8_t *)dev_masks, C);
+}
+
+static int undistort_params(const double K[9], const double *dist, int ndist, int W, int H,
+                            int C, arvx::UndistortParams &p) {
+    if (!K || (!dist && ndist)) return fail(ARVX_ERR_INVALID, "null calibration");
+    if (ndist != 0 && ndist != 4 && ndist != 5 && ndist != 8)
+        return fail(ARVX_ERR_INVALID, "distortion coefficients: 4, 5 or 8 (got %d)", ndist);
+    if (W < 1 || H < 1 || C < 1 || C > 4) return fail(ARVX_ERR_INVALID, "bad image format");
+    if (K[0] == 0 || K[4] == 0) return fail(ARVX_ERR_INVALID, "singular camera matrix");
+    memset(&p, 0, sizeof p);
+    p.fx = K[0];
+    p.fy = K[4];
+    p.cx = K[2];
+    p.cy = K[5];
+    p.ir0 = 1.0 / p.fx;  // inv(A) of an upper-triangular A with a unit last row
+    p.ir2 = -p.cx / p.fx;
+    p.ir4 = 1.0 / p.fy;
+    p.ir5 = -p.cy / p.fy;
+    double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < ndist; ++i) k[i] = dist[i];
+    p.k1 = k[0];
+    p.k2 = k[1];
+    p.p1 = k[2];
+    p.p2 = k[3];
+    p.k3 = k[4];
+    p.k4 = k[5];
+    p.k5 = k[6];
+    p.k6 = k[7];
+    p.W = W;
+    p.H = H;
+    p.C = C;
+    return ARVX_OK;
+}
+
+int arvx_undistort_device(arvx_ctx *ctx, int V, const void *dev_src, int W, int H, int C,
+                          const double K[9], const double *dist, int ndist, void *dev_dst) {
+    ARVX_CHECK_CTX(ctx);
+    if (!dev_src || !dev_dst || dev_src == dev_dst || V < 1)
+        return fail(ARVX_ERR_INVALID, "bad argument (src and dst must differ)");
+    arvx::UndistortParams p;
+    if (int rc = undistort_params(K, dist, ndist, W, H, C, p)) return rc;
+    hipLaunchKernelGGL(arvx::undistort_kernel, dim3((W + 63) / 64, (H + 3) / 4, V), dim3(256), 0,
+                       ctx->stream, (const uint8_t *)dev_src, (uint8_t *)dev_dst, p);
+    ARVX_HIP(hipGetLastError());
+    return ARVX_OK;
+}
+
+int arvx_undistort(arvx_ctx *ctx, int V, const uint8_t *const *src, int W, int H, int C,
+                   size_t stride, const double K[9], const double *dist, int ndist,
+                   uint8_t *const *dst) {
+    ARVX_CHECK_CTX(ctx);
+    if (!src || !dst || V < 1) return fail(ARVX_ERR_INVALID, "bad argument");
+    arvx::UndistortParams p;
+    if (int rc = undistort_params(K, dist, ndist, W, H, C, p)) return rc;
+    const size_t rowb = (size_t)W * C, img = rowb * H;
+    if (stride < rowb) return fail(ARVX_ERR_INVALID, "stride %zu < W*C", stride);
+    for (int i = 0; i < V; ++i)
+        if (!src[i] || !dst[i]) return fail(ARVX_ERR_INVALID, "null image %d", i);
+    if (int rc = ensure_scratch(ctx, 2 * img * V + 64)) return rc;
+    uint8_t *d_src = (uint8_t *)ctx->d_scratch, *d_dst = d_src + img * V;
+    for (int i = 0; i < V; ++i)
+        ARVX_HIP(hipMemcpy2DAsync(d_src + img * i, rowb, src[i], stride, rowb, H,
+                                  hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(arvx::undistort_kernel, dim3((W + 63) / 64, (H + 3) / 4, V), dim3(256), 0,
+                       ctx->stream, d_src, d_dst, p);
+    ARVX_HIP(hipGetLastError());
+    for (int i = 0; i < V; ++i)
+        ARVX_HIP(hipMemcpy2DAsync(dst[i], stride, d_dst + img * i, rowb, rowb, H,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    return ARVX_OK;
 }
 
 // ---- state -------------------------------------------------------------------

@@ -128,6 +128,20 @@ int arvx_set_views(arvx_ctx *ctx, int V, const float *M, const float *campos,
 int arvx_set_views_device(arvx_ctx *ctx, int V, const float *M,
                           const float *campos, const void *dev_masks, int W,
                           int H, int C);
+/* cv::undistort(src, dst, cameraMatrix, distCoeffs) for V images of one size on the device --
+ * what the reference does to every mask and image before its voxel loops
+ * (src/VoxelCarving.cpp:35-36; src/ColorReconstruction.h:22-27): map in double precision,
+ * 5-bit fixed-point bilinear weights, constant-0 border (csrc/undistort_kernels.h; restated
+ * from OpenCV 4.x, parity UNPINNED -- no OpenCV in this image).  K: cameraMatrix row-major;
+ * dist: k1 k2 p1 p2 [k3 [k4 k5 k6]] (ndist = 4, 5 or 8).  src/dst: V host images, H rows of
+ * `stride` bytes, C interleaved u8 channels; dst may equal src.  The _device form takes and
+ * leaves tightly packed images in device memory (dst != src), ready for
+ * arvx_set_views_device. */
+int arvx_undistort(arvx_ctx *ctx, int V, const uint8_t *const *src, int W, int H, int C,
+                   size_t stride, const double K[9], const double *dist, int ndist,
+                   uint8_t *const *dst);
+int arvx_undistort_device(arvx_ctx *ctx, int V, const void *dev_src, int W, int H, int C,
+                          const double K[9], const double *dist, int ndist, void *dev_dst);
 /* Undistorted colour images for arvx_color: V host pointers, BGR u8, H rows
  * of `stride` bytes, same W/H as the masks. */
 int arvx_set_images(arvx_ctx *ctx, const uint8_t *const *images, size_t stride);

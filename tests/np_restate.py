@@ -220,3 +220,47 @@ def mc_mesh(X, Y, Z, rgba, threshold=0.5):
     if not faces:
         return np.zeros((0, 3), F32), np.zeros((0, 3), np.int64)
     return np.array(verts, F32), np.array(faces, np.int64)
+
+
+# ---- cv::undistort (OpenCV 4.x calib3d/imgproc, restated; see csrc/undistort_kernels.h) -------
+
+def undistort(img, K, dist):
+    """img (H,W[,C]) uint8 -> same shape: initUndistortRectifyMap (double) + remap with 5-bit
+    fixed-point bilinear weights and a constant-0 border."""
+    im = np.asarray(img, np.uint8)
+    squeeze = im.ndim == 2
+    if squeeze:
+        im = im[..., None]
+    H, W, C = im.shape
+    K = np.asarray(K, F64).reshape(3, 3)
+    k = np.zeros(8, F64)
+    d = np.asarray(dist, F64).reshape(-1)
+    k[:len(d)] = d
+    k1, k2, p1, p2, k3, k4, k5, k6 = k
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    u = np.arange(W, dtype=F64)[None, :]
+    v = np.arange(H, dtype=F64)[:, None]
+    x = u * (1.0 / fx) + (-cx / fx) + 0 * v
+    y = v * (1.0 / fy) + (-cy / fy) + 0 * u
+    x2, y2 = x * x, y * y
+    r2 = x2 + y2
+    _2xy = 2 * x * y
+    kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2)
+    xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2)
+    yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy
+    iu = np.rint((fx * xd + cx) * 32.0).astype(np.int64)  # cvRound: half to even
+    iv = np.rint((fy * yd + cy) * 32.0).astype(np.int64)
+    sx = np.clip(iu >> 5, -32768, 32767)
+    sy = np.clip(iv >> 5, -32768, 32767)
+    a, b = iu & 31, iv & 31
+    w = [(32 - a) * (32 - b) * 32, a * (32 - b) * 32, (32 - a) * b * 32, a * b * 32]
+
+    def tap(yy, xx):
+        ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+        t = im[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)].astype(np.int64)
+        return np.where(ok[..., None], t, 0)
+
+    acc = (w[0][..., None] * tap(sy, sx) + w[1][..., None] * tap(sy, sx + 1) +
+           w[2][..., None] * tap(sy + 1, sx) + w[3][..., None] * tap(sy + 1, sx + 1))
+    out = ((acc + (1 << 14)) >> 15).astype(np.uint8)
+    return out[..., 0] if squeeze else out

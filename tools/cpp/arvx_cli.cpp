@@ -285,6 +285,33 @@ int main(int argc, char *argv[]) {
         return 1;
     }
     std::cout << "LOG - " << tag << ": read cameraMatrix and distCoefficients." << std::endl;
+    if (parser.b("undistort")) {
+        // raw inputs: what the reference does per view inside carve / the colour pass
+        // (cv::undistort of mask and image, src/VoxelCarving.cpp:35-36), once, on the device
+        arvx_ctx *u = nullptr;
+        if (arvx_ctx_create(&u, 0, 8, 8, 8, 1.f) != ARVX_OK) return 3;
+        const int V = (int)in.views.size();
+        std::vector<const uint8_t *> src(V);
+        std::vector<uint8_t *> dst(V);
+        int rc = ARVX_OK;
+        for (int pass = 0; pass < 2 && rc == ARVX_OK; ++pass) {
+            for (int i = 0; i < V; ++i) {
+                const arvx::Image &im = pass ? in.views[i].image : in.views[i].mask;
+                src[i] = im.data;
+                dst[i] = const_cast<uint8_t *>(im.data);
+            }
+            const arvx::Image &f = pass ? in.views[0].image : in.views[0].mask;
+            if (!f.data) continue;
+            rc = arvx_undistort(u, V, src.data(), f.width, f.height, f.channels, f.stride, K,
+                                in.dist.data(), (int)in.dist.size(), dst.data());
+        }
+        arvx_ctx_destroy(u);
+        if (rc != ARVX_OK) {
+            std::cerr << "arvx_undistort: " << arvx_last_error() << std::endl;
+            return 3;
+        }
+        std::cout << "LOG - " << tag << ": undistorted masks and images." << std::endl;
+    }
     const arvx::Vec3f modelTranslation(parser.f("dx"), parser.f("dy"), parser.f("dz"));
     try {
         if (choose == 6) {
