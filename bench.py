@@ -293,13 +293,26 @@ def main():
     alg_bytes = nv_rank * r["V"] + r["V"] * r["sc"].W * r["sc"].H
     achieved = alg_bytes / (r["kern_ms"] * 1e-3) / 1e9
     traffic = traffic_step = None
+    valu = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and world == 1:
         try:
             tj = json.load(open(tpath))
             key = f"{r['X']}x{r['Y']}x{r['Z']}x{r['V']}" + ("_nocull" if args.no_cull else "")
-            traffic = tj.get(key, {}).get("bytes_per_launch")
-            traffic_step = tj.get(key, {}).get("bytes_per_step")
+            ent = tj.get(key, {})
+            traffic = ent.get("bytes_per_launch")
+            traffic_step = ent.get("bytes_per_step")
+            # what the dominant kernel is actually bound by: vector-instruction issue.  Peak:
+            # 256 CUs x 4 SIMD-32, one wave64 instruction per 2 cycles at 2.4 GHz (the guide's
+            # FP32 vector peak counted in instructions; fp64 adds / converts issue slower)
+            ins = ent.get("valu_wave_instructions", {}).get("exact")
+            t_ns = ent.get("kernel_avg_ns_rocprofv3", {}).get("exact")
+            if ins and t_ns:
+                peak = 256 * 4 * 2.4e9 / 2
+                valu = {"kernel": "carve_exact_blocks_kernel", "SQ_INSTS_VALU": ins,
+                        "kernel_us_rocprofv3": t_ns / 1e3, "achieved_Ginst_per_s": ins / t_ns,
+                        "peak_Ginst_per_s": peak / 1e9, "frac": ins / (t_ns * 1e-9) / peak,
+                        "source": "profiles/traffic.json (PMC pass of the same command)"}
         except Exception:
             traffic = None
     phys = (traffic / (r["kern_ms"] * 1e-3) / 1e9) if traffic else None
@@ -310,24 +323,27 @@ def main():
                            "time); see physical_frac for what the chip moves",
                 "physical_GBps": phys,
                 "physical_frac": (phys / HBM_PEAK_GBS) if phys else None,
-                "kernel": "carve_coarse_kernel + carve_classify_kernel + carve_exact_blocks_kernel "
-                          "(one arvx_carve call)",
+                "kernel": "carve_coarse_kernel + carve_fill_kernel + carve_classify_kernel + "
+                          "carve_exact_blocks_kernel (one arvx_carve call)",
                 "kernel_ms": r["kern_ms"],
                 "algorithmic_bytes": alg_bytes,
-                "step": {"kernels": "mask_to_bits + sat_rows + sat_cols (arvx_set_views_device) "
-                                    "+ the three carve kernels",
+                "valu": valu,
+                "step": {"kernels": "views_bits + views_tile_sums + views_table "
+                                    "(arvx_set_views_device) + the four carve kernels",
                          "kernel_ms": step_kernel_ms,
                          "effective_frac": alg_bytes / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic_step,
                          "physical_frac": (traffic_step / (step_kernel_ms * 1e-3) / 1e9 /
                                            HBM_PEAK_GBS) if traffic_step else None},
                 "note": "algorithmic = N*V + V*W*H read bytes of the per-view streaming "
-                        "formulation (SURVEY 8d); the kernels read the state at most once and "
-                        "decide most 16x8x8 sub-tiles from a pixel-rectangle test, so `frac` "
-                        "is an EFFECTIVE rate and exceeds the physical peak; `traffic` "
-                        "is the rocprofv3 PMC FETCH_SIZE+WRITE_SIZE byte count per launch (profiles/"
-                        "traffic.json) and `physical_frac` = traffic / kernel time / peak: the "
-                        "kernels are bound by VALU issue and L2/Infinity-Cache latency, not HBM"}
+                        "formulation (SURVEY 8d); the kernels keep the state at 2 bits per voxel, "
+                        "write it once and decide most 16x8x8 sub-tiles (and 4x4x4 blocks) from "
+                        "pixel-rectangle tests, so `frac` is an EFFECTIVE rate and exceeds the "
+                        "physical peak; `traffic` is the rocprofv3 PMC byte count per launch "
+                        "(2 x FETCH_SIZE + WRITE_SIZE per the guide's gfx950 correction, "
+                        "profiles/traffic.json) and `physical_frac` = traffic / kernel time / "
+                        "peak: the path is bound by vector-instruction issue in the exact kernel "
+                        "(`valu`) and by dependent-read latency in the classification, not by HBM"}
 
     out = {
         "metric": "Mvoxel-views/s (voxels x views / s) + carve wall-time, 512^3 grid x 36 views",
