@@ -5,13 +5,16 @@
  * may include, link or load this file.  Allowed users: tests/,
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg.
  *
- * PARITY UNPINNED: the reference has no unit tests, golden vectors or
- * fixtures at the level of this path, its only
- * known-answer files (Data/box_dataset/generated_models/{1,2,3}.off) need
- * OpenCV-aruco poses, and the reference itself cannot be built in this image
- * (OpenCV + Eigen3 absent).  The arithmetic of the two third-party calls on
- * the path (cv::gemm, cv::norm; opencv 4.6.x, unpinned in the reference's
- * CMakeLists.txt:16) is restated from its published source, see arvx_oracle.c.
+ * PARITY: PARTLY PINNED.  The reference has no unit tests or golden vectors at the level of
+ * this path and cannot be built in this image (OpenCV + Eigen3 absent).
+ * Pinned against the reference's own Data/box_dataset/generated_models/1.off (fixture
+ * tests/golden/box_off1.npz, tools/make_off_fixture.py; tests/test_mc_off.py): the marching
+ * cubes + OFF writer restatement reproduces the file byte for byte, the surface selection
+ * (Model::isInner) is the file's vertex set, the closure is the one dilation the file's model
+ * is the image of.  UNPINNED: the arithmetic of the two third-party calls on the carve path
+ * (cv::gemm, cv::norm; opencv 4.6.x, unpinned in the reference's CMakeLists.txt:16), restated
+ * from the published source, see arvx_oracle.c -- in particular the grouping of the M*world
+ * row sums, for which both candidates are built and told apart by a test.
  *
  * State plane convention (one byte per voxel, index x + X*(y + Y*z), the
  * reference's Model::flatten, src/Model.h:104-106):
