@@ -715,6 +715,20 @@ int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
         ARVX_HIP(hipGetLastError());
         return ARVX_OK;
     }
+    if (ctx->X % 8 == 0 && ((size_t)ctx->X * ctx->Y) % 32 == 0 && (uintptr_t)dev_words % 4 == 0 &&
+        (ctx->rec_valid || !ctx->bytes_valid)) {
+        if (int mrc = need_rec(ctx)) return mrc;
+        arvx::CarveParams g;
+        carve_geometry(ctx, g);
+        g.rec = ctx->d_rec;
+        const int nz = ctx->z1 - ctx->z0;
+        const size_t nwords = ((size_t)ctx->X * ctx->Y * nz / 8 + 3) / 4;
+        hipLaunchKernelGGL(arvx::pack_occupancy_rec8_kernel, dim3((unsigned)((nwords + 255) / 256)),
+                           dim3(256), 0, ctx->stream, g, ctx->z0 - ctx->ze0, nz, 0,
+                           (uint32_t *)dev_words);
+        ARVX_HIP(hipGetLastError());
+        return ARVX_OK;
+    }
     if (int mrc = need_bytes(ctx)) return mrc;
     if (ctx->nvox % 32 == 0 && (uintptr_t)ctx->owned() % 16 == 0 && (uintptr_t)dev_words % 4 == 0) {
         const size_t nwords = ctx->nvox / 32;
@@ -747,6 +761,19 @@ int arvx_pack_occupancy_global(arvx_ctx *ctx, void *dev_global_words) {
         const int nz = ctx->z1 - ctx->z0;
         const size_t nwords = (size_t)(ctx->X / 32) * ctx->Y * nz;
         hipLaunchKernelGGL(arvx::pack_occupancy_rec_kernel, dim3((unsigned)((nwords + 255) / 256)),
+                           dim3(256), 0, ctx->stream, g, ctx->z0 - ctx->ze0, nz, 1,
+                           (uint32_t *)dev_global_words);
+        ARVX_HIP(hipGetLastError());
+        return ARVX_OK;
+    }
+    if (ctx->X % 8 == 0 && (ctx->rec_valid || !ctx->bytes_valid)) {  // (X * Y % 64 == 0 above)
+        if (int mrc = need_rec(ctx)) return mrc;
+        arvx::CarveParams g;
+        carve_geometry(ctx, g);
+        g.rec = ctx->d_rec;
+        const int nz = ctx->z1 - ctx->z0;
+        const size_t nwords = (size_t)ctx->X * ctx->Y * nz / 32;
+        hipLaunchKernelGGL(arvx::pack_occupancy_rec8_kernel, dim3((unsigned)((nwords + 255) / 256)),
                            dim3(256), 0, ctx->stream, g, ctx->z0 - ctx->ze0, nz, 1,
                            (uint32_t *)dev_global_words);
         ARVX_HIP(hipGetLastError());

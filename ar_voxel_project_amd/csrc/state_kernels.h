@@ -88,6 +88,38 @@ __global__ __launch_bounds__(256) void pack_occupancy_rec_kernel(const CarvePara
     out[(zo * p.Y + y) * wpr + k] = w;
 }
 
+// The same for any X % 8 == 0 (e.g. the 648- and 816-wide grids of the 2- and 4-GPU weak
+// scaling): a byte of the flat packing holds eight voxels of ONE row; a thread assembles one
+// output word from its four bytes.  n_bytes = X * Y * nz / 8 (a multiple of 4 is not needed:
+// the last word is padded with zeros).
+__global__ __launch_bounds__(256) void pack_occupancy_rec8_kernel(const CarveParams p, int zl0,
+                                                                  int nz, int global,
+                                                                  uint32_t *__restrict__ out) {
+    const size_t plane_bytes = (size_t)p.X * p.Y / 8;  // X % 8 == 0
+    const size_t n_bytes = plane_bytes * nz;
+    const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (w * 4 >= n_bytes) return;
+    uint32_t word = 0;
+    size_t dst = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t b = w * 4 + k;
+        if (b >= n_bytes) break;
+        const int zi = (int)(b / plane_bytes);
+        const size_t in_plane = b % plane_bytes;
+        const int y = (int)(in_plane / (p.X / 8)), x0 = (int)(in_plane % (p.X / 8)) * 8;
+        const int z = zl0 + zi;
+        const uint16_t *rec =
+            p.rec + rec_index(p, x0 >> 6, y >> 3, z >> 3, (x0 >> 4) & 3) * kRecU16;
+        const uint32_t e = rec[(z & 7) * 8 + (y & 7)];
+        word |= ((e >> (x0 & 15)) & 0xffu) << (8 * k);
+        if (k == 0) dst = global ? ((size_t)global_z(p, z) * plane_bytes + in_plane) : b;
+    }
+    // (global: planes start on word boundaries because X * Y % 64 == 0, and the four bytes of
+    // a word never straddle a plane for the same reason)
+    out[dst / 4] = word;
+}
+
 // Model::handleUnseen on records: occ |= ~seen (voxels outside the grid are kept "seen")
 __global__ __launch_bounds__(256) void rec_handle_unseen_kernel(uint32_t *__restrict__ rec32,
                                                                 size_t nrec) {
