@@ -38,7 +38,7 @@ SYMBOLS = [
     "arvx_color", "arvx_surface_count", "arvx_surface_download",
     "arvx_surface_depth_download",
     "arvx_colors_upload", "arvx_closure", "arvx_closure_count", "arvx_closure_download",
-    "arvx_mc_cells", "arvx_mc_cells_download",
+    "arvx_mc_cells", "arvx_mc_cells_download", "arvx_mc_mesh", "arvx_mc_mesh_download",
     "arvx_occupancy_packet_words", "arvx_occupancy_compress", "arvx_occupancy_expand",
     "arvx_occupancy_expand_striped",
     "arvx_export_model", "arvx_get_stats", "arvx_selftest_divide", "arvx_selftest_round",
@@ -444,6 +444,18 @@ class Context:
             self._ck(self._lib.arvx_mc_cells_download(
                 self._h, cells.ctypes.data_as(C.POINTER(C.c_int32))))
         return cells
+
+    def mc_mesh(self, apply_unseen: bool = False):
+        """(verts (3T, 3) float32 in voxel units, face_rgb (T, 3) uint32) of marchingCubes()."""
+        n = C.c_int64()
+        self._lib.arvx_mc_mesh.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+        self._lib.arvx_mc_mesh_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self._ck(self._lib.arvx_mc_mesh(self._h, int(apply_unseen), C.byref(n)))
+        verts = np.empty((3 * n.value, 3), np.float32)
+        rgb = np.empty((n.value, 3), np.uint32)
+        if n.value:
+            self._ck(self._lib.arvx_mc_mesh_download(self._h, verts.ctypes.data, rgb.ctypes.data))
+        return verts, rgb
 
     def export_model(self, apply_unseen: bool = False) -> np.ndarray:
         out = np.empty((self.nvox, 4), np.float32)

@@ -24,6 +24,7 @@
 #include "bitplane_kernels.h"
 #include "fast_carve_kernels.h"
 #include "mc_kernels.h"
+#include "mc_mesh_kernels.h"
 #include "exchange_kernels.h"
 #include <algorithm>
 
@@ -1538,6 +1539,79 @@ int arvx_mc_cells_download(arvx_ctx *ctx, int32_t *cells) {
     if (!ctx->mc_ready) return fail(ARVX_ERR_STATE, "no cell list (call arvx_mc_cells)");
     if (ctx->mc_count) {
         ARVX_HIP(hipMemcpyAsync(cells, ctx->d_mc_cells, (size_t)ctx->mc_count * sizeof(int4),
+                                hipMemcpyDeviceToHost, ctx->stream));
+        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return ARVX_OK;
+}
+
+int arvx_mc_mesh(arvx_ctx *ctx, int apply_unseen, int64_t *triangles) {
+    ARVX_CHECK_CTX(ctx);
+    if (!triangles) return fail(ARVX_ERR_INVALID, "null argument");
+    if (ctx->z0 != 0 || ctx->z1 != ctx->Z || ctx->stripe_world > 1)
+        return fail(ARVX_ERR_STATE, "arvx_mc_mesh needs the whole grid in one context");
+    if (ctx->closure_ready && (apply_unseen != 0) != (ctx->closure_unseen != 0))
+        return fail(ARVX_ERR_STATE, "arvx_closure was computed with apply_unseen=%d",
+                    ctx->closure_unseen);
+    int64_t ncells = 0;
+    if (int rc = arvx_mc_cells(ctx, &ncells)) return rc;
+    ctx->mesh_tris = 0;
+    *triangles = 0;
+    if (ncells == 0) return ARVX_OK;
+    const int n = (int)ncells;
+    const int nsb = (n + arvx::kScanBlock - 1) / arvx::kScanBlock;
+    if (int rc = ensure_scratch(ctx, (size_t)(n + nsb + 1) * sizeof(long long) +
+                                         (size_t)(n + nsb) * sizeof(int) + 64))
+        return rc;
+    long long *d_off = (long long *)ctx->d_scratch, *d_boff = d_off + n;
+    int *d_cnt = (int *)(d_boff + nsb + 1), *d_bsum = d_cnt + n;
+    const unsigned nblk = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(arvx::mc_tri_count_kernel, dim3(nblk), dim3(256), 0, ctx->stream,
+                       (const int4 *)ctx->d_mc_cells, (long long)n, d_cnt);
+    hipLaunchKernelGGL(arvx::mc_block_sum_kernel, dim3(nsb), dim3(256), 0, ctx->stream, d_cnt, n,
+                       d_bsum);
+    hipLaunchKernelGGL(arvx::mc_scan_blocks_kernel, dim3(1), dim3(256), 0, ctx->stream, d_bsum, nsb,
+                       d_boff);
+    hipLaunchKernelGGL(arvx::mc_block_scan_kernel, dim3(nsb), dim3(256), 0, ctx->stream, d_cnt, n,
+                       d_boff, d_off);
+    ARVX_HIP(hipGetLastError());
+    long long total = 0;
+    ARVX_HIP(hipMemcpyAsync(&total, d_boff + nsb, sizeof total, hipMemcpyDeviceToHost,
+                            ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    if (total > 0) {
+        ARVX_HIP(ctx->pool_mesh_verts.reserve((size_t)total * 9 * sizeof(float)));
+        ARVX_HIP(ctx->pool_mesh_rgb.reserve((size_t)total * 3 * sizeof(unsigned)));
+        arvx::McMeshParams mp;
+        mp.state = ctx->d_state;  // (arvx_mc_cells made the byte plane current)
+        mp.X = ctx->X;
+        mp.Y = ctx->Y;
+        mp.Z = ctx->Z;
+        mp.apply_unseen = apply_unseen ? 1 : 0;
+        mp.col_index = ctx->color_ready ? ctx->d_surf_index : nullptr;
+        mp.col_rgb = ctx->color_ready ? ctx->d_surf_rgb : nullptr;
+        mp.col_has = ctx->color_ready ? ctx->d_surf_has : nullptr;
+        mp.ncol = ctx->color_ready ? ctx->surf_count : 0;
+        mp.clo_index = ctx->closure_ready ? ctx->d_clo_index : nullptr;
+        mp.clo_rgba = ctx->closure_ready ? (const float4 *)ctx->d_clo_rgba : nullptr;
+        mp.nclo = ctx->closure_ready ? ctx->clo_count : 0;
+        hipLaunchKernelGGL(arvx::mc_mesh_kernel, dim3(nblk), dim3(256), 0, ctx->stream, mp,
+                           (const int4 *)ctx->d_mc_cells, (long long)n, d_off,
+                           (float *)ctx->pool_mesh_verts.p, (unsigned *)ctx->pool_mesh_rgb.p);
+        ARVX_HIP(hipGetLastError());
+    }
+    ctx->mesh_tris = total;
+    *triangles = total;
+    return ARVX_OK;
+}
+
+int arvx_mc_mesh_download(arvx_ctx *ctx, float *verts, uint32_t *face_rgb) {
+    ARVX_CHECK_CTX(ctx);
+    if (!verts || !face_rgb) return fail(ARVX_ERR_INVALID, "null argument");
+    if (ctx->mesh_tris > 0) {
+        ARVX_HIP(hipMemcpyAsync(verts, ctx->pool_mesh_verts.p, (size_t)ctx->mesh_tris * 36,
+                                hipMemcpyDeviceToHost, ctx->stream));
+        ARVX_HIP(hipMemcpyAsync(face_rgb, ctx->pool_mesh_rgb.p, (size_t)ctx->mesh_tris * 12,
                                 hipMemcpyDeviceToHost, ctx->stream));
         ARVX_HIP(hipStreamSynchronize(ctx->stream));
     }

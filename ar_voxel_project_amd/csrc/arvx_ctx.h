@@ -117,7 +117,8 @@ struct Ctx {
     bool mc_ready = false;
     // storage behind the d_surf_* / d_clo_* / d_mc_cells views (kept until destroy)
     DevPool pool_surf_index, pool_surf_rgb, pool_surf_depth, pool_surf_has, pool_clo_index,
-        pool_clo_rgba, pool_mc_cells, pool_raw_masks;
+        pool_clo_rgba, pool_mc_cells, pool_raw_masks, pool_mesh_verts, pool_mesh_rgb;
+    int64_t mesh_tris = 0;  // triangles of the last arvx_mc_mesh
     void release_pools() {
         pool_surf_index.release();
         pool_surf_rgb.release();
@@ -127,6 +128,8 @@ struct Ctx {
         pool_clo_rgba.release();
         pool_mc_cells.release();
         pool_raw_masks.release();
+        pool_mesh_verts.release();
+        pool_mesh_rgb.release();
     }
     void free_mc() {
         d_mc_cells = nullptr;

@@ -1,0 +1,133 @@
+// mc_mesh_kernels.h -- the triangles of the reference's marchingCubes() on the device, for the
+// models the device can hold: every w is 0 or 1 (src/Model.h:90-91; what carve, the colour
+// pass, handleUnseen and the closure produce).
+//
+// Input: the cell list of mc_kernels.h (cells cut by the surface, with cube index, in the
+// reference's visiting order).  Per cell (one thread), Polygonise + ProcessVoxel
+// (src/MarchingCubes.h:478-578) reduce to: a cut edge joins an occupied corner and an empty one,
+// so its vertex SNAPS to the occupied corner and takes that voxel's colour (VertexInterp,
+// :432-441) -- integer lattice coordinates; every triangle of Bourke's table row gets three
+// fresh vertices, and its face colour is round((c0 + c1 + c1) / 3) per channel in fp32: the
+// third corner's colour is the second's (:506, kept) and MeanColorFloats rounds half away from
+// zero (:414-416).
+//
+// A voxel's colour as Model::get would return it (src/main.cpp:262-299 order): UNSEEN_COLOR if
+// handleUnseen painted it, else the closure's mean colour if the closure filled it, else the
+// colour pass's result if it has one, else MODEL_COLOR.  The two sparse lists are sorted by flat
+// index: binary searches.
+#pragma once
+
+#include "arvx/mc_tables.hpp"
+#include "arvx_device.h"
+
+namespace arvx {
+
+struct McTriTable {
+    int8_t e[256][16];  // edge numbers, three per triangle, -1 terminated
+    int8_t n[256];      // triangles per cube index
+};
+
+constexpr McTriTable make_mc_tri_table() {
+    McTriTable t{};
+    for (int i = 0; i < 256; ++i) {
+        int k = 0;
+        for (const char *s = mc::kTriangles[i]; *s; ++s) t.e[i][k++] = (int8_t)mc::hex_digit(*s);
+        t.n[i] = (int8_t)(k / 3);
+        for (; k < 16; ++k) t.e[i][k] = -1;
+    }
+    return t;
+}
+
+__constant__ McTriTable kMcTri = make_mc_tri_table();
+
+struct McMeshParams {
+    const uint8_t *state;  // whole grid, bit0 occupied, bit1 seen, bit2 painted UNSEEN
+    int X, Y, Z;
+    int apply_unseen;      // never-seen voxels are painted UNSEEN_COLOR
+    const int *col_index;  // colour pass: ascending flat index, rgb, has-sample flag
+    const float *col_rgb;
+    const uint8_t *col_has;
+    long long ncol;
+    const int *clo_index;  // closure: ascending flat index, rgba
+    const float4 *clo_rgba;
+    long long nclo;
+};
+
+__device__ __forceinline__ long long mc_find(const int *__restrict__ idx, long long n, int key) {
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (idx[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return (lo < n && idx[lo] == key) ? lo : -1;
+}
+
+// rgb of an occupied voxel
+__device__ inline float3 mc_voxel_rgb(const McMeshParams &p, int x, int y, int z) {
+    const int i = x + p.X * (y + p.Y * z);
+    const uint8_t st = p.state[i];
+    if ((st & 4u) || (p.apply_unseen && !(st & 2u))) return make_float3(204.f, 0.f, 0.f);
+    if (p.nclo) {
+        const long long k = mc_find(p.clo_index, p.nclo, i);
+        if (k >= 0) return make_float3(p.clo_rgba[k].x, p.clo_rgba[k].y, p.clo_rgba[k].z);
+    }
+    if (p.ncol) {
+        const long long k = mc_find(p.col_index, p.ncol, i);
+        if (k >= 0 && p.col_has[k])
+            return make_float3(p.col_rgb[3 * k], p.col_rgb[3 * k + 1], p.col_rgb[3 * k + 2]);
+    }
+    return make_float3(50.f, 168.f, 141.f);
+}
+
+__global__ __launch_bounds__(256) void mc_tri_count_kernel(const int4 *__restrict__ cells,
+                                                           long long n, int *__restrict__ counts) {
+    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (c < n) counts[c] = kMcTri.n[cells[c].w & 255];
+}
+
+__device__ __forceinline__ unsigned mc_mean3(float a, float b, float c) {
+    const float s = (a + b) + c;
+    return (unsigned)roundf(s / 3.f);
+}
+
+__global__ __launch_bounds__(256) void mc_mesh_kernel(const McMeshParams p,
+                                                      const int4 *__restrict__ cells, long long n,
+                                                      const long long *__restrict__ tri_offset,
+                                                      float *__restrict__ verts,
+                                                      unsigned *__restrict__ face_rgb) {
+    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const int4 cell = cells[c];
+    const int idx = cell.w & 255;
+    // corner i of ProcessVoxel (src/MarchingCubes.h:537-552); bit i of idx set = NOT in the model
+    const int cx[8] = {1, 0, 0, 1, 1, 0, 0, 1}, cy[8] = {0, 0, 1, 1, 0, 0, 1, 1},
+              cz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+    float3 col[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        col[i] = make_float3(0.f, 0.f, 0.f);
+        if (!((idx >> i) & 1)) col[i] = mc_voxel_rgb(p, cell.x + cx[i], cell.y + cy[i], cell.z + cz[i]);
+    }
+    long long t = tri_offset[c];
+    const int8_t *row = kMcTri.e[idx];
+    for (int k = 0; row[k] >= 0; k += 3, ++t) {
+        int corner[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const int e = row[k + v];
+            const int a = e & 7, b = mc::kSecondCorner[e];  // e % 8 and its partner (:491)
+            corner[v] = ((idx >> a) & 1) ? b : a;           // the corner that is in the model
+            float *o = verts + 9 * t + 3 * v;
+            o[0] = (float)(cell.x + cx[corner[v]]);
+            o[1] = (float)(cell.y + cy[corner[v]]);
+            o[2] = (float)(cell.z + cz[corner[v]]);
+        }
+        const float3 c0 = col[corner[0]], c1 = col[corner[1]];  // col[2] = col[1], :506
+        face_rgb[3 * t] = mc_mean3(c0.x, c1.x, c1.x);
+        face_rgb[3 * t + 1] = mc_mean3(c0.y, c1.y, c1.y);
+        face_rgb[3 * t + 2] = mc_mean3(c0.z, c1.z, c1.z);
+    }
+}
+
+}  // namespace arvx

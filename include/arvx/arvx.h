@@ -270,6 +270,17 @@ int arvx_closure_download(arvx_ctx *ctx, int64_t *index, float *rgba);
 int arvx_mc_cells(arvx_ctx *ctx, int64_t *count);
 int arvx_mc_cells_download(arvx_ctx *ctx, int32_t *cells);
 
+/* The triangles marchingCubes() builds from the current model (before WriteMesh scales and
+ * writes them), for the models the device holds: every w is 0 or 1, threshold in (0, 1].
+ * Triangle t has the three fresh vertices 3t, 3t+1, 3t+2 (src/MarchingCubes.h:561-568) --
+ * `verts` gets 9 floats per triangle, voxel units -- and the face colour face_rgb[3t..3t+2]
+ * (rounded mean with the reference's `i + 1` quirk, :506).  Voxel colours: UNSEEN_COLOR where
+ * handleUnseen painted (apply_unseen != 0: every never-seen voxel; bit2 of uploaded bytes),
+ * else the closure's colour, else the colour pass's, else MODEL_COLOR.  Whole-grid contexts.
+ * Runs arvx_mc_cells itself; the order is the reference's. */
+int arvx_mc_mesh(arvx_ctx *ctx, int apply_unseen, int64_t *triangles);
+int arvx_mc_mesh_download(arvx_ctx *ctx, float *verts, uint32_t *face_rgb);
+
 /* Model::voxels as the reference would hold it after carve [+ colour]
  * [+ handleUnseen]: n*4 floats (RGBA), n = slab voxels. */
 int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen);

@@ -222,11 +222,54 @@ inline bool ProcessVoxel(Model *model, int x, int y, int z, SimpleMesh *mesh, fl
     return any;
 }
 
-// The mesh marchingCubes() writes, without writing it.
+// The mesh marchingCubes() writes, without writing it.  When every w of the model is 0 or 1
+// (all the reference's own pipeline produces) the triangles come from the device
+// (arvx_mc_mesh: state, colour list and closure result are already there); a model with
+// fractional w is triangulated on the host from the device's cell list.
 inline SimpleMesh marchingCubesMesh(Model *model, float threshold = 0.5f) {
     SimpleMesh mesh;
-    for (const McCell &c : marchingCubesCells(*model, threshold))
-        ProcessVoxel(model, c.x, c.y, c.z, &mesh, threshold);
+    if (!(threshold > 0.f)) return mesh;
+    bool on_device = false;
+    (void)model->inside_state(threshold, on_device);
+    if (!on_device) {
+        for (const McCell &c : marchingCubesCells(*model, threshold))
+            ProcessVoxel(model, c.x, c.y, c.z, &mesh, threshold);
+        return mesh;
+    }
+    arvx_ctx *ctx = model->device_for_reading();
+    // painted voxels: derived on the device when the paint is exactly "not seen", else carried
+    // by the byte plane (bit2)
+    const bool painted = model->painted();
+    if (painted && !model->paint_is_unseen()) {
+        const std::vector<uint8_t> st = model->byte_state();
+        detail::check(arvx_state_upload(ctx, st.data()), "arvx_state_upload");
+        model->set_colors_on_device(false);
+    }
+    if (!model->colors_on_device()) {
+        std::vector<int64_t> idx;
+        std::vector<float> rgb;
+        (void)model->sorted_colors(idx, rgb);  // (w is 0 or 1 here)
+        detail::check(arvx_colors_upload(ctx, (int64_t)idx.size(), idx.data(), rgb.data()),
+                      "arvx_colors_upload");
+        model->set_colors_on_device(true);
+    }
+    int64_t n = 0;
+    detail::check(arvx_mc_mesh(ctx, (painted && model->paint_is_unseen()) ? 1 : 0, &n),
+                  "arvx_mc_mesh");
+    std::vector<float> verts((size_t)n * 9);
+    std::vector<uint32_t> rgb((size_t)n * 3);
+    if (n) detail::check(arvx_mc_mesh_download(ctx, verts.data(), rgb.data()),
+                         "arvx_mc_mesh_download");
+    std::vector<Vec3f> &mv = mesh.GetVertices();
+    std::vector<Triangle> &mt = mesh.GetTriangles();
+    mv.resize((size_t)n * 3);
+    mt.resize((size_t)n);
+    for (size_t t = 0; t < (size_t)n; ++t) {
+        for (int v = 0; v < 3; ++v)
+            mv[3 * t + v] = Vec3f(verts[9 * t + 3 * v], verts[9 * t + 3 * v + 1], verts[9 * t + 3 * v + 2]);
+        mt[t] = Triangle{(unsigned)(3 * t), (unsigned)(3 * t + 1), (unsigned)(3 * t + 2), rgb[3 * t],
+                         rgb[3 * t + 1], rgb[3 * t + 2]};
+    }
     return mesh;
 }
 

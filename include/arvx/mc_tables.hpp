@@ -25,7 +25,7 @@ constexpr int edge_mask(int cubeIndex) {
 
 constexpr int hex_digit(char c) { return c <= '9' ? c - '0' : c - 'a' + 10; }
 
-static const char *const kTriangles[256] = {
+static constexpr const char *kTriangles[256] = {
 #include "arvx/mc_triangles.inc"
 };
 

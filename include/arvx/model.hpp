@@ -261,6 +261,7 @@ class Model {
             device_stale_ = true;
             closure_on_device_ = false;
         }
+        if (device_stale_) colors_on_device_ = false;  // an upload drops the context's lists
         if (device_stale_) {
             if (pristine_) {
                 detail::check(arvx_state_reset(link_->ctx), "arvx_state_reset");

@@ -40,6 +40,7 @@ inline int applyClosure(Model *model, int kernelSize) {
         }
         detail::check(arvx_colors_upload(ctx, (int64_t)idx.size(), idx.data(), rgb.data()),
                       "arvx_colors_upload");
+        model->set_colors_on_device(true);
     }
     std::cout << "LOG - PP: starting dilution." << std::endl;
     detail::check(arvx_closure(ctx, kernelSize, (painted && model->paint_is_unseen()) ? 1 : 0),

@@ -153,6 +153,57 @@ def test_gpu_cells_surface_and_closure_on_the_files_model(arvx, oracle, off1):
     assert (frgba == np.float32([50, 168, 141, 1])).all()
 
 
+@pytest.mark.gpu
+def test_gpu_mesh_reproduces_1_off(arvx, oracle, off1):
+    """arvx_mc_mesh: the triangles from the device, written with the reference's format."""
+    X, Y, Z = off1["X"], off1["Y"], off1["Z"]
+    with arvx.Context(X, Y, Z, off1["s"]) as ctx:
+        ctx.upload_state(state_of(off1["occ"]))
+        verts, rgb = ctx.mc_mesh()
+    assert len(verts) == off1["nv"] and len(rgb) == off1["nf"]
+    text = oracle.off_text(verts, rgb, scale_factor=np.float32(1.0) * off1["s"])
+    assert text.encode() == off1["text"]
+
+
+@pytest.mark.gpu
+def test_gpu_mesh_colour_rules(arvx, oracle):
+    """Colour pass colours, UNSEEN paint (explicit bit2 and apply_unseen), closure colours and
+    the `i + 1` quirk: device triangles == oracle triangles on random models with w in {0, 1}."""
+    rng = np.random.default_rng(23)
+    for dims in [(12, 9, 7), (40, 33, 20), (64, 64, 8), (1, 1, 1)]:
+        X, Y, Z = dims
+        rgba = random_coloured_model(rng, X, Y, Z, False)
+        occ = rgba[:, 3] != 0
+        seen = rng.random(len(rgba)) < 0.8
+        state = (occ * 1 | seen * 2).astype(np.uint8)
+        # explicit colours of occupied voxels that are neither MODEL nor UNSEEN coloured
+        plain = occ & ~((rgba[:, :3] == [50, 168, 141]).all(1)) & ~((rgba[:, :3] == [204, 0, 0]).all(1))
+        painted = occ & (rgba[:, :3] == [204, 0, 0]).all(1)
+        idx = np.flatnonzero(plain)
+        with arvx.Context(X, Y, Z, 0.01) as ctx:
+            ctx.upload_state(state | (painted * 4).astype(np.uint8))  # bit2: painted by the host
+            ctx.upload_colors(idx, rgba[idx, :3])
+            verts, rgb = ctx.mc_mesh(False)
+            want_v, want_rgb = oracle.mc_mesh(X, Y, Z, rgba)
+            assert np.array_equal(verts, want_v) and np.array_equal(rgb, want_rgb), dims
+            # handleUnseen semantics: every never-seen voxel is UNSEEN_COLOR and occupied
+            ctx.upload_state(state)
+            ctx.upload_colors(idx, rgba[idx, :3])
+            ctx.handle_unseen()
+            verts, rgb = ctx.mc_mesh(True)
+            model = oracle.handle_unseen(state, np.where(painted[:, None], [50, 168, 141, 1], rgba)
+                                         .astype(np.float32))
+            want_v, want_rgb = oracle.mc_mesh(X, Y, Z, model)
+            assert np.array_equal(verts, want_v) and np.array_equal(rgb, want_rgb), dims
+            # after the closure: filled voxels carry their mean colours
+            if X > 1:
+                ctx.closure(3, True)
+                verts, rgb = ctx.mc_mesh(True)
+                closed = oracle.closure(X, Y, Z, model)
+                want_v, want_rgb = oracle.mc_mesh(X, Y, Z, closed)
+                assert np.array_equal(verts, want_v) and np.array_equal(rgb, want_rgb), dims
+
+
 @pytest.fixture(scope="module")
 def host_bin():
     exe = os.path.join(ROOT, "tests", "cpp", "test_host")
