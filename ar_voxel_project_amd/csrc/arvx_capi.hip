@@ -304,15 +304,28 @@ static int views_common(Ctx *ctx, int V, const float *M, const float *campos, in
             return arvx::fail_hip(e, "hipMalloc(views)", __FILE__, __LINE__);
         }
     }
-    ctx->h_M.assign(M, M + (size_t)V * 12);
-    ARVX_HIP(hipMemcpyAsync(ctx->d_M, ctx->h_M.data(), (size_t)V * 12 * sizeof(float),
-                            hipMemcpyHostToDevice, ctx->stream));
+    // matrices and camera positions: sent only when they differ from what the device holds
+    // (a pipeline re-derives its views per batch of masks with the same cameras; the two
+    // small copies cost more than a kernel of the step each)
+    const bool same_M = same && ctx->h_M.size() == (size_t)V * 12 &&
+                        memcmp(ctx->h_M.data(), M, (size_t)V * 12 * sizeof(float)) == 0;
+    if (!same_M) {
+        ctx->h_M.assign(M, M + (size_t)V * 12);
+        ARVX_HIP(hipMemcpyAsync(ctx->d_M, ctx->h_M.data(), (size_t)V * 12 * sizeof(float),
+                                hipMemcpyHostToDevice, ctx->stream));
+    }
     ctx->has_campos = campos != nullptr;
     if (campos) {
-        ctx->h_campos.assign(campos, campos + (size_t)V * 3);
-        ARVX_HIP(hipMemcpyAsync(ctx->d_campos, ctx->h_campos.data(),
-                                (size_t)V * 3 * sizeof(float), hipMemcpyHostToDevice,
-                                ctx->stream));
+        const bool same_c = same && ctx->h_campos.size() == (size_t)V * 3 &&
+                            memcmp(ctx->h_campos.data(), campos, (size_t)V * 3 * sizeof(float)) == 0;
+        if (!same_c) {
+            ctx->h_campos.assign(campos, campos + (size_t)V * 3);
+            ARVX_HIP(hipMemcpyAsync(ctx->d_campos, ctx->h_campos.data(),
+                                    (size_t)V * 3 * sizeof(float), hipMemcpyHostToDevice,
+                                    ctx->stream));
+        }
+    } else {
+        ctx->h_campos.clear();
     }
     return ARVX_OK;
 }
@@ -896,9 +909,12 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
     const bool cull = !(flags & ARVX_CARVE_NO_CULL);
     const bool split = cull && !(flags & ARVX_CARVE_FUSED) && p.nchunks <= arvx::kMaxChunks;
     const size_t ncoarse = (size_t)p.coarseX * p.coarseY * p.coarseZ;
-    int ncu = 256;
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    if (ncu <= 0) ncu = 256;
+    if (ctx->ncu <= 0) {
+        ctx->ncu = 256;
+        (void)hipDeviceGetAttribute(&ctx->ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        if (ctx->ncu <= 0) ctx->ncu = 256;
+    }
+    const int ncu = ctx->ncu;
     if (cull) {
         const size_t words = ncoarse * p.nchunks;
         // coarse masks | coarse codes | undecided list | two list counters

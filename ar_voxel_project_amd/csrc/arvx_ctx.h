@@ -62,6 +62,7 @@ struct Ctx {
     uint8_t *d_state = nullptr;  // byte plane, planes ze0..ze1-1 (lazy)
     bool bytes_valid = false;    // d_state holds the current state
     uint8_t *owned() const { return d_state + (size_t)(z0 - ze0) * X * Y; }
+    int ncu = 0;                 // compute units of the device (cached)
     int carve_seq = 0;           // parity of the undecided-list counters (carve_coarse_kernel)
     size_t carve_layout = 0;     // d_coarse layout those counters were zeroed for
     void *d_timeline = nullptr;  // ARVX_TIMELINE diagnostic builds only

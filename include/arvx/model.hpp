@@ -105,9 +105,11 @@ class Model {
     // reference src/Model.cpp:9-14: every voxel MODEL_COLOR, nothing seen
     Model(int x, int y, int z, float size)
         : size_x(x), size_y(y), size_z(z), voxel_size(size), wpr_((x + 31) / 32),
-          occ_((size_t)wpr_ * y * z), seen_((size_t)wpr_ * y * z, 0u) {
-        const uint32_t last = (x & 31) ? ((1u << (x & 31)) - 1u) : 0xffffffffu;
-        for (size_t i = 0; i < occ_.size(); ++i) occ_[i] = ((int)(i % wpr_) == wpr_ - 1) ? last : 0xffffffffu;
+          occ_((size_t)wpr_ * y * z, 0xffffffffu), seen_((size_t)wpr_ * y * z, 0u) {
+        if (x & 31) {  // the bits behind the end of every row stay zero
+            const uint32_t last = (1u << (x & 31)) - 1u;
+            for (size_t i = (size_t)wpr_ - 1; i < occ_.size(); i += (size_t)wpr_) occ_[i] = last;
+        }
     }
     // a copy is an independent model: host data only, its own device context when it needs one
     Model(const Model &o)
