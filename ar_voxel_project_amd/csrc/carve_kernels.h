@@ -1028,13 +1028,14 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
     // All sixteen blocks are projected before the table is read: ONE wait per view.  (The
     // sub-tiles that stay fully occupied pay every wait in every view, and they are what
     // the kernel ends on.)
+    // `did`: the blocks that were projected (scalar): only those read the table and update
+    // their state below -- after the block-level rectangle tests that is a few of the sixteen,
+    // and the fixed frame of sixteen loads and updates per view was most of what was left
     uint32_t pix[4][4];  // pixel_tagged
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pix[m][j] = (uint32_t)zero_pix;
+    unsigned did = 0;
     auto project = [&](const int m, const int j, const double s0, const double s1,
                        const double s2) {
+        did |= 1u << (4 * m + j);
         const float a0 = (float)s0, a1 = (float)s1, a2 = (float)s2;
         float u, v;
         if (fast) {
@@ -1118,16 +1119,20 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
         }
     }
 #endif
+    if (!did) return false;
     uint32_t word[4][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) word[m][j] = bgv[(pix[m][j] & 0x7fffffffu) >> 5];
+        for (int j = 0; j < 4; ++j)
+            if ((did >> (4 * m + j)) & 1u) word[m][j] = bgv[(pix[m][j] & 0x7fffffffu) >> 5];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
+        if (!((did >> (4 * m)) & 15u)) continue;
         uint32_t w = st[m];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if (!((did >> (4 * m + j)) & 1u)) continue;
             const uint32_t isbg = __builtin_amdgcn_ubfe(word[m][j], pix[m][j], 1u);  // bit pix & 31
             const uint32_t seen = (pix[m][j] >> 31) << (8 * j + 1);
             w = (w | seen) & ~(isbg << (8 * j));
