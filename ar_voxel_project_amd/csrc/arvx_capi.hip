@@ -71,10 +71,28 @@ static int ensure_scratch(Ctx *ctx, size_t need) {
     return ARVX_OK;
 }
 
+static int need_bytes(Ctx *ctx);
+static void carve_geometry(const Ctx *ctx, arvx::CarveParams &p);
+
+// The context's planes ze0 .. ze0 + g.Z - 1 as ONE bit plane (bitplane_kernels.h) under PRED:
+// straight from the records when they hold the state, else from the byte plane (which alone
+// can carry bit2, the host's UNSEEN paint).
 template <int PRED>
-static int launch_bit_pack(Ctx *ctx, const uint8_t *state, const arvx::BitGrid &g,
-                           int apply_unseen, unsigned long long *bits) {
+static int launch_bit_pack(Ctx *ctx, const arvx::BitGrid &g, int apply_unseen,
+                           unsigned long long *bits) {
     const size_t nwords = (size_t)g.XW * g.Y * g.Z;
+    if (ctx->rec_valid) {
+        arvx::CarveParams p;
+        carve_geometry(ctx, p);
+        p.rec = ctx->d_rec;
+        hipLaunchKernelGGL(arvx::bitgrid_from_rec_kernel, dim3((unsigned)((nwords + 255) / 256)),
+                           dim3(256), 0, ctx->stream, p, 0, g.Z,
+                           (PRED == arvx::kBitClosureOccupied && apply_unseen) ? 1 : 0, bits);
+        ARVX_HIP(hipGetLastError());
+        return ARVX_OK;
+    }
+    if (int rc = need_bytes(ctx)) return rc;
+    const uint8_t *state = ctx->d_state;
     if (g.X % 32 == 0 && ((uintptr_t)state & 15u) == 0)
         hipLaunchKernelGGL(arvx::bit_pack32_kernel<PRED>, dim3((unsigned)((nwords * 2 + 255) / 256)),
                            dim3(256), 0, ctx->stream, state, g, apply_unseen, bits);
@@ -1097,7 +1115,8 @@ int arvx_set_images(arvx_ctx *ctx, const uint8_t *const *images, size_t stride) 
 
 int arvx_color(arvx_ctx *ctx, int mode) {
     ARVX_CHECK_CTX(ctx);
-    if (int mrc = need_bytes(ctx)) return mrc;
+    if (!ctx->rec_valid)  // (a state that came in as bytes; records are used where they exist)
+        if (int mrc = need_bytes(ctx)) return mrc;
     if (!ctx->cameras_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
     if (!ctx->images_ready) return fail(ARVX_ERR_STATE, "arvx_set_images has not been called");
     if (!ctx->has_campos) return fail(ARVX_ERR_STATE, "arvx_set_views was given no campos");
@@ -1121,7 +1140,7 @@ int arvx_color(arvx_ctx *ctx, int mode) {
     unsigned long long *d_surf = d_occ + nw_ext;
     long long *d_off = (long long *)(d_surf + nw_own);
     int *d_cnt = (int *)(d_off + nblk + 1);
-    if (int rc = launch_bit_pack<arvx::kBitOccupied>(ctx, ctx->d_state, gext, 0, d_occ)) return rc;
+    if (int rc = launch_bit_pack<arvx::kBitOccupied>(ctx, gext, 0, d_occ)) return rc;
     hipLaunchKernelGGL(arvx::bit_surface_kernel, dim3((unsigned)((nw_own + 255) / 256)), dim3(256),
                        0, ctx->stream, d_occ, gext, ctx->z0 - ctx->ze0, Zown, d_surf);
     ARVX_HIP(hipGetLastError());
@@ -1422,8 +1441,7 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     hipLaunchKernelGGL(arvx::closure_rows_kernel, dim3((unsigned)((nrows + 256) / 256)), dim3(256),
                        0, ctx->stream, cp.col_index, cp.ncol, cp.X, (long long)nrows, d_rows);
     ARVX_HIP(hipGetLastError());
-    if (int rc = launch_bit_pack<arvx::kBitClosureOccupied>(ctx, ctx->d_state, g, cp.apply_unseen,
-                                                            d_occ))
+    if (int rc = launch_bit_pack<arvx::kBitClosureOccupied>(ctx, g, cp.apply_unseen, d_occ))
         return rc;
     const unsigned gw = (unsigned)((nwords + 255) / 256);
     hipLaunchKernelGGL(arvx::bit_dilate_x_kernel, dim3(gw), dim3(256), 0, ctx->stream, d_occ, g,

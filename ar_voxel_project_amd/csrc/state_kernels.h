@@ -120,6 +120,32 @@ __global__ __launch_bounds__(256) void pack_occupancy_rec8_kernel(const CarvePar
     out[dst / 4] = word;
 }
 
+// Records -> one bit plane in the layout of bitplane_kernels.h (rows padded to 64-bit words,
+// XW = ceil(X / 64) words per row): local planes [zl0, zl0 + nz).  closure_occupied: occupied
+// OR never seen (what the closure calls occupied after handleUnseen), else occupied.
+__global__ __launch_bounds__(256) void bitgrid_from_rec_kernel(const CarveParams p, int zl0, int nz,
+                                                               int closure_occupied,
+                                                               unsigned long long *__restrict__ bits) {
+    const int XW = (p.X + 63) >> 6;
+    const size_t n = (size_t)XW * p.Y * nz;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int xw = (int)(i % XW), y = (int)((i / XW) % p.Y), zi = (int)(i / ((size_t)XW * p.Y));
+    const int z = zl0 + zi, r = (z & 7) * 8 + (y & 7);
+    const uint16_t *rec = p.rec + rec_index(p, xw, y >> 3, z >> 3, 0) * kRecU16;
+    unsigned long long w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // the tile's four sub-tiles: 16 voxels each
+        if (64 * xw + 16 * k >= p.X) break;
+        unsigned long long e = rec[k * kRecU16 + r];
+        if (closure_occupied) e |= (unsigned long long)(uint16_t)~rec[k * kRecU16 + 64 + r];
+        w |= e << (16 * k);
+    }
+    const int nx = p.X - 64 * xw;  // voxels behind the end of the row: zero
+    if (nx < 64) w &= (1ull << nx) - 1ull;
+    bits[i] = w;
+}
+
 // Model::handleUnseen on records: occ |= ~seen (voxels outside the grid are kept "seen")
 __global__ __launch_bounds__(256) void rec_handle_unseen_kernel(uint32_t *__restrict__ rec32,
                                                                 size_t nrec) {
