@@ -351,7 +351,10 @@ static int views_common(Ctx *ctx, int V, const float *M, const float *campos, in
 static int views_preprocess(Ctx *ctx, const uint8_t *d_masks, int C) {
     const int npix = ctx->W * ctx->H;
     ARVX_HIP(hipGetLastError());  // anything stale would be blamed on the launches below
-    if (C == 1 || C == 3) {
+    if (C == 1 && npix % 32 == 0 && ((uintptr_t)d_masks & 15u) == 0) {
+        hipLaunchKernelGGL(arvx::views_bits16_kernel, dim3((npix / 16 + 255) / 256, ctx->V),
+                           dim3(256), 0, ctx->stream, d_masks, npix, ctx->d_bg, ctx->bgWords);
+    } else if (C == 1 || C == 3) {
         const dim3 g1(((npix + 3) / 4 + 255) / 256, ctx->V);
         if (C == 1)
             hipLaunchKernelGGL(arvx::views_bits_kernel<1>, g1, dim3(256), 0, ctx->stream, d_masks,

@@ -185,15 +185,8 @@ __global__ __launch_bounds__(256) void carve_coarse_kernel(const CarveParams p) 
     }
     // 1: some view carves the whole tile.  2 / 3: no view needs a closer look and none
     // carves -- every voxel keeps its occupancy and is seen (2) or not even seen (3).
-    if (lane == 0) {
-        const int code = any_carved ? 1 : (any_mixed ? 0 : (any_fg ? 2 : 3));
-        p.coarseCarved[ct] = (uint8_t)code;
-        // what carve_fill_kernel cannot settle with a constant goes on the list of
-        // carve_classify_kernel: undecided tiles, and -- on a model that is not fresh --
-        // the ones whose voxels keep their occupancy
-        if (p.undecidedList && (code == 0 || (code >= 2 && !(p.flags & 4u))))
-            p.undecidedList[atomicAdd(p.undecidedCount, 1)] = ct;
-    }
+    if (lane == 0)
+        p.coarseCarved[ct] = (uint8_t)(any_carved ? 1 : (any_mixed ? 0 : (any_fg ? 2 : 3)));
 }
 
 // in-grid voxels of entry r of sub-tile `wave` of tile (tx, ty, tz)
@@ -213,7 +206,15 @@ __global__ __launch_bounds__(256) void carve_fill_kernel(const CarveParams p) {
     const int ct = blockIdx.x;
     // (flags bit4: every coarse tile as "untouched, not seen" -- a fresh model as records)
     const int code = (p.flags & 16u) ? 3 : p.coarseCarved[ct];
-    if (!(code == 1 || (code >= 2 && (p.flags & 4u)))) return;
+    if (!(code == 1 || (code >= 2 && (p.flags & 4u)))) {
+        // what cannot be settled with a constant goes on the list of carve_classify_kernel:
+        // undecided tiles, and -- on a model that is not fresh -- the ones whose voxels keep
+        // their occupancy.  (Appended here, not in the pre-pass: there the atomic was one more
+        // dependent round trip at the end of every wave.)
+        if (threadIdx.x == 0 && p.undecidedList)
+            p.undecidedList[atomicAdd(p.undecidedCount, 1)] = ct;
+        return;
+    }
     const int cx = ct % p.coarseX, cy = (ct / p.coarseX) % p.coarseY, cz = ct / (p.coarseX * p.coarseY);
     const int tshift = p.cyShift + p.czShift;
     uint4 *dst = reinterpret_cast<uint4 *>(p.rec + (((size_t)ct << (tshift + 2)) * kRecU16));

@@ -64,6 +64,34 @@ __global__ __launch_bounds__(256) void views_bits_kernel(const uint8_t *__restri
     if ((threadIdx.x & 7) == 0 && w0 < bgWords - 1) dst[w0] = word;
 }
 
+// one-channel masks, sixteen pixels per lane (one 16-byte load), two lanes per word
+__global__ __launch_bounds__(256) void views_bits16_kernel(const uint8_t *__restrict__ masks,
+                                                           int npix, uint32_t *__restrict__ bg,
+                                                           int bgWords) {
+    const int v = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;  // pixels 16 q .. 16 q + 15 (npix % 32 == 0)
+    uint32_t *dst = bg + (size_t)v * bgWords;
+    if (q == 0) dst[bgWords - 1] = 0;
+    uint32_t half = 0;
+    if (16 * (size_t)q < (size_t)npix) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(masks + (size_t)v * npix + 16 * (size_t)q);
+        const uint32_t d[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // a zero byte -> bit: (x - 0x01010101) & ~x & 0x80808080 marks zero bytes exactly
+            // when no borrow crosses a byte, which the per-byte form below avoids
+            uint32_t z = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) z |= (((d[k] >> (8 * b)) & 0xffu) == 0u ? 1u : 0u) << b;
+            half |= z << (4 * k);
+        }
+    }
+    uint32_t word = half << (16 * (threadIdx.x & 1));
+    word |= __shfl_xor(word, 1);
+    const int w0 = q >> 1;
+    if ((threadIdx.x & 1) == 0 && w0 < bgWords - 1) dst[w0] = word;
+}
+
 // any channel count (the reference's masks have 3, the bench's 1)
 __global__ __launch_bounds__(256) void views_bits_generic_kernel(const uint8_t *__restrict__ masks,
                                                                  int C, int npix,
