@@ -929,6 +929,7 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
     const unsigned grid = (unsigned)(rows8 * p.tilesX);
     const bool cull = !(flags & ARVX_CARVE_NO_CULL);
     const bool split = cull && !(flags & ARVX_CARVE_FUSED) && p.nchunks <= arvx::kMaxChunks;
+    static const bool two_launches = getenv("ARVX_COARSE_SPLIT") != nullptr;  // A/B
     const size_t ncoarse = (size_t)p.coarseX * p.coarseY * p.coarseZ;
     if (ctx->ncu <= 0) {
         ctx->ncu = 256;
@@ -986,9 +987,11 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
             p.itemMasks = p.itemInfo + nitems;
             // (carve_coarse_kernel zeroes the `ints` counters at base)
         }
-        hipLaunchKernelGGL(arvx::carve_coarse_kernel, dim3((unsigned)((ncoarse + 3) / 4)),
-                           dim3(256), 0, ctx->stream, p);
-        ARVX_HIP(hipGetLastError());
+        if (!split || two_launches) {
+            hipLaunchKernelGGL(arvx::carve_coarse_kernel, dim3((unsigned)((ncoarse + 3) / 4)),
+                               dim3(256), 0, ctx->stream, p);
+            ARVX_HIP(hipGetLastError());
+        }
     }
     // the statistics counters live in the row-mapped variant
     static const bool row_map = getenv("ARVX_EXACT_ROWS") != nullptr;
@@ -1000,9 +1003,14 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
     static const bool no_block_tests = getenv("ARVX_NO_BLOCK_TESTS") != nullptr;  // A/B
     if (no_block_tests) p.flags |= 32u;
     if (split) {
-        // decided coarse tiles: constant records, one workgroup each
-        hipLaunchKernelGGL(arvx::carve_fill_kernel, dim3((unsigned)ncoarse), dim3(256), 0,
-                           ctx->stream, p);
+        // coarse tiles: classified, and the decided ones written as constant records, one
+        // workgroup each
+        if (two_launches)
+            hipLaunchKernelGGL(arvx::carve_fill_kernel, dim3((unsigned)ncoarse), dim3(256), 0,
+                               ctx->stream, p);
+        else
+            hipLaunchKernelGGL(arvx::carve_coarse_fill_kernel, dim3((unsigned)ncoarse), dim3(256),
+                               0, ctx->stream, p);
         ARVX_HIP(hipGetLastError());
         // the others: a fixed grid walks the list (8 waves per SIMD)
         static const int cgrid_env = getenv("ARVX_CLASSIFY_WGS") ? atoi(getenv("ARVX_CLASSIFY_WGS")) : 0;

@@ -182,6 +182,9 @@ __global__ __launch_bounds__(64) void views_tile_sums_kernel(const uint32_t *__r
     if (lane == 63) tilesum[((size_t)v * TI + I) * TJ + J] = sc;
 }
 
+// (Tried and dropped: bit planes and tile sums in one launch for one-channel masks -- lane r
+// reading the 64 mask BYTES of its row of the tile: the strided 64-byte reads cost more than the
+// launch saves, step +1.5 us at 36 views of 640 x 480.)
 // one wave per tile: the table entries of its 64 columns x 64 rows
 __global__ __launch_bounds__(64) void views_table_kernel(const uint32_t *__restrict__ bg,
                                                          int bgWords, int W, int H, int TJ, int TI,
