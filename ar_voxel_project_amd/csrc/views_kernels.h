@@ -132,7 +132,10 @@ __global__ __launch_bounds__(256) void views_bits_generic_kernel(const uint8_t *
 // The 4 (W+1)(H+1) bytes per view are written once and never read back.  In both kernels lane
 // r first LOADS row r's 64 bits (one round trip for the whole tile) and the rows are then
 // taken from the lanes one by one.
-constexpr int kTileRows = 64;
+#ifndef ARVX_TILE_ROWS
+#define ARVX_TILE_ROWS 64
+#endif
+constexpr int kTileRows = ARVX_TILE_ROWS;
 
 // 64 foreground bits of row y starting at column x0 (bit j = pixel x0 + j; 0 outside the image)
 __device__ __forceinline__ unsigned long long row_fg64(const uint32_t *__restrict__ bits,

@@ -2,8 +2,9 @@
  * arvx_oracle.c -- CPU restatement of the AR_Voxel_Project carving hot path.
  *
  * TEST INFRASTRUCTURE ONLY (see arvx_oracle.h).  PARITY PARTLY PINNED: marching cubes,
- * surface selection and closure geometry against the reference's own 1.off; the cv::gemm /
- * cv::norm arithmetic of the carve path is unpinned (the reference cannot be built here).
+ * surface selection and closure geometry against the reference's own 1.off, the face-colour
+ * rule against its 2.off / 3.off; the cv::gemm / cv::norm arithmetic of the carve path is
+ * unpinned (the reference cannot be built here).
  *
  * Every function cites the reference lines it follows (paths relative to the
  * reference checkout).  Two third-party calls sit on the path; their

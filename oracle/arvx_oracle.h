@@ -11,7 +11,9 @@
  * tests/golden/box_off1.npz, tools/make_off_fixture.py; tests/test_mc_off.py): the marching
  * cubes + OFF writer restatement reproduces the file byte for byte, the surface selection
  * (Model::isInner) is the file's vertex set, the closure is the one dilation the file's model
- * is the image of.  UNPINNED: the arithmetic of the two third-party calls on the carve path
+ * is the image of; 2.off / 3.off (box_off23.npz) decide the face-colour rule (third corner =
+ * second corner's colour, then round(sum / 3)) and are reproduced byte for byte on a voxel
+ * colouring they admit.  UNPINNED: the arithmetic of the two third-party calls on the carve path
  * (cv::gemm, cv::norm; opencv 4.6.x, unpinned in the reference's CMakeLists.txt:16), restated
  * from the published source, see arvx_oracle.c -- in particular the grouping of the M*world
  * row sums, for which both candidates are built and told apart by a test.

@@ -2,6 +2,11 @@
 Data/box_dataset/generated_models/1.off, as the fixture tests/golden/box_off1.npz
 (tools/make_off_fixture.py: the model the file determines + the file's bytes).
 
+And against 2.off / 3.off of the same directory (colour modes 1 and 2: the same mesh, coloured):
+the files decide the face-colour rule -- round((c0 + 2 c1) / 3), the reference's `i + 1`
+(src/MarchingCubes.h:506) -- and on a voxel colouring they admit (tests/golden/box_off23.npz)
+oracle, device and C++ writer must produce them byte for byte.
+
 CPU part (not gpu): the oracle's marching cubes, surface selection (Model::isInner) and
 closure against the fixture, and against a second restatement in numpy on coloured models.
 GPU part: arvx_mc_cells, arvx_color's surface list, arvx_closure and the C++
@@ -29,6 +34,18 @@ def off1():
     assert hashlib.sha256(text).digest() == d["off_sha256"].tobytes()
     return dict(X=X, Y=Y, Z=Z, s=np.float32(d["voxel_size"]), occ=occ, text=text,
                 surface_index=d["surface_index"], nv=int(d["n_vertices"]), nf=int(d["n_faces"]))
+
+
+@pytest.fixture(scope="module")
+def off23():
+    d = np.load(os.path.join(ROOT, "tests", "golden", "box_off23.npz"))
+    return {k: d[k] for k in d.files}
+
+
+def coloured_model(oracle, off1, vox_rgb):
+    rgba = oracle.model_from_state(state_of(off1["occ"]))
+    rgba[off1["surface_index"], :3] = vox_rgb
+    return rgba
 
 
 def state_of(occ):
@@ -77,6 +94,39 @@ def test_oracle_closure_is_one_dilation_on_the_files_model(oracle, off1):
     assert np.array_equal((closed[:, 3] != 0).reshape(Z, Y, X), occ)
     assert np.array_equal(closed[closed[:, 3] != 0], np.tile(np.float32([50, 168, 141, 1]),
                                                              (int(occ.sum()), 1)))
+
+
+@pytest.mark.parametrize("name", ["2", "3"])
+def test_reference_files_decide_the_face_colour_rule(off1, off23, name):
+    """Every vertex of 2.off / 3.off is a voxel, so each face colour is a linear constraint on
+    three voxel colours.  With the reference's rule -- third corner = second corner's colour,
+    then round(sum / 3) -- all 16 352 faces can be met with room to spare; with the mean of
+    three different corners they cannot (the best colouring misses some face by tens of
+    levels).  This is the `i + 1` of src/MarchingCubes.h:506 read off the reference's files."""
+    from tests.face_colour_lp import face_colour_program
+    X, Y = off1["X"], off1["Y"]
+    text = off1["text"].decode().split("\n")
+    v = np.array([ln.split() for ln in text[2:2 + off1["nv"]]], np.float64)
+    lat = np.rint(v / float(off1["s"])).astype(np.int64)
+    vox = np.searchsorted(off1["surface_index"], lat[:, 0] + X * (lat[:, 1] + Y * lat[:, 2]))
+    f = off23["face_rgb" + name][:, 1]  # green: the quickest of the three programs
+    n = len(off1["surface_index"])
+    status, margin, x = face_colour_program(vox, f, "second_twice", n)
+    assert status == 0 and margin > 0.1
+    status, margin, _ = face_colour_program(vox, f, "three_corners", n)
+    assert status == 0 and margin < -10.0
+
+
+@pytest.mark.parametrize("name", ["2", "3"])
+def test_oracle_marching_cubes_reproduces_2_off_and_3_off(oracle, off1, off23, name):
+    X, Y, Z = off1["X"], off1["Y"], off1["Z"]
+    rgba = coloured_model(oracle, off1, off23["vox_rgb" + name])
+    verts, rgb = oracle.mc_mesh(X, Y, Z, rgba, 0.5)
+    assert np.array_equal(rgb.astype(np.uint8), off23["face_rgb" + name])
+    text = oracle.off_text(verts, rgb, scale_factor=np.float32(1.0) * off1["s"])
+    assert hashlib.sha256(text.encode()).digest() == off23["sha256_" + name].tobytes()
+    tv, trgb = npr.mc_mesh(X, Y, Z, rgba, 0.5)
+    assert np.array_equal(verts, tv) and np.array_equal(rgb.astype(np.int64), trgb)
 
 
 def random_coloured_model(rng, X, Y, Z, fractional):
@@ -166,6 +216,20 @@ def test_gpu_mesh_reproduces_1_off(arvx, oracle, off1):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["2", "3"])
+def test_gpu_mesh_reproduces_2_off_and_3_off(arvx, oracle, off1, off23, name):
+    """The coloured files: arvx_mc_mesh's colour lookups, the `i + 1` rule and the rounding."""
+    X, Y, Z = off1["X"], off1["Y"], off1["Z"]
+    with arvx.Context(X, Y, Z, off1["s"]) as ctx:
+        ctx.upload_state(state_of(off1["occ"]))
+        ctx.upload_colors(off1["surface_index"].astype(np.int64), off23["vox_rgb" + name])
+        verts, rgb = ctx.mc_mesh()
+    assert np.array_equal(np.asarray(rgb).astype(np.uint8), off23["face_rgb" + name])
+    text = oracle.off_text(verts, rgb, scale_factor=np.float32(1.0) * off1["s"])
+    assert hashlib.sha256(text.encode()).digest() == off23["sha256_" + name].tobytes()
+
+
+@pytest.mark.gpu
 def test_gpu_mesh_colour_rules(arvx, oracle):
     """Colour pass colours, UNSEEN paint (explicit bit2 and apply_unseen), closure colours and
     the `i + 1` quirk: device triangles == oracle triangles on random models with w in {0, 1}."""
@@ -240,6 +304,16 @@ def test_cpp_marching_cubes_writes_1_off(host_bin, oracle, off1, tmp_path):
     assert "LOG - MC: Mesh written, marchingCubes completed." in log
     assert "ERR - MC: unable to write output file!" in log  # the second, unwritable call
     assert open(out, "rb").read() == off1["text"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["2", "3"])
+def test_cpp_marching_cubes_writes_2_off_and_3_off(host_bin, oracle, off1, off23, tmp_path, name):
+    X, Y, Z = off1["X"], off1["Y"], off1["Z"]
+    model, out = str(tmp_path / "model.bin"), str(tmp_path / "mesh.off")
+    write_model(model, X, Y, Z, off1["s"], coloured_model(oracle, off1, off23["vox_rgb" + name]))
+    run_mc(host_bin, model, out)
+    assert hashlib.sha256(open(out, "rb").read()).digest() == off23["sha256_" + name].tobytes()
 
 
 @pytest.mark.gpu
