@@ -256,20 +256,18 @@ inline SimpleMesh marchingCubesMesh(Model *model, float threshold = 0.5f) {
     int64_t n = 0;
     detail::check(arvx_mc_mesh(ctx, (painted && model->paint_is_unseen()) ? 1 : 0, &n),
                   "arvx_mc_mesh");
-    std::vector<float> verts((size_t)n * 9);
-    std::vector<uint32_t> rgb((size_t)n * 3);
-    if (n) detail::check(arvx_mc_mesh_download(ctx, verts.data(), rgb.data()),
-                         "arvx_mc_mesh_download");
+    // the device writes a triangle's three corners as nine floats: the mesh's vertex array
+    static_assert(sizeof(Vec3f) == 3 * sizeof(float), "Vec3f is three packed floats");
     std::vector<Vec3f> &mv = mesh.GetVertices();
     std::vector<Triangle> &mt = mesh.GetTriangles();
     mv.resize((size_t)n * 3);
+    std::vector<uint32_t> rgb((size_t)n * 3);
+    if (n) detail::check(arvx_mc_mesh_download(ctx, &mv[0].v[0], rgb.data()),
+                         "arvx_mc_mesh_download");
     mt.resize((size_t)n);
-    for (size_t t = 0; t < (size_t)n; ++t) {
-        for (int v = 0; v < 3; ++v)
-            mv[3 * t + v] = Vec3f(verts[9 * t + 3 * v], verts[9 * t + 3 * v + 1], verts[9 * t + 3 * v + 2]);
+    for (size_t t = 0; t < (size_t)n; ++t)
         mt[t] = Triangle{(unsigned)(3 * t), (unsigned)(3 * t + 1), (unsigned)(3 * t + 2), rgb[3 * t],
                          rgb[3 * t + 1], rgb[3 * t + 2]};
-    }
     return mesh;
 }
 

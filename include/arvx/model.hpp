@@ -308,8 +308,10 @@ class Model {
     void set_sorted(const std::vector<int64_t> &index, const float *rgba, int channels,
                     bool occupy) {
         if (index.empty()) return;
-        // (the planes are only touched to occupy voxels or to clear paint)
-        const bool touch = occupy || !paint_.empty() || paint_pending_;
+        // The planes are only touched to occupy voxels or to clear paint.  Voxels a device stage
+        // has just occupied (the closure's: host_stale_) arrive with the planes at the next
+        // sync, and they were empty before, hence not painted: nothing to touch.
+        const bool touch = (occupy && !host_stale_) || (!occupy && (!paint_.empty() || paint_pending_));
         if (touch) sync_host();
         std::vector<int> idx(index.size());
         std::vector<Vec4f> val(index.size());
@@ -317,16 +319,18 @@ class Model {
             idx[k] = (int)index[k];
             const float *c = rgba + (size_t)channels * k;
             val[k] = Vec4f(c[0], c[1], c[2], channels == 4 ? c[3] : 1.f);
-            const int x = idx[k] % size_x, y = (idx[k] / size_x) % size_y,
-                      z = idx[k] / (size_x * size_y);
-            if (touch) {
+        }
+        if (touch)
+            for (size_t k = 0; k < index.size(); ++k) {
+                const int x = idx[k] % size_x, y = (idx[k] / size_x) % size_y,
+                          z = idx[k] / (size_x * size_y);
                 const size_t w = word(x, y, z);
                 const uint32_t b = 1u << (x & 31);
                 if (occupy && val[k].w() != 0) occ_[w] |= b;
                 if (!paint_.empty()) paint_[w] &= ~b;
             }
-            if (!overlay_.empty()) overlay_.erase(idx[k]);
-        }
+        if (!overlay_.empty())
+            for (size_t k = 0; k < index.size(); ++k) overlay_.erase(idx[k]);
         if (cidx_.empty()) {
             cidx_.swap(idx);
             cval_.swap(val);
