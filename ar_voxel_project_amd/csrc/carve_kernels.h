@@ -1183,6 +1183,8 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
 // Returns, lane s = the s-th view of `views` (ascending bit order), the 16-bit mask of the
 // blocks to project in it (bit 4 m + j, m = 2 byi + bzi); carved / seen get the blocks some
 // view settled.  `part`/`pshift`: only every 2^pshift-th view belongs to this wave.
+// (Tried and dropped: eight views per pass as two independent groups, so that two groups share
+// the pass's two dependent round trips -- more scratch, carve +2 % at 512^3 and 1024^3.)
 __device__ __forceinline__ unsigned block_tests(const CarveParams &p, const SubTile &t, int vbase,
                                                 unsigned long long views, int part, int pshift,
                                                 int lane, unsigned &carved, unsigned &seen) {
