@@ -10,7 +10,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def names():
     return sorted(n for n in (os.path.splitext(os.path.basename(p))[0]
                               for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-                  if n not in ("dataset_masks", "box_off1"))
+                  if n not in ("dataset_masks", "box_off1", "box_off23"))
 
 
 def dataset_masks(which, recentre=False):
