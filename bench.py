@@ -333,13 +333,13 @@ def main():
                            "time); see physical_frac for what the chip moves",
                 "physical_GBps": phys,
                 "physical_frac": (phys / HBM_PEAK_GBS) if phys else None,
-                "kernel": "carve_coarse_kernel + carve_fill_kernel + carve_classify_kernel + "
+                "kernel": "carve_coarse_fill_kernel + carve_classify_kernel + "
                           "carve_exact_blocks_kernel (one arvx_carve call)",
                 "kernel_ms": r["kern_ms"],
                 "algorithmic_bytes": alg_bytes,
                 "valu": valu,
                 "step": {"kernels": "views_bits + views_tile_sums + views_table "
-                                    "(arvx_set_views_device) + the four carve kernels",
+                                    "(arvx_set_views_device) + the three carve kernels",
                          "kernel_ms": step_kernel_ms,
                          "effective_frac": alg_bytes / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic_step,

@@ -16,7 +16,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CARVE = ("coarse", "fill", "classify", "exact", "fused")
+CARVE = ("coarse_fill", "coarse", "fill", "classify", "exact", "fused")
 VIEWS = ("views_bits", "views_tile_sums", "views_table", "views_rows", "views_cols",
          "mask_to_bits", "sat_rows", "sat_cols")
 

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kernel_key(name):
-    for k in ("coarse", "classify", "exact", "fused", "fill"):
+    for k in ("coarse_fill", "coarse", "classify", "exact", "fused", "fill"):
         if "carve_" + k in name:
             return k
     # arvx_set_views_device (round 1 names, then csrc/views_kernels.h)
