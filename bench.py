@@ -99,8 +99,8 @@ def cpu_baseline(sc, X, Y, Z, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--grid", type=int, default=512, help="base grid edge per GPU")
     ap.add_argument("--views", type=int, default=36)
     ap.add_argument("--no-cull", action="store_true", help="evaluate every voxel in every view")
