@@ -31,6 +31,7 @@ host on a bounded slab of the same workload).
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -229,6 +230,11 @@ def main():
                 drain()
             # packets start at the worst-case size; size them to what this scene needs
             packet_cap = ex.retune((nstep[0] - 1) % 2)
+        # (the interpreter's cyclic collector pauses for 40-85 ms once torch is loaded -- seen at
+        # the 543rd set_views_device call, tools/host_probe.py -- and a pause that long drains
+        # the launch queue: no collections inside the timed region)
+        gc.collect()
+        gc.disable()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -238,6 +244,7 @@ def main():
         barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        gc.enable()
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Probe: how much of arvx_set_views_device hides behind arvx_carve when the two run on
 different streams (two contexts, no dependency between them)?  GPU required."""
+import gc
 import os
 import sys
 import time
@@ -43,7 +44,8 @@ def run(mode, steps=200):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-for _ in range(2):
+gc.disable()
+for _ in range(4):
     for mode in ("serial", "carve", "views", "overlap"):
         run(mode, 20)
         print(N, mode, round(run(mode), 4), "ms per step")
