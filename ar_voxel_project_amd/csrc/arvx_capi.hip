@@ -1675,11 +1675,13 @@ int arvx_fast_carve(arvx_ctx *ctx) {
     ctx->closure_ready = false;
     arvx::FloodParams fp;
     // a fresh model (the usual case: src/main.cpp calls fastCarve on a new Model) is neither
-    // filled nor read: the kernels know its bytes, and flood_apply writes the whole plane
+    // filled nor read: the kernels know its records, and flood_apply_rec_kernel writes them all
     fp.fresh = ctx->fresh_pending ? 1 : 0;
     if (fp.fresh) {
-        if (!ctx->d_state) ARVX_HIP(hipMalloc(&ctx->d_state, ctx->nvox_ext));
-    } else if (int mrc = need_bytes(ctx)) {
+        void *buf = ctx->d_rec;
+        if (int rc = ensure_records(ctx, &buf, &ctx->rec_bytes)) return rc;
+        ctx->d_rec = (uint16_t *)buf;
+    } else if (int mrc = need_rec(ctx)) {
         return mrc;
     }
     fp.X = ctx->X;
@@ -1691,12 +1693,11 @@ int arvx_fast_carve(arvx_ctx *ctx) {
     const int tile_rows = tilesY * tilesZ;
     const unsigned gflood = (unsigned)((size_t)fp.XW * tile_rows);
     const bool prepass = fp.XW <= 64 && tile_rows <= arvx::kFloodMaxTileRows;
-    const bool by8 = (fp.X % 8 == 0);  // 8 voxels per thread, 8-byte accesses
 
-    // one work buffer, kept by the context: carvable plane | open, reach bit planes |
-    // whole-tile rows (full, reached) | wake flags (2 x tiles) | changed flag
+    // one work buffer, kept by the context: open, reach bit planes | whole-tile rows (full,
+    // reached) | wake flags (2 x tiles) | changed flag
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t o_bits = up(ctx->nvox);
+    const size_t o_bits = 0;
     const size_t o_tiles = o_bits + up(2 * nwords * sizeof(unsigned long long));
     const size_t o_dirty = o_tiles + up(2 * (size_t)tile_rows * sizeof(unsigned long long));
     const size_t o_changed = o_dirty + up(2 * (size_t)gflood);
@@ -1709,7 +1710,6 @@ int arvx_fast_carve(arvx_ctx *ctx) {
         ctx->flood_bytes = need;
     }
     uint8_t *base = (uint8_t *)ctx->d_flood;
-    uint8_t *d_tmp = base;
     fp.open = (unsigned long long *)(base + o_bits);
     fp.reach = fp.open + nwords;
     unsigned long long *d_tiles = (unsigned long long *)(base + o_tiles);
@@ -1717,33 +1717,14 @@ int arvx_fast_carve(arvx_ctx *ctx) {
     fp.changed = (int *)(base + o_changed);
     fp.dirty_cur = fp.dirty_next = nullptr;  // set per launch of flood_step_kernel
 
-    // carvable = what the dense carve clears on a fresh model: carved into records of its
-    // own, then expanded to the byte form the flood kernels read
+    // carvable = what the dense carve clears on a fresh model: carved into records of its own
     if (int rc = ensure_records(ctx, &ctx->d_flood_rec, &ctx->flood_rec_bytes)) return rc;
     if (int rc = launch_carve(ctx, (uint16_t *)ctx->d_flood_rec, 0, ctx->V, 0, true)) return rc;
-    {
-        arvx::CarveParams g;
-        carve_geometry(ctx, g);
-        g.rec = (uint16_t *)ctx->d_flood_rec;
-        hipLaunchKernelGGL(arvx::rec_to_bytes_kernel,
-                           dim3((unsigned)((size_t)g.tilesX * g.tilesY * g.tilesZ)), dim3(256), 0,
-                           ctx->stream, g, d_tmp);
-        ARVX_HIP(hipGetLastError());
-    }
-    if (fp.X % 32 == 0 && (((uintptr_t)d_tmp | (uintptr_t)ctx->d_state) & 15u) == 0) {
-        ARVX_HIP(hipMemsetAsync(fp.reach, 0, nwords * sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(arvx::flood_pack_open32_kernel,
-                           dim3((unsigned)((nwords * 2 + 255) / 256)), dim3(256), 0, ctx->stream,
-                           d_tmp, ctx->d_state, fp);
-    } else if (by8) {
-        ARVX_HIP(hipMemsetAsync(fp.reach, 0, nwords * sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(arvx::flood_pack_open8_kernel,
-                           dim3((unsigned)((nwords * 8 + 255) / 256)), dim3(256), 0, ctx->stream,
-                           d_tmp, ctx->d_state, fp);
-    } else {
-        hipLaunchKernelGGL(arvx::flood_pack_open_kernel, dim3((unsigned)((nwords + 3) / 4)),
-                           dim3(256), 0, ctx->stream, d_tmp, ctx->d_state, fp);
-    }
+    arvx::CarveParams g;
+    carve_geometry(ctx, g);
+    g.rec = ctx->d_rec;
+    hipLaunchKernelGGL(arvx::flood_open_from_rec_kernel, dim3((unsigned)((nwords + 255) / 256)),
+                       dim3(256), 0, ctx->stream, g, (const uint16_t *)ctx->d_flood_rec, fp);
     ARVX_HIP(hipGetLastError());
     // whole-tile pre-pass (fast_carve_kernels.h): seeds every completely open tile
     // that is connected to the origin tile through completely open tiles
@@ -1782,21 +1763,15 @@ int arvx_fast_carve(arvx_ctx *ctx) {
         if (launched >= max_launches) return fail(ARVX_ERR_HIP, "flood fill did not converge");
         if (round >= 1 && batch < 8) batch *= 2;
     }
-    if (fp.X % 16 == 0)
-        hipLaunchKernelGGL(arvx::flood_apply_wide_kernel<uint16_t>,
-                           dim3((unsigned)((ctx->nvox / 16 + 255) / 256)), dim3(256), 0,
-                           ctx->stream, ctx->d_state, fp);
-    else if (by8)
-        hipLaunchKernelGGL(arvx::flood_apply_wide_kernel<uint8_t>,
-                           dim3((unsigned)((ctx->nvox / 8 + 255) / 256)), dim3(256), 0,
-                           ctx->stream, ctx->d_state, fp);
-    else
-        hipLaunchKernelGGL(arvx::flood_apply_kernel, dim3((unsigned)((ctx->nvox + 255) / 256)),
-                           dim3(256), 0, ctx->stream, ctx->d_state, fp);
+    {
+        const size_t nrec = arvx::rec_count(g);
+        hipLaunchKernelGGL(arvx::flood_apply_rec_kernel, dim3((unsigned)((nrec * 32 + 255) / 256)),
+                           dim3(256), 0, ctx->stream, g, fp, nrec);
+    }
     ARVX_HIP(hipGetLastError());
-    ctx->fresh_pending = false;  // the byte plane now holds every voxel's state
-    ctx->bytes_valid = true;
-    ctx->rec_valid = false;
+    ctx->fresh_pending = false;  // the records now hold every voxel's state
+    ctx->rec_valid = true;
+    ctx->bytes_valid = false;
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
     return ARVX_OK;
 }

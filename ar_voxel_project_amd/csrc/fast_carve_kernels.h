@@ -41,86 +41,32 @@ struct FloodParams {
                 // flood_apply writes every voxel instead of the changed ones
 };
 
-// open = carvable & !seen0, one wave per (row, word)
-__global__ __launch_bounds__(256) void flood_pack_open_kernel(const uint8_t *__restrict__ carved_tmp,
-                                                              const uint8_t *__restrict__ state,
-                                                              const FloodParams p) {
-    const size_t wv = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const size_t nrows = (size_t)p.Y * p.Z;
-    if (wv >= nrows * p.XW) return;
-    const size_t row = wv / p.XW;
-    const int xw = (int)(wv % p.XW);
-    const int x = xw * 64 + (threadIdx.x & 63);
-    bool o = false;
-    if (x < p.X) {
-        const size_t i = row * p.X + x;
-        o = !(carved_tmp[i] & 1u) && (p.fresh || !(state[i] & 2u));
+// open = carvable & !seen0 from the two sets of sub-tile records (arvx_device.h): `carv` is a
+// fresh model carved by all views -- a voxel is carvable where its occupancy bit is gone --,
+// `state` the model's own records (not read for a fresh model).  One thread per 64-bit word of
+// the bit plane = the same row of the four sub-tiles of one tile.  The thread of voxel
+// (0,0,0) plants the seed.
+__global__ __launch_bounds__(256) void flood_open_from_rec_kernel(const CarveParams g,
+                                                                  const uint16_t *__restrict__ carv,
+                                                                  const FloodParams p) {
+    const size_t n = (size_t)p.XW * p.Y * p.Z;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int xw = (int)(i % p.XW), y = (int)((i / p.XW) % p.Y), z = (int)(i / ((size_t)p.XW * p.Y));
+    const int r = (z & 7) * 8 + (y & 7);
+    const size_t rec0 = rec_index(g, xw, y >> 3, z >> 3, 0) * kRecU16;
+    unsigned long long w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // the tile's four sub-tiles: 16 voxels each
+        if (64 * xw + 16 * k >= p.X) break;
+        unsigned long long o = (uint16_t)~carv[rec0 + k * kRecU16 + r];
+        if (!p.fresh) o &= (unsigned long long)(uint16_t)~g.rec[rec0 + k * kRecU16 + 64 + r];
+        w |= o << (16 * k);
     }
-    const unsigned long long b = __ballot(o);
-    if ((threadIdx.x & 63) == 0) {
-        p.open[wv] = b;
-        p.reach[wv] = (wv == 0) ? (b & 1ull) : 0ull;  // seed: voxel (0,0,0) if it is open
-    }
-}
-
-// The same for X % 8 == 0: one thread packs 8 voxels into one BYTE of the bit plane
-// (byte j of a little-endian 64-bit word = voxels 8j..8j+7), 8-byte loads, byte store.
-// Rows are padded to whole words; the padding bytes are written as zero.  `reach`
-// is cleared by the host; the thread of voxel (0,0,0) plants the seed.
-__global__ __launch_bounds__(256) void flood_pack_open8_kernel(const uint8_t *__restrict__ carved_tmp,
-                                                               const uint8_t *__restrict__ state,
-                                                               const FloodParams p) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int rowBytes = p.XW * 8;
-    const size_t nrows = (size_t)p.Y * p.Z;
-    if (t >= nrows * rowBytes) return;
-    const size_t row = t / rowBytes;
-    const int g = (int)(t % rowBytes);
-    uint8_t b = 0;
-    if (g * 8 < p.X) {
-        const size_t i = row * p.X + (size_t)g * 8;
-        const unsigned long long c = *(const unsigned long long *)(carved_tmp + i);
-        const unsigned long long s =
-            p.fresh ? 0x0101010101010101ull : *(const unsigned long long *)(state + i);
-        // open = carved on the fresh plane (bit0 clear) and not seen (bit1 clear)
-        const unsigned long long m = ~c & ~(s >> 1) & 0x0101010101010101ull;
-        b = (uint8_t)((m * 0x0102040810204080ull) >> 56);  // byte j's bit 0 -> bit j
-    }
-    ((uint8_t *)p.open)[t] = b;
-    if (t == 0) ((uint8_t *)p.reach)[0] = b & 1u;
-}
-
-// The same for X % 32 == 0: 32 voxels per thread, 16-byte loads, one 32-bit half word out.
-__global__ __launch_bounds__(256) void flood_pack_open32_kernel(const uint8_t *__restrict__ carved_tmp,
-                                                                const uint8_t *__restrict__ state,
-                                                                const FloodParams p) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int rowHalves = p.XW * 2;
-    const size_t nrows = (size_t)p.Y * p.Z;
-    if (t >= nrows * rowHalves) return;
-    const size_t row = t / rowHalves;
-    const int h = (int)(t % rowHalves);
-    uint32_t w = 0;
-    if (h * 32 < p.X) {
-        const size_t i = row * p.X + (size_t)h * 32;
-        const ulonglong2 *c = (const ulonglong2 *)(carved_tmp + i);
-        const ulonglong2 c0 = c[0], c1 = c[1];
-        ulonglong2 s0, s1;
-        s0.x = s0.y = s1.x = s1.y = 0x0101010101010101ull;
-        if (!p.fresh) {
-            const ulonglong2 *sp = (const ulonglong2 *)(state + i);
-            s0 = sp[0];
-            s1 = sp[1];
-        }
-        const unsigned long long one = 0x0101010101010101ull, mul = 0x0102040810204080ull;
-        auto pack = [&](unsigned long long cc, unsigned long long ss) -> uint32_t {
-            return (uint32_t)(((~cc & ~(ss >> 1) & one) * mul) >> 56);
-        };
-        w = pack(c0.x, s0.x) | (pack(c0.y, s0.y) << 8) | (pack(c1.x, s1.x) << 16) |
-            (pack(c1.y, s1.y) << 24);
-    }
-    ((uint32_t *)p.open)[t] = w;
-    if (t == 0) ((uint8_t *)p.reach)[0] = (uint8_t)(w & 1u);
+    const int nx = p.X - 64 * xw;  // voxels behind the end of the row: not open
+    if (nx < 64) w &= (1ull << nx) - 1ull;
+    p.open[i] = w;
+    p.reach[i] = (i == 0) ? (w & 1ull) : 0ull;
 }
 
 __device__ __forceinline__ unsigned long long fill_row(unsigned long long seed,
@@ -308,81 +254,67 @@ __global__ __launch_bounds__(256) void flood_step_kernel(const FloodParams p) {
     }
 }
 
-// occ &= !E ; seen |= E | N6(E) | origin      (state plane, one byte per voxel)
-__global__ __launch_bounds__(256) void flood_apply_kernel(uint8_t *__restrict__ state,
-                                                          const FloodParams p) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t n = (size_t)p.X * p.Y * p.Z;
-    if (i >= n) return;
-    const int x = (int)(i % p.X);
-    const size_t t = i / p.X;
-    const int y = (int)(t % p.Y), z = (int)(t / p.Y);
-    auto bit = [&](int xx, int yy, int zz) -> bool {
-        if (xx < 0 || xx >= p.X || yy < 0 || yy >= p.Y || zz < 0 || zz >= p.Z) return false;
-        return (p.reach[((size_t)zz * p.Y + yy) * p.XW + (xx >> 6)] >> (xx & 63)) & 1ull;
-    };
-    uint8_t s = p.fresh ? (uint8_t)1 : state[i];
-    if (bit(x, y, z)) {
-        s = (uint8_t)((s & ~1u) | 2u);  // carved (src/VoxelCarving.cpp:125) and visited (:108)
-    } else if (!(s & 2u)) {
-        const bool nb = bit(x - 1, y, z) || bit(x + 1, y, z) || bit(x, y - 1, z) ||
-                        bit(x, y + 1, z) || bit(x, y, z - 1) || bit(x, y, z + 1);
-        if (nb || i == 0) s |= 2u;  // pushed by a carved neighbour (:132-163) or the seed (:100)
-    }
-    state[i] = s;
-}
-
-// The same for X % 8 == 0 (T = uint8_t: one thread owns the 8 voxels of one byte of
-// the bit plane, 8-byte state access) and X % 16 == 0 (T = uint16_t: 16 voxels, 16-byte
-// state access).
-template <typename T>
-__global__ __launch_bounds__(256) void flood_apply_wide_kernel(uint8_t *__restrict__ state,
-                                                               const FloodParams p) {
-    constexpr int kV = 8 * (int)sizeof(T);  // voxels per thread
+// occ &= !E ; seen |= E | N6(E) | origin, on the model's records.  One thread per pair of
+// entries of a record (rows y, y + 1 of a sub-tile: 16 voxels each): the record is read and
+// written in whole words, the 16-bit pieces of the reach plane come through the L2.  For a
+// fresh model nothing is read and EVERY record is written (padding as occ 0 / seen 1).
+__global__ __launch_bounds__(256) void flood_apply_rec_kernel(const CarveParams g,
+                                                              const FloodParams p, size_t nrec) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int rowUnits = p.XW * 64 / kV, gmax = p.X / kV;
-    const size_t nrows = (size_t)p.Y * p.Z;
-    if (t >= nrows * gmax) return;
-    const size_t row = t / gmax;
-    const int g = (int)(t % gmax);
-    const int y = (int)(row % p.Y), z = (int)(row / p.Y);
-    const T *rb = (const T *)p.reach + row * rowUnits + g;
-    const unsigned top = kV - 1, mask = (kV == 8) ? 0xFFu : 0xFFFFu;
-    const unsigned e = rb[0];
-    unsigned nb = ((e << 1) | (e >> 1)) & mask;
-    if (g > 0) nb |= (unsigned)rb[-1] >> top;
-    if (g + 1 < gmax) nb |= ((unsigned)rb[1] & 1u) << top;
-    if (y > 0) nb |= rb[-(ptrdiff_t)rowUnits];
-    if (y + 1 < p.Y) nb |= rb[rowUnits];
-    if (z > 0) nb |= rb[-(ptrdiff_t)rowUnits * p.Y];
-    if (z + 1 < p.Z) nb |= rb[(ptrdiff_t)rowUnits * p.Y];
-    if (t == 0) nb |= 1u;  // the seed is visited whatever happens (:100)
-    if ((e | nb) == 0u && !p.fresh) return;
-    // bit j -> 0x01 in byte j
-    auto spread = [](unsigned b) -> unsigned long long {
-        const unsigned long long v = ((b & 0xFFu) * 0x0101010101010101ull) & 0x8040201008040201ull;
-        return ((v + 0x7F7F7F7F7F7F7F7Full) >> 7) & 0x0101010101010101ull;
-    };
-    // carved: clear bit0, set bit1; pushed by a carved neighbour: set bit1
-    unsigned long long *sp = (unsigned long long *)(state + row * p.X + (size_t)g * kV);
-    if (kV == 8) {
-        const unsigned long long s = p.fresh ? 0x0101010101010101ull : sp[0];
-        const unsigned long long E = spread(e), N = spread(nb);
-        const unsigned long long ns = (s & ~E) | ((E | N) << 1);
-        if (ns != s || p.fresh) sp[0] = ns;
-    } else {
-        ulonglong2 s;
-        if (p.fresh)
-            s.x = s.y = 0x0101010101010101ull;
-        else
-            s = *(const ulonglong2 *)sp;
-        const unsigned long long E0 = spread(e), N0 = spread(nb);
-        const unsigned long long E1 = spread(e >> 8), N1 = spread(nb >> 8);
-        ulonglong2 ns;
-        ns.x = (s.x & ~E0) | ((E0 | N0) << 1);
-        ns.y = (s.y & ~E1) | ((E1 | N1) << 1);
-        if (ns.x != s.x || ns.y != s.y || p.fresh) *(ulonglong2 *)sp = ns;
+    if (t >= nrec * 32) return;
+    const size_t ri = t >> 5;
+    const int j = (int)(t & 31);  // entries 2 j, 2 j + 1
+    // record index -> tile and sub-tile (inverse of rec_index)
+    const int wave = (int)(ri & 3);
+    const int tshift = g.cyShift + g.czShift;
+    const size_t tile = ri >> 2;
+    const int tl = (int)(tile & ((1u << tshift) - 1)), ct = (int)(tile >> tshift);
+    const int tx = ct % g.coarseX;
+    const int ty = (((ct / g.coarseX) % g.coarseY) << g.cyShift) + (tl & ((1 << g.cyShift) - 1));
+    const int tz = ((ct / (g.coarseX * g.coarseY)) << g.czShift) + (tl >> g.cyShift);
+    const int x0 = tx * kTileX + wave * kSubX;
+    const int u = x0 >> 4, units = p.XW * 4;  // 16-bit pieces of a row of the bit plane
+    const uint16_t *reach = reinterpret_cast<const uint16_t *>(p.reach);
+    uint32_t *occ32 = reinterpret_cast<uint32_t *>(g.rec + ri * kRecU16) + j;
+    uint32_t *seen32 = occ32 + 32;
+    uint32_t occ = 0, seen = 0xffffffffu;
+    if (!p.fresh) {
+        occ = *occ32;
+        seen = *seen32;
     }
+    const uint32_t occ_before = occ, seen_before = seen;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = 2 * j + h;
+        const int y = ty * kTileY + (r & 7), z = tz * kTileZ + (r >> 3);
+        const uint32_t in = row_inmask(g, tx, ty, tz, wave, r);
+        if (!in) continue;  // outside the grid: occ 0, seen 1
+        const size_t row = (size_t)z * p.Y + y;
+        const uint16_t *c = reach + row * units + u;
+        const uint32_t e = c[0];
+        uint32_t nb = (e << 1) | (e >> 1);
+        if (u > 0) nb |= (uint32_t)c[-1] >> 15;
+        if (u + 1 < units) nb |= ((uint32_t)c[1] & 1u) << 15;
+        if (y > 0) nb |= c[-(ptrdiff_t)units];
+        if (y + 1 < p.Y) nb |= c[units];
+        if (z > 0) nb |= c[-(ptrdiff_t)units * p.Y];
+        if (z + 1 < p.Z) nb |= c[(ptrdiff_t)units * p.Y];
+        if (row == 0 && u == 0) nb |= 1u;  // the seed is visited whatever happens (:100)
+        const uint32_t visited = (e | nb) & in;  // carved (:125, :108) or pushed by a carved
+                                                 // neighbour (:132-163)
+        uint32_t o16, s16;
+        if (p.fresh) {
+            o16 = in & ~e;
+            s16 = (~in & 0xffffu) | visited;
+        } else {
+            o16 = ((occ >> (16 * h)) & 0xffffu) & ~e;
+            s16 = ((seen >> (16 * h)) & 0xffffu) | visited;
+        }
+        occ = (occ & ~(0xffffu << (16 * h))) | (o16 << (16 * h));
+        seen = (seen & ~(0xffffu << (16 * h))) | (s16 << (16 * h));
+    }
+    if (p.fresh || occ != occ_before) *occ32 = occ;
+    if (p.fresh || seen != seen_before) *seen32 = seen;
 }
 
 }  // namespace arvx
