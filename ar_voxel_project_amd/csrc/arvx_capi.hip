@@ -1764,9 +1764,9 @@ int arvx_fast_carve(arvx_ctx *ctx) {
         if (round >= 1 && batch < 8) batch *= 2;
     }
     {
-        const size_t nrec = arvx::rec_count(g);
-        hipLaunchKernelGGL(arvx::flood_apply_rec_kernel, dim3((unsigned)((nrec * 32 + 255) / 256)),
-                           dim3(256), 0, ctx->stream, g, fp, nrec);
+        const size_t ntiles = arvx::rec_count(g) / 4;
+        hipLaunchKernelGGL(arvx::flood_apply_rec_kernel, dim3((unsigned)((ntiles + 3) / 4)),
+                           dim3(256), 0, ctx->stream, g, fp, ntiles);
     }
     ARVX_HIP(hipGetLastError());
     ctx->fresh_pending = false;  // the records now hold every voxel's state

@@ -254,67 +254,57 @@ __global__ __launch_bounds__(256) void flood_step_kernel(const FloodParams p) {
     }
 }
 
-// occ &= !E ; seen |= E | N6(E) | origin, on the model's records.  One thread per pair of
-// entries of a record (rows y, y + 1 of a sub-tile: 16 voxels each): the record is read and
-// written in whole words, the 16-bit pieces of the reach plane come through the L2.  For a
-// fresh model nothing is read and EVERY record is written (padding as occ 0 / seen 1).
+// occ &= !E ; seen |= E | N6(E) | origin, on the model's records.  One wave per tile (four
+// records), lane = entry r of the records = row (y & 7, z & 7) of the tile: the lane reads its
+// 64-bit word of the reach plane and the words around it, and the 16-bit entries of the four
+// sub-tiles are written lane by lane -- 128 contiguous bytes per store.  For a fresh model
+// nothing is read and EVERY record is written (padding as occ 0 / seen 1).
 __global__ __launch_bounds__(256) void flood_apply_rec_kernel(const CarveParams g,
-                                                              const FloodParams p, size_t nrec) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= nrec * 32) return;
-    const size_t ri = t >> 5;
-    const int j = (int)(t & 31);  // entries 2 j, 2 j + 1
-    // record index -> tile and sub-tile (inverse of rec_index)
-    const int wave = (int)(ri & 3);
+                                                              const FloodParams p, size_t ntiles) {
+    const size_t tile = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const int r = threadIdx.x & 63;
+    // tile index in record order -> tile coordinates (inverse of rec_index)
     const int tshift = g.cyShift + g.czShift;
-    const size_t tile = ri >> 2;
     const int tl = (int)(tile & ((1u << tshift) - 1)), ct = (int)(tile >> tshift);
     const int tx = ct % g.coarseX;
     const int ty = (((ct / g.coarseX) % g.coarseY) << g.cyShift) + (tl & ((1 << g.cyShift) - 1));
     const int tz = ((ct / (g.coarseX * g.coarseY)) << g.czShift) + (tl >> g.cyShift);
-    const int x0 = tx * kTileX + wave * kSubX;
-    const int u = x0 >> 4, units = p.XW * 4;  // 16-bit pieces of a row of the bit plane
-    const uint16_t *reach = reinterpret_cast<const uint16_t *>(p.reach);
-    uint32_t *occ32 = reinterpret_cast<uint32_t *>(g.rec + ri * kRecU16) + j;
-    uint32_t *seen32 = occ32 + 32;
-    uint32_t occ = 0, seen = 0xffffffffu;
-    if (!p.fresh) {
-        occ = *occ32;
-        seen = *seen32;
-    }
-    const uint32_t occ_before = occ, seen_before = seen;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int r = 2 * j + h;
-        const int y = ty * kTileY + (r & 7), z = tz * kTileZ + (r >> 3);
-        const uint32_t in = row_inmask(g, tx, ty, tz, wave, r);
-        if (!in) continue;  // outside the grid: occ 0, seen 1
+    const int y = ty * kTileY + (r & 7), z = tz * kTileZ + (r >> 3);
+    uint16_t *rec = g.rec + (tile << 2) * kRecU16;
+    unsigned long long e = 0, nb = 0, in = 0;
+    if (y < p.Y && z < p.Z && tx < p.XW) {
+        const int nx = p.X - 64 * tx;
+        in = nx >= 64 ? ~0ull : ((1ull << nx) - 1ull);
         const size_t row = (size_t)z * p.Y + y;
-        const uint16_t *c = reach + row * units + u;
-        const uint32_t e = c[0];
-        uint32_t nb = (e << 1) | (e >> 1);
-        if (u > 0) nb |= (uint32_t)c[-1] >> 15;
-        if (u + 1 < units) nb |= ((uint32_t)c[1] & 1u) << 15;
-        if (y > 0) nb |= c[-(ptrdiff_t)units];
-        if (y + 1 < p.Y) nb |= c[units];
-        if (z > 0) nb |= c[-(ptrdiff_t)units * p.Y];
-        if (z + 1 < p.Z) nb |= c[(ptrdiff_t)units * p.Y];
-        if (row == 0 && u == 0) nb |= 1u;  // the seed is visited whatever happens (:100)
-        const uint32_t visited = (e | nb) & in;  // carved (:125, :108) or pushed by a carved
-                                                 // neighbour (:132-163)
-        uint32_t o16, s16;
-        if (p.fresh) {
-            o16 = in & ~e;
-            s16 = (~in & 0xffffu) | visited;
-        } else {
-            o16 = ((occ >> (16 * h)) & 0xffffu) & ~e;
-            s16 = ((seen >> (16 * h)) & 0xffffu) | visited;
-        }
-        occ = (occ & ~(0xffffu << (16 * h))) | (o16 << (16 * h));
-        seen = (seen & ~(0xffffu << (16 * h))) | (s16 << (16 * h));
+        const unsigned long long *c = p.reach + row * p.XW + tx;
+        e = c[0];
+        nb = (e << 1) | (e >> 1);
+        if (tx > 0) nb |= c[-1] >> 63;
+        if (tx + 1 < p.XW) nb |= c[1] << 63;
+        if (y > 0) nb |= c[-(ptrdiff_t)p.XW];
+        if (y + 1 < p.Y) nb |= c[p.XW];
+        if (z > 0) nb |= c[-(ptrdiff_t)p.XW * p.Y];
+        if (z + 1 < p.Z) nb |= c[(ptrdiff_t)p.XW * p.Y];
+        if (row == 0 && tx == 0) nb |= 1ull;  // the seed is visited whatever happens (:100)
     }
-    if (p.fresh || occ != occ_before) *occ32 = occ;
-    if (p.fresh || seen != seen_before) *seen32 = seen;
+    // carved (:125, :108) or pushed by a carved neighbour (:132-163)
+    const unsigned long long visited = (e | nb) & in;
+    if (!p.fresh && __builtin_amdgcn_readfirstlane(__ballot(visited != 0) == 0)) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // the tile's four sub-tiles: 16 voxels each
+        const uint32_t e16 = (uint32_t)(e >> (16 * k)) & 0xffffu;
+        const uint32_t v16 = (uint32_t)(visited >> (16 * k)) & 0xffffu;
+        const uint32_t in16 = (uint32_t)(in >> (16 * k)) & 0xffffu;
+        uint16_t *o = rec + k * kRecU16 + r, *sn = o + 64;
+        if (p.fresh) {
+            *o = (uint16_t)(in16 & ~e16);
+            *sn = (uint16_t)((~in16 & 0xffffu) | v16);
+        } else if (v16) {
+            if (e16) *o = (uint16_t)(*o & ~e16);
+            *sn = (uint16_t)(*sn | v16);
+        }
+    }
 }
 
 }  // namespace arvx

@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ar_voxel_project_amd import capi, synthetic as syn
 
-for N in (256, 512, 1024):
+for N in ([int(a) for a in sys.argv[1:]] or [256, 512, 1024]):
     sc = syn.sphere_scene(N, 36)
     with capi.Context(N, N, N, sc.voxel_size) as ctx:
         ctx.set_views(sc.M, sc.masks)
