@@ -1742,24 +1742,27 @@ int arvx_fast_carve(arvx_ctx *ctx) {
     // (which sets the first buffer) all tiles are awake at first
     if (!prepass) ARVX_HIP(hipMemsetAsync(d_dirty, 1, gflood, ctx->stream));
     ARVX_HIP(hipMemsetAsync(d_dirty + gflood, 0, gflood, ctx->stream));
-    // every launch that is not the last grows at least one word; the flag is read
-    // back after 4, 4, 8, 8, ... launches (a launch with no tile awake costs microseconds)
+    // every launch that is not the last grows at least one word; the launches of a batch write
+    // one flag each, read back after 4, 4, 8, 8, ... launches: the fill has converged when the
+    // LAST launch of a batch changed nothing (a launch with no tile awake costs microseconds)
     const long max_launches = 128 + (long)gflood * 256;
     long launched = 0;
+    int *const flags = fp.changed;
     for (int batch = 4, round = 0;; ++round) {
-        int changed = 0;
-        ARVX_HIP(hipMemsetAsync(fp.changed, 0, sizeof(int), ctx->stream));
+        int changed[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        ARVX_HIP(hipMemsetAsync(flags, 0, 8 * sizeof(int), ctx->stream));
         for (int k = 0; k < batch; ++k, ++launched) {
             fp.dirty_cur = d_dirty + (launched & 1) * (size_t)gflood;
             fp.dirty_next = d_dirty + ((launched + 1) & 1) * (size_t)gflood;
+            fp.changed = flags + k;
             hipLaunchKernelGGL(arvx::flood_step_kernel, dim3(gflood), dim3(256), 0, ctx->stream,
                                fp);
             ARVX_HIP(hipGetLastError());
         }
-        ARVX_HIP(hipMemcpyAsync(&changed, fp.changed, sizeof(int), hipMemcpyDeviceToHost,
+        ARVX_HIP(hipMemcpyAsync(changed, flags, 8 * sizeof(int), hipMemcpyDeviceToHost,
                                 ctx->stream));
         ARVX_HIP(hipStreamSynchronize(ctx->stream));
-        if (!changed) break;
+        if (!changed[batch - 1]) break;
         if (launched >= max_launches) return fail(ARVX_ERR_HIP, "flood fill did not converge");
         if (round >= 1 && batch < 8) batch *= 2;
     }
