@@ -1723,8 +1723,13 @@ int arvx_fast_carve(arvx_ctx *ctx) {
     arvx::CarveParams g;
     carve_geometry(ctx, g);
     g.rec = ctx->d_rec;
-    hipLaunchKernelGGL(arvx::flood_open_from_rec_kernel, dim3((unsigned)((nwords + 255) / 256)),
-                       dim3(256), 0, ctx->stream, g, (const uint16_t *)ctx->d_flood_rec, fp);
+    // (both conversions: one workgroup per row of tiles, 64 rows x (tiles along x + 1) words
+    // of LDS, twice that for the way back)
+    const int chunk = std::min(arvx::kFloodChunk, fp.XW);
+    const size_t lds_words = (size_t)64 * (chunk + 1);
+    hipLaunchKernelGGL(arvx::flood_open_from_rec_kernel, dim3((unsigned)(g.tilesY * g.tilesZ)),
+                       dim3(256), lds_words * sizeof(unsigned long long), ctx->stream, g,
+                       (const uint16_t *)ctx->d_flood_rec, fp);
     ARVX_HIP(hipGetLastError());
     // whole-tile pre-pass (fast_carve_kernels.h): seeds every completely open tile
     // that is connected to the origin tile through completely open tiles
@@ -1767,9 +1772,9 @@ int arvx_fast_carve(arvx_ctx *ctx) {
         if (round >= 1 && batch < 8) batch *= 2;
     }
     {
-        const size_t ntiles = arvx::rec_count(g) / 4;
-        hipLaunchKernelGGL(arvx::flood_apply_rec_kernel, dim3((unsigned)((ntiles + 3) / 4)),
-                           dim3(256), 0, ctx->stream, g, fp, ntiles);
+        const unsigned rows = (unsigned)((g.coarseY << g.cyShift) * (g.coarseZ << g.czShift));
+        hipLaunchKernelGGL(arvx::flood_apply_rec_kernel, dim3(rows), dim3(256),
+                           2 * lds_words * sizeof(unsigned long long), ctx->stream, g, fp);
     }
     ARVX_HIP(hipGetLastError());
     ctx->fresh_pending = false;  // the records now hold every voxel's state

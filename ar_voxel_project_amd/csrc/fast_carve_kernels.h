@@ -41,32 +41,62 @@ struct FloodParams {
                 // flood_apply writes every voxel instead of the changed ones
 };
 
+// The bit planes of the flood fill are row-major (64 voxels of a row per word, XW words per
+// row); the records are tile-major (a tile = 64 x 8 x 8 voxels = four records; entry r of a
+// record = row (y & 7, z & 7) of the tile).  Both conversions below take one workgroup per ROW
+// OF TILES (all tiles with the same ty, tz) and go through LDS, so that each side is read and
+// written in whole lines: with lane = entry r on the record side (128 contiguous bytes per
+// access) and lane = tile along x on the plane side (a row's XW words are contiguous).
+// LDS: 64 rows x (chunk of up to 32 tiles + 1) words.
+constexpr int kFloodChunk = 32;  // tiles along x per pass (apply: 2 x 64 x 33 words = 33 KB of LDS)
+
+// the tile row's (ty, tz) and the records of its tile tx
+__device__ __forceinline__ void flood_tile_row(const CarveParams &g, int b, int &ty, int &tz) {
+    ty = b % g.tilesY;
+    tz = b / g.tilesY;
+}
+
 // open = carvable & !seen0 from the two sets of sub-tile records (arvx_device.h): `carv` is a
 // fresh model carved by all views -- a voxel is carvable where its occupancy bit is gone --,
-// `state` the model's own records (not read for a fresh model).  One thread per 64-bit word of
-// the bit plane = the same row of the four sub-tiles of one tile.  The thread of voxel
-// (0,0,0) plants the seed.
+// g.rec the model's own records (not read for a fresh model).  reach = 0, and the seed at
+// voxel (0,0,0) if it is open.
 __global__ __launch_bounds__(256) void flood_open_from_rec_kernel(const CarveParams g,
                                                                   const uint16_t *__restrict__ carv,
                                                                   const FloodParams p) {
-    const size_t n = (size_t)p.XW * p.Y * p.Z;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int xw = (int)(i % p.XW), y = (int)((i / p.XW) % p.Y), z = (int)(i / ((size_t)p.XW * p.Y));
-    const int r = (z & 7) * 8 + (y & 7);
-    const size_t rec0 = rec_index(g, xw, y >> 3, z >> 3, 0) * kRecU16;
-    unsigned long long w = 0;
+    extern __shared__ unsigned long long lds[];
+    int ty, tz;
+    flood_tile_row(g, blockIdx.x, ty, tz);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int tx0 = 0; tx0 < p.XW; tx0 += kFloodChunk) {
+        const int nt = min(kFloodChunk, p.XW - tx0), ld = nt + 1;
+        for (int t = wave; t < nt; t += 4) {  // lane = entry r of the tile's records
+            const int tx = tx0 + t;
+            const size_t rec0 = rec_index(g, tx, ty, tz, 0) * kRecU16;
+            unsigned long long w = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {  // the tile's four sub-tiles: 16 voxels each
-        if (64 * xw + 16 * k >= p.X) break;
-        unsigned long long o = (uint16_t)~carv[rec0 + k * kRecU16 + r];
-        if (!p.fresh) o &= (unsigned long long)(uint16_t)~g.rec[rec0 + k * kRecU16 + 64 + r];
-        w |= o << (16 * k);
+            for (int k = 0; k < 4; ++k) {  // the tile's four sub-tiles: 16 voxels each
+                if (64 * tx + 16 * k >= p.X) break;
+                unsigned long long o = (uint16_t)~carv[rec0 + k * kRecU16 + lane];
+                if (!p.fresh)
+                    o &= (unsigned long long)(uint16_t)~g.rec[rec0 + k * kRecU16 + 64 + lane];
+                w |= o << (16 * k);
+            }
+            const int nx = p.X - 64 * tx;  // voxels behind the end of the row: not open
+            if (nx < 64) w &= (1ull << nx) - 1ull;
+            lds[lane * ld + t] = w;
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 64 * nt; idx += 256) {  // threads along the rows
+            const int r = idx / nt, t = idx % nt;
+            const int y = ty * kTileY + (r & 7), z = tz * kTileZ + (r >> 3);
+            if (y >= p.Y || z >= p.Z) continue;
+            const size_t i = ((size_t)z * p.Y + y) * p.XW + tx0 + t;
+            const unsigned long long w = lds[r * ld + t];
+            p.open[i] = w;
+            p.reach[i] = (i == 0) ? (w & 1ull) : 0ull;
+        }
+        __syncthreads();
     }
-    const int nx = p.X - 64 * xw;  // voxels behind the end of the row: not open
-    if (nx < 64) w &= (1ull << nx) - 1ull;
-    p.open[i] = w;
-    p.reach[i] = (i == 0) ? (w & 1ull) : 0ull;
 }
 
 __device__ __forceinline__ unsigned long long fill_row(unsigned long long seed,
@@ -254,56 +284,75 @@ __global__ __launch_bounds__(256) void flood_step_kernel(const FloodParams p) {
     }
 }
 
-// occ &= !E ; seen |= E | N6(E) | origin, on the model's records.  One wave per tile (four
-// records), lane = entry r of the records = row (y & 7, z & 7) of the tile: the lane reads its
-// 64-bit word of the reach plane and the words around it, and the 16-bit entries of the four
-// sub-tiles are written lane by lane -- 128 contiguous bytes per store.  For a fresh model
-// nothing is read and EVERY record is written (padding as occ 0 / seen 1).
+// occ &= !E ; seen |= E | N6(E) | origin, on the model's records; one workgroup per row of
+// tiles as above: the reach plane is read row by row (the row itself and its four neighbours in
+// y and z, lane = tile along x), the records are written entry by entry.  For a fresh model
+// nothing is read from the records and EVERY record of the row is written (padding as occ 0 /
+// seen 1).  `nrows` = tile rows of the records (the grid's, padded to whole coarse tiles).
 __global__ __launch_bounds__(256) void flood_apply_rec_kernel(const CarveParams g,
-                                                              const FloodParams p, size_t ntiles) {
-    const size_t tile = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= ntiles) return;
-    const int r = threadIdx.x & 63;
-    // tile index in record order -> tile coordinates (inverse of rec_index)
-    const int tshift = g.cyShift + g.czShift;
-    const int tl = (int)(tile & ((1u << tshift) - 1)), ct = (int)(tile >> tshift);
-    const int tx = ct % g.coarseX;
-    const int ty = (((ct / g.coarseX) % g.coarseY) << g.cyShift) + (tl & ((1 << g.cyShift) - 1));
-    const int tz = ((ct / (g.coarseX * g.coarseY)) << g.czShift) + (tl >> g.cyShift);
-    const int y = ty * kTileY + (r & 7), z = tz * kTileZ + (r >> 3);
-    uint16_t *rec = g.rec + (tile << 2) * kRecU16;
-    unsigned long long e = 0, nb = 0, in = 0;
-    if (y < p.Y && z < p.Z && tx < p.XW) {
-        const int nx = p.X - 64 * tx;
-        in = nx >= 64 ? ~0ull : ((1ull << nx) - 1ull);
-        const size_t row = (size_t)z * p.Y + y;
-        const unsigned long long *c = p.reach + row * p.XW + tx;
-        e = c[0];
-        nb = (e << 1) | (e >> 1);
-        if (tx > 0) nb |= c[-1] >> 63;
-        if (tx + 1 < p.XW) nb |= c[1] << 63;
-        if (y > 0) nb |= c[-(ptrdiff_t)p.XW];
-        if (y + 1 < p.Y) nb |= c[p.XW];
-        if (z > 0) nb |= c[-(ptrdiff_t)p.XW * p.Y];
-        if (z + 1 < p.Z) nb |= c[(ptrdiff_t)p.XW * p.Y];
-        if (row == 0 && tx == 0) nb |= 1ull;  // the seed is visited whatever happens (:100)
-    }
-    // carved (:125, :108) or pushed by a carved neighbour (:132-163)
-    const unsigned long long visited = (e | nb) & in;
-    if (!p.fresh && __builtin_amdgcn_readfirstlane(__ballot(visited != 0) == 0)) return;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {  // the tile's four sub-tiles: 16 voxels each
-        const uint32_t e16 = (uint32_t)(e >> (16 * k)) & 0xffffu;
-        const uint32_t v16 = (uint32_t)(visited >> (16 * k)) & 0xffffu;
-        const uint32_t in16 = (uint32_t)(in >> (16 * k)) & 0xffffu;
-        uint16_t *o = rec + k * kRecU16 + r, *sn = o + 64;
-        if (p.fresh) {
-            *o = (uint16_t)(in16 & ~e16);
-            *sn = (uint16_t)((~in16 & 0xffffu) | v16);
-        } else if (v16) {
-            if (e16) *o = (uint16_t)(*o & ~e16);
-            *sn = (uint16_t)(*sn | v16);
+                                                              const FloodParams p) {
+    extern __shared__ unsigned long long lds[];
+    // tile rows in the order of the coarse padding: (ty, tz) over the padded extent
+    const int padY = g.coarseY << g.cyShift;
+    const int ty = blockIdx.x % padY, tz = blockIdx.x / padY;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int padX = g.coarseX;  // tiles along x in the records (= XW)
+    for (int tx0 = 0; tx0 < padX; tx0 += kFloodChunk) {
+        const int nt = min(kFloodChunk, padX - tx0), ld = nt + 1;
+        unsigned long long *e_s = lds, *v_s = lds + 64 * ld;
+        for (int idx = threadIdx.x; idx < 64 * nt; idx += 256) {  // threads along the rows
+            const int r = idx / nt, t = idx % nt;
+            const int y = ty * kTileY + (r & 7), z = tz * kTileZ + (r >> 3);
+            const int tx = tx0 + t;
+            unsigned long long e = 0, vis = 0;
+            if (y < p.Y && z < p.Z && tx < p.XW) {
+                const size_t row = (size_t)z * p.Y + y;
+                const unsigned long long *c = p.reach + row * p.XW + tx;
+                e = c[0];
+                unsigned long long nb = (e << 1) | (e >> 1);
+                if (tx > 0) nb |= c[-1] >> 63;
+                if (tx + 1 < p.XW) nb |= c[1] << 63;
+                if (y > 0) nb |= c[-(ptrdiff_t)p.XW];
+                if (y + 1 < p.Y) nb |= c[p.XW];
+                if (z > 0) nb |= c[-(ptrdiff_t)p.XW * p.Y];
+                if (z + 1 < p.Z) nb |= c[(ptrdiff_t)p.XW * p.Y];
+                if (row == 0 && tx == 0) nb |= 1ull;  // the seed is visited anyway (:100)
+                const int nx = p.X - 64 * tx;
+                const unsigned long long in = nx >= 64 ? ~0ull : ((1ull << nx) - 1ull);
+                // carved (:125, :108) or pushed by a carved neighbour (:132-163)
+                vis = (e | nb) & in;
+            }
+            e_s[r * ld + t] = e;
+            v_s[r * ld + t] = vis;
         }
+        __syncthreads();
+        for (int t = wave; t < nt; t += 4) {  // lane = entry r of the tile's records
+            const int tx = tx0 + t;
+            const unsigned long long e = e_s[lane * ld + t], vis = v_s[lane * ld + t];
+            if (!p.fresh && __ballot(vis != 0) == 0) continue;
+            const int y = ty * kTileY + (lane & 7), z = tz * kTileZ + (lane >> 3);
+            unsigned long long in = 0;
+            if (y < p.Y && z < p.Z && tx < p.XW) {
+                const int nx = p.X - 64 * tx;
+                in = nx >= 64 ? ~0ull : ((1ull << nx) - 1ull);
+            }
+            uint16_t *rec = g.rec + rec_index(g, tx, ty, tz, 0) * kRecU16;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // the tile's four sub-tiles: 16 voxels each
+                const uint32_t e16 = (uint32_t)(e >> (16 * k)) & 0xffffu;
+                const uint32_t v16 = (uint32_t)(vis >> (16 * k)) & 0xffffu;
+                const uint32_t in16 = (uint32_t)(in >> (16 * k)) & 0xffffu;
+                uint16_t *o = rec + k * kRecU16 + lane, *sn = o + 64;
+                if (p.fresh) {
+                    *o = (uint16_t)(in16 & ~e16);
+                    *sn = (uint16_t)((~in16 & 0xffffu) | v16);
+                } else if (v16) {
+                    if (e16) *o = (uint16_t)(*o & ~e16);
+                    *sn = (uint16_t)(*sn | v16);
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
