@@ -305,12 +305,10 @@ static int views_common(Ctx *ctx, int V, const float *M, const float *campos, in
     // one word more than the pixels need: bit 32 * (bgWords - 1) is a background bit that is
     // always 0, which the block-mapped exact kernel reads for voxels outside the image
     ctx->bgWords = (int)(((size_t)W * H + 31) / 32) + 1;
-    // foreground counts per block of (1 << satShift)^2 pixels (views_kernels.h); 0 = per pixel
-    static const int shift_env = getenv("ARVX_SAT_SHIFT") ? atoi(getenv("ARVX_SAT_SHIFT")) : 0;
-    ctx->satShift = shift_env < 0 ? 0 : (shift_env > 3 ? 3 : shift_env);
-    const int blk = 1 << ctx->satShift;
-    ctx->satW = (W + blk - 1) / blk + 1;
-    ctx->satH = (H + blk - 1) / blk + 1;
+    // summed-area table (views_kernels.h): (H + 1) rows of W + 1 entries, the rows padded to
+    // whole 128-byte lines so that the table kernel's stores are line-aligned
+    ctx->satW = (W + 1 + 31) / 32 * 32;
+    ctx->satH = H + 1;
     ctx->satStride = ctx->satW * ctx->satH;
     if (!same) {
         hipError_t e = hipMalloc(&ctx->d_M, (size_t)V * 12 * sizeof(float));
@@ -368,35 +366,17 @@ static int views_preprocess(Ctx *ctx, const uint8_t *d_masks, int C) {
                            C, npix, ctx->d_bg, ctx->bgWords);
     }
     ARVX_HIP(hipGetLastError());
-    if (ctx->satShift == 0) {  // per-pixel table: written in one pass (views_kernels.h)
-        const int W = ctx->W, H = ctx->H, V = ctx->V;
-        const int TJ = (W + 63) / 64, TI = (H + arvx::kTileRows - 1) / arvx::kTileRows;
-        const size_t n_rs = (size_t)V * H * TJ, n_T = (size_t)V * TI * W, n_ts = (size_t)V * TI * TJ;
-        if (int rc = ensure_scratch(ctx, (n_rs + n_T + n_ts) * sizeof(int) + 64)) return rc;
-        int *d_rs = (int *)ctx->d_scratch, *d_T = d_rs + n_rs, *d_ts = d_T + n_T;
-        hipLaunchKernelGGL(arvx::views_tile_sums_kernel, dim3(TJ, TI, V), dim3(64), 0, ctx->stream,
-                           ctx->d_bg, ctx->bgWords, W, H, TJ, TI, d_rs, d_T, d_ts);
-        hipLaunchKernelGGL(arvx::views_table_kernel, dim3(TJ, TI, V), dim3(64), 0, ctx->stream,
-                           ctx->d_bg, ctx->bgWords, W, H, TJ, TI, d_rs, d_T, d_ts, ctx->d_sat,
-                           ctx->satStride);
-        ARVX_HIP(hipGetLastError());
-        ctx->views_ready = true;
-        ctx->cameras_ready = true;
-        return ARVX_OK;
-    }
-    const int Hs = ctx->satH - 1;  // block rows
-    hipLaunchKernelGGL(arvx::views_rows_kernel, dim3(Hs, ctx->V), dim3(64), 0, ctx->stream,
-                       ctx->d_bg, ctx->bgWords, ctx->W, ctx->H, ctx->satShift, ctx->d_sat,
+    const int W = ctx->W, H = ctx->H, V = ctx->V;
+    // tiles of 64 table columns x 64 image rows (views_kernels.h)
+    const int TJ = (W + 1 + 63) / 64, TI = (H + arvx::kTileRows - 1) / arvx::kTileRows;
+    const size_t n_rs = (size_t)V * H * TJ, n_T = (size_t)V * TI * TJ * 64, n_ts = (size_t)V * TI * TJ;
+    if (int rc = ensure_scratch(ctx, (n_rs + n_T + n_ts) * sizeof(int) + 64)) return rc;
+    int *d_rs = (int *)ctx->d_scratch, *d_T = d_rs + n_rs, *d_ts = d_T + n_T;
+    hipLaunchKernelGGL(arvx::views_tile_sums_kernel, dim3(TJ, TI, V), dim3(64), 0, ctx->stream,
+                       ctx->d_bg, ctx->bgWords, W, H, TJ, TI, d_rs, d_T, d_ts);
+    hipLaunchKernelGGL(arvx::views_table_kernel, dim3(TJ, TI, V), dim3(64), 0, ctx->stream,
+                       ctx->d_bg, ctx->bgWords, W, H, TJ, TI, d_rs, d_T, d_ts, ctx->d_sat,
                        ctx->satStride, ctx->satW);
-    ARVX_HIP(hipGetLastError());
-    const dim3 gc((ctx->satW + arvx::kColsPerWg - 1) / arvx::kColsPerWg, ctx->V);
-    const dim3 bc(arvx::kColsPerWg * arvx::kColGroups);
-    if (Hs <= 16 * arvx::kColGroups)
-        hipLaunchKernelGGL(arvx::views_cols_kernel<false>, gc, bc, 0, ctx->stream, ctx->satW, Hs,
-                           ctx->d_sat, ctx->satStride);
-    else
-        hipLaunchKernelGGL(arvx::views_cols_kernel<true>, gc, bc, 0, ctx->stream, ctx->satW, Hs,
-                           ctx->d_sat, ctx->satStride);
     ARVX_HIP(hipGetLastError());
     ctx->views_ready = true;
     ctx->cameras_ready = true;
@@ -917,7 +897,6 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
     p.H = ctx->H;
     p.bgWords = ctx->bgWords;
     p.satStride = ctx->satStride;
-    p.satShift = ctx->satShift;
     p.satW = ctx->satW;
     p.v0 = first;
     p.v1 = first + count;

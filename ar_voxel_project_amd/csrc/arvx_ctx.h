@@ -85,7 +85,7 @@ struct Ctx {
     bool has_campos = false;
     int V = 0, W = 0, H = 0;
     int bgWords = 0, satStride = 0;
-    int satShift = 1, satW = 0, satH = 0;  // table of (1 << satShift)^2-pixel blocks: satH x satW entries
+    int satW = 0, satH = 0;  // summed-area table: satH = H + 1 rows of satW >= W + 1 entries
     float *d_M = nullptr;
     float *d_campos = nullptr;
     uint32_t *d_bg = nullptr;

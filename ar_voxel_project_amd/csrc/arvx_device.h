@@ -55,7 +55,7 @@ struct CarveParams {
     float s;                // voxel edge
     int W, H;
     int bgWords, satStride;
-    int satShift, satW;     // table per block of (1 << satShift)^2 pixels, satW entries per row
+    int satW;               // entries per row of a view's table (>= W + 1, padded to whole lines)
     int v0, v1;             // view range [v0, v1)
     unsigned flags;         // bit0 no cull, bit1 stats, bit2 state is fresh (skip the load),
                             // bit3 the exact kernel may split items between waves

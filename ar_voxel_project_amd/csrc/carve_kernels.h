@@ -65,10 +65,10 @@ __device__ __forceinline__ BoxW make_box(float s, int x0, int x1, int y0, int y1
 // plus the roundings of the exact path's divide (1u|u|), of rcp+mul here (<3u|u|)
 // and of the bound arithmetic below (<2u|u|): 2^-20|u| = 16u|u| and an absolute
 // 2^-12 cover them.  roundf(t) lies in [t-0.5, t+0.5].
-// sat: the view's table of foreground counts per block of (1 << satShift)^2 pixels, satW
-// entries per row (views_kernels.h); the pixel rectangle is rounded outwards to whole blocks.
+// sat: the view's summed-area table of foreground pixels, satW entries per row
+// (views_kernels.h): entry (Y, X) = foreground pixels in rows < Y, columns < X.
 __device__ inline int classify_box(const float *__restrict__ M, const BoxW b, int W, int H,
-                                   const int *__restrict__ sat, int satShift, int satW) {
+                                   const int *__restrict__ sat, int satW) {
     const float dy = b.wy1 - b.wy0, dx = b.wx1 - b.wx0, dz = b.wz1 - b.wz0;
     const float ay = fmaxf(fabsf(b.wy0), fabsf(b.wy1));
     const float ax = fmaxf(fabsf(b.wx0), fabsf(b.wx1));
@@ -124,15 +124,12 @@ __device__ inline int classify_box(const float *__restrict__ M, const BoxW b, in
     const int pyhi = (int)floorf(vmax + mv + 0.5f);
     if (pxhi < 0 || pxlo >= W || pyhi < 0 || pylo >= H) return kClsOut;
     if (pxlo < 0 || pxhi >= W || pylo < 0 || pyhi >= H) return kClsMixed | fast;
-    const int X0 = pxlo >> satShift, X1 = (pxhi >> satShift) + 1;
-    const int Y0 = pylo >> satShift, Y1 = (pyhi >> satShift) + 1;
+    const int X0 = pxlo, X1 = pxhi + 1;
+    const int Y0 = pylo, Y1 = pyhi + 1;
     const int cnt = sat[Y1 * satW + X1] - sat[Y0 * satW + X1] - sat[Y1 * satW + X0] +
                     sat[Y0 * satW + X0];
-    if (cnt == 0) return kClsCarved;  // no foreground in the enlarged rectangle, so none inside
-    // pixels of the enlarged rectangle that exist (the last block may overhang the image)
-    const int area = (min(X1 << satShift, W) - (X0 << satShift)) *
-                     (min(Y1 << satShift, H) - (Y0 << satShift));
-    return (cnt == area) ? kClsFg : (kClsMixed | fast);
+    if (cnt == 0) return kClsCarved;  // no foreground in the rectangle
+    return (cnt == (X1 - X0) * (Y1 - Y0)) ? kClsFg : (kClsMixed | fast);
 }
 
 // Pre-pass over coarse tiles of 64 x 32 x 32 voxels (64 sub-tiles each; striped
@@ -173,7 +170,7 @@ __device__ __forceinline__ int coarse_classify(const CarveParams &p, const int c
         int cls = kClsOut;
         if (myv < p.v1)
             cls = classify_box(p.M + 12 * myv, box, p.W, p.H, p.sat + (size_t)myv * p.satStride,
-                               p.satShift, p.satW) &
+                               p.satW) &
                   3;
         const unsigned long long carved = __ballot(cls == kClsCarved);
         const unsigned long long mixed = __ballot(cls == kClsMixed);
@@ -497,7 +494,7 @@ __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p
                     cls = kClsFg;  // inherited: the coarse rectangle contains this one
                 else if ((cm >> lane) & 1ull)
                     cls = classify_box(p.M + 12 * myv, box, p.W, p.H,
-                                       p.sat + (size_t)myv * p.satStride, p.satShift, p.satW);
+                                       p.sat + (size_t)myv * p.satStride, p.satW);
             }
         }
         const unsigned long long fastdiv = __ballot((cls & kFastDiv) != 0);
@@ -686,7 +683,7 @@ __global__ __launch_bounds__(256, 8) void carve_classify_kernel(const CarveParam
                     cls = kClsFg;  // inherited: the coarse rectangle contains this one
                 else if (sel & 2u)
                     cls = classify_box(Mr, box, p.W, p.H, p.sat + (size_t)myv * p.satStride,
-                                       p.satShift, p.satW);
+                                       p.satW);
             }
             fast_c[chunk] = __ballot((cls & kFastDiv) != 0);
             cls &= 3;
@@ -1216,7 +1213,7 @@ __device__ __forceinline__ unsigned block_tests(const CarveParams &p, const SubT
         if (q < n && inside) {
             const int view = vbase + myb;
             cls = classify_box(p.M + 12 * view, box, p.W, p.H, p.sat + (size_t)view * p.satStride,
-                               p.satShift, p.satW) & 3;
+                               p.satW) & 3;
         }
         const unsigned long long c = __ballot(cls == kClsCarved), f = __ballot(cls == kClsFg),
                                  x = __ballot(cls == kClsMixed);

@@ -3,20 +3,15 @@
 // src/VoxelCarving.cpp:49-50) and the summed-area table of FOREGROUND pixels that the
 // rectangle tests of the carve kernels query.
 //
-// Per pixel by default (satShift = 0): three launches for all views (below: "summed-area
-// table, per pixel") --
+// Three launches for all views (below: "summed-area table") --
 //   views_bits_kernel        mask bytes -> background bits, four pixels per lane
 //   views_tile_sums_kernel   per-tile row and column sums from the bit plane (small arrays)
 //   views_table_kernel       the table, written once: per row a popcount, two adds, a store
 // (Round 1: memset + mask_to_bits + sat_rows + sat_cols, 79 us for 36 views of 640 x 480: the
-// row pass wrote the table, the column pass read and rewrote it -- 132 MB for a 44 MB table.)
-//
-// ARVX_SAT_SHIFT=s keeps the table per BLOCK of b x b pixels (b = 1 << s) instead: entry
-// (Y, X) counts the foreground of image rows < b Y and columns < b X, and a rectangle test
-// rounds its rectangle outwards to whole blocks (classify_box) -- conservative, b^2 times
-// smaller and cheaper to derive, but the one-pixel rim of extra "mixed" answers costs the
-// exact kernel more than the derivation saves (s = 1: 512^3 exact +11 %, 1024^3 +29 %; kept
-// for A/B runs; views_rows_kernel + views_cols_kernel build it).
+// row pass wrote the table, the column pass read and rewrote it -- 132 MB for a 44 MB table.
+// Tried and dropped in round 2: a table per BLOCK of 2 x 2 pixels, rectangles rounded outwards
+// -- four times smaller and cheaper to derive, but the one-pixel rim of extra "mixed" answers
+// cost the exact kernel more than the derivation saved: 512^3 exact +11 %, 1024^3 +29 %.)
 #pragma once
 
 #include "arvx_device.h"
@@ -115,32 +110,38 @@ __global__ __launch_bounds__(256) void views_bits_generic_kernel(const uint8_t *
     }
 }
 
-// ---- summed-area table, per pixel (satShift == 0), in one pass over the output --------------
+// ---- summed-area table, in one pass over the output ------------------------------------------
 //
-// table[y + 1][x + 1] = sum of fg over rows <= y, columns <= x.  With the image cut into tiles
-// of 64 columns x 64 rows (tile (I, J)):
-//   table[y + 1][x + 1] = LT(I, J) + Lin(y, J) + A(I, x) + sum over the tile's rows y' <= y of
-//                         inrow(y', x)
-//   inrow(y', x) = fg pixels of row y' in columns 64 J .. x        (popcount below the lane)
-//   Lin(y, J)    = fg pixels of the tile's rows <= y in the columns left of tile column J
-//   LT(I, J)     = fg pixels above tile row I and left of tile column J
-//   A(I, x)      = fg pixels of the rows above tile row I in columns 64 J .. x
+// table[Y][X] = foreground pixels in rows < Y, columns < X, for Y <= H, X <= W; ld (>= W + 1,
+// a multiple of 32) entries per row, so that every row starts on a 128-byte line.  The table is
+// cut into tiles of 64 COLUMNS OF THE TABLE x 64 image rows: tile (I, J) holds the entries
+// X = 64 J + lane of the rows Y = 64 I + r + 1 -- whole lines -- and entry X counts the pixel
+// columns up to x = X - 1: the tile's "columns" c = 0..63 are the pixel columns 64 J - 1 + c
+// (column -1 does not exist: no foreground).  With fgc(y, c) = foreground of pixel row y in
+// the tile's column c:
+//   table[y + 1][64 J + c] = LT(I, J) + Lin(y, J) + A(I, J, c) + sum over the tile's rows
+//                            y' <= y of inrow(y', c)
+//   inrow(y', c) = fg of row y' in the tile's columns <= c          (popcount up to the lane)
+//   Lin(y, J)    = fg of the tile's rows <= y in the tile columns left of J
+//   LT(I, J)     = fg above tile row I and left of tile column J
+//   A(I, J, c)   = fg of the rows above tile row I in the tile's columns <= c
 // views_tile_sums_kernel takes three small arrays from the bit plane (per row and tile column
-// the row's count, per tile row and column x the running count along x, per tile its total);
-// views_table_kernel sums what it needs of them (a few independent loads per lane) and writes
-// the table: per row two scalar reads of the row's bits, a popcount, two adds and the store.
-// The 4 (W+1)(H+1) bytes per view are written once and never read back.  In both kernels lane
-// r first LOADS row r's 64 bits (one round trip for the whole tile) and the rows are then
-// taken from the lanes one by one.
+// the row's count, per tile row and tile column c the running count along c, per tile its
+// total); views_table_kernel sums what it needs of them (a few independent loads per lane) and
+// writes the table: per row two scalar reads of the row's bits, a popcount, two adds and the
+// store.  The table's bytes are written once and never read back.  In both kernels lane r
+// first LOADS row r's 64 bits (one round trip for the whole tile) and the rows are then taken
+// from the lanes one by one.
 #ifndef ARVX_TILE_ROWS
 #define ARVX_TILE_ROWS 64
 #endif
 constexpr int kTileRows = ARVX_TILE_ROWS;
 
-// 64 foreground bits of row y starting at column x0 (bit j = pixel x0 + j; 0 outside the image)
+// 64 foreground bits of row y starting at pixel column x0 >= 0 (bit j = pixel x0 + j; 0
+// outside the image)
 __device__ __forceinline__ unsigned long long row_fg64(const uint32_t *__restrict__ bits,
                                                        int bgWords, int W, int H, int y, int x0) {
-    if (y >= H) return 0ull;
+    if (y >= H || x0 >= W) return 0ull;
     const long long pos = (long long)y * W + x0;
     const int w = (int)(pos >> 5), sh = (int)(pos & 31);
     const int last = bgWords - 1;  // the always-zero word
@@ -153,14 +154,21 @@ __device__ __forceinline__ unsigned long long row_fg64(const uint32_t *__restric
     return ~bg & valid;
 }
 
+// the tile's 64 columns of row y: bit c = foreground of pixel column 64 J - 1 + c
+__device__ __forceinline__ unsigned long long tile_row_fg(const uint32_t *__restrict__ bits,
+                                                          int bgWords, int W, int H, int y, int J) {
+    if (J == 0) return row_fg64(bits, bgWords, W, H, y, 0) << 1;  // (column -1: nothing)
+    return row_fg64(bits, bgWords, W, H, y, 64 * J - 1);
+}
+
 __device__ __forceinline__ unsigned long long lane_value64(unsigned long long v, int srcLane) {
     const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, srcLane);
     const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), srcLane);
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// one wave per tile: rowsum[v][y][J] = fg of row y inside tile column J; T[v][I][x] = fg of
-// tile row I in columns 64 J .. x; tilesum[v][I][J] = fg of the tile
+// one wave per tile: rowsum[v][y][J] = fg of row y inside tile column J; T[v][I][J][c] = fg of
+// tile row I in the tile's columns <= c; tilesum[v][I][J] = fg of the tile
 __global__ __launch_bounds__(64) void views_tile_sums_kernel(const uint32_t *__restrict__ bg,
                                                              int bgWords, int W, int H, int TJ,
                                                              int TI, int *__restrict__ rowsum,
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(64) void views_tile_sums_kernel(const uint32_t *__r
     const int J = blockIdx.x, I = blockIdx.y, v = blockIdx.z, lane = threadIdx.x;
     const uint32_t *bits = bg + (size_t)v * bgWords;
     const int yr = I * kTileRows + lane;
-    const unsigned long long mine = row_fg64(bits, bgWords, W, H, yr, 64 * J);  // row `lane`
+    const unsigned long long mine = tile_row_fg(bits, bgWords, W, H, yr, J);  // row `lane`
     if (yr < H) rowsum[((size_t)v * H + yr) * TJ + J] = __popcll(mine);
     int col = 0;
 #pragma unroll
@@ -180,27 +188,23 @@ __global__ __launch_bounds__(64) void views_tile_sums_kernel(const uint32_t *__r
         const int t = __shfl_up(sc, d);
         if (lane >= d) sc += t;
     }
-    const int x = 64 * J + lane;
-    if (x < W) T[((size_t)v * TI + I) * W + x] = sc;
+    T[(((size_t)v * TI + I) * TJ + J) * 64 + lane] = sc;
     if (lane == 63) tilesum[((size_t)v * TI + I) * TJ + J] = sc;
 }
 
-// (Tried and dropped: bit planes and tile sums in one launch for one-channel masks -- lane r
-// reading the 64 mask BYTES of its row of the tile: the strided 64-byte reads cost more than the
-// launch saves, step +1.5 us at 36 views of 640 x 480.)
 // one wave per tile: the table entries of its 64 columns x 64 rows
 __global__ __launch_bounds__(64) void views_table_kernel(const uint32_t *__restrict__ bg,
                                                          int bgWords, int W, int H, int TJ, int TI,
                                                          const int *__restrict__ rowsum,
                                                          const int *__restrict__ T,
                                                          const int *__restrict__ tilesum,
-                                                         int *__restrict__ sat, int satStride) {
+                                                         int *__restrict__ sat, int satStride,
+                                                         int ld) {
     const int J = blockIdx.x, I = blockIdx.y, v = blockIdx.z, lane = threadIdx.x;
     const uint32_t *bits = bg + (size_t)v * bgWords;
     int *tab = sat + (size_t)v * satStride;
-    const int x = 64 * J + lane, yr = I * kTileRows + lane;
-    const size_t ld = (size_t)W + 1;
-    const unsigned long long mine = row_fg64(bits, bgWords, W, H, yr, 64 * J);  // row `lane`
+    const int X = 64 * J + lane, yr = I * kTileRows + lane;  // X: this lane's table column
+    const unsigned long long mine = tile_row_fg(bits, bgWords, W, H, yr, J);  // row `lane`
     // Lin: running sum over this tile's rows of the row sums of the tile columns to the left
     int left = 0;
     if (yr < H)
@@ -210,8 +214,7 @@ __global__ __launch_bounds__(64) void views_table_kernel(const uint32_t *__restr
     for (int e = lane; e < I * J; e += 64) lt += tilesum[((size_t)v * TI + e / J) * TJ + e % J];
     // A: the tile rows above, this lane's column
     int acc = 0;
-    if (x < W)
-        for (int k = 0; k < I; ++k) acc += T[((size_t)v * TI + k) * W + x];
+    for (int k = 0; k < I; ++k) acc += T[(((size_t)v * TI + k) * TJ + J) * 64 + lane];
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const int t = __shfl_up(left, d);
@@ -219,11 +222,7 @@ __global__ __launch_bounds__(64) void views_table_kernel(const uint32_t *__restr
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) lt += __shfl_xor(lt, d);
-    if (I == 0) {  // row 0 of the table
-        if (x < W) tab[x + 1] = 0;
-        if (J == 0 && lane == 0) tab[0] = 0;
-    }
-    if (J == 0 && yr < H) tab[(size_t)(yr + 1) * ld] = 0;  // column 0
+    if (I == 0 && X <= W) tab[X] = 0;  // row 0 of the table
     const int nrows = min(kTileRows, H - I * kTileRows);
     acc += lt;
     for (int r = 0; r < nrows; ++r) {
@@ -232,101 +231,7 @@ __global__ __launch_bounds__(64) void views_table_kernel(const uint32_t *__restr
                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)fg, 0u));
         acc += below + (int)((fg >> lane) & 1ull);
         const int lin = __builtin_amdgcn_readlane(left, r);
-        if (x < W) tab[(size_t)(I * kTileRows + r + 1) * ld + x + 1] = acc + lin;
-    }
-}
-
-// Block row Y of the table: entry (Y + 1, X + 1) = foreground pixels of the block row's
-// columns < b (X + 1) -- the column pass turns that into the sum over all rows above.
-__global__ __launch_bounds__(64) void views_rows_kernel(const uint32_t *__restrict__ bg,
-                                                        int bgWords, int W, int H, int shift,
-                                                        int *__restrict__ sat, int satStride,
-                                                        int satW) {
-    const int v = blockIdx.y, Y = blockIdx.x, lane = threadIdx.x;
-    const int b = 1 << shift;
-    const uint32_t *bits = bg + (size_t)v * bgWords;
-    int *out = sat + (size_t)v * satStride + (size_t)(Y + 1) * satW;
-    if (lane == 0) out[0] = 0;
-    int carry = 0;
-    for (int X0 = 0; X0 < satW - 1; X0 += 64) {
-        const int X = X0 + lane;
-        int cnt = 0;
-        if (X < satW - 1) {
-            for (int dy = 0; dy < b; ++dy) {
-                const int y = (Y << shift) + dy;
-                if (y >= H) break;
-                for (int dx = 0; dx < b; ++dx) {
-                    const int x = (X << shift) + dx;
-                    if (x >= W) break;
-                    const int pix = y * W + x;
-                    cnt += 1 - (int)((bits[pix >> 5] >> (pix & 31)) & 1u);
-                }
-            }
-        }
-        int sc = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(sc, d);
-            if (lane >= d) sc += t;
-        }
-        if (X < satW - 1) out[X + 1] = carry + sc;
-        carry += __shfl(sc, 63);
-    }
-}
-
-// Column sums over the table's rows 1 .. Hs (Hs = block rows), row 0 = zeros.
-constexpr int kColGroups = 32, kColsPerWg = 16;
-
-template <bool kTall>
-__global__ __launch_bounds__(kColsPerWg * kColGroups) void views_cols_kernel(int satW, int Hs,
-                                                                             int *__restrict__ sat,
-                                                                             int satStride) {
-    __shared__ int part[kColGroups][kColsPerWg];
-    const int v = blockIdx.y;
-    const int c = threadIdx.x % kColsPerWg, g = threadIdx.x / kColsPerWg;
-    const int col = blockIdx.x * kColsPerWg + c;  // 0 .. satW - 1
-    const int R = (Hs + kColGroups - 1) / kColGroups;  // rows per group (<= 16 unless kTall)
-    const int r0 = 1 + g * R, r1 = min(Hs + 1, r0 + R);  // table rows [r0, r1)
-    const bool ok = col < satW;
-    const size_t ld = (size_t)satW;
-    int *s = sat + (size_t)v * satStride + (ok ? col : 0);
-    int t[16];
-    int sum = 0;
-    if (!kTall) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t[k] = (ok && r0 + k < r1) ? s[(size_t)(r0 + k) * ld] : 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) sum += t[k];
-    } else {
-        for (int y0 = r0; y0 < r1; y0 += 16) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) t[k] = (ok && y0 + k < r1) ? s[(size_t)(y0 + k) * ld] : 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) sum += t[k];
-        }
-    }
-    part[g][c] = sum;
-    __syncthreads();
-    int acc = 0;
-    for (int k = 0; k < g; ++k) acc += part[k][c];
-    if (!ok) return;
-    if (g == 0) s[0] = 0;
-    if (!kTall) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            acc += t[k];
-            if (r0 + k < r1) s[(size_t)(r0 + k) * ld] = acc;
-        }
-    } else {
-        for (int y0 = r0; y0 < r1; y0 += 16) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) t[k] = (y0 + k < r1) ? s[(size_t)(y0 + k) * ld] : 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                acc += t[k];
-                if (y0 + k < r1) s[(size_t)(y0 + k) * ld] = acc;
-            }
-        }
+        if (X <= W) tab[(size_t)(I * kTileRows + r + 1) * ld + X] = acc + lin;
     }
 }
 
