@@ -526,14 +526,14 @@ def test_fuzz_against_oracle(arvx, oracle):
 
 @pytest.mark.parametrize("W,H,C", [(64, 3, 1), (128, 50, 3), (192, 117, 1), (640, 480, 3),
                                    (96, 64, 3), (65, 64, 1), (64, 600, 1), (130, 129, 4),
-                                   (96, 70, 1), (70, 33, 1)])
+                                   (96, 70, 1), (70, 33, 1), (63, 40, 1), (127, 70, 3)])
 def test_view_preprocessing_paths(arvx, oracle, W, H, C):
     """Bit planes and summed-area tables (csrc/views_kernels.h) for image widths that are and
     are not multiples of 64 (tile columns of the table kernels), heights above and below one
     tile row, 1 and 3 channels (one channel with W x H % 32 == 0: views_bits16_kernel; else
     views_bits_kernel): checked through the carve they drive, from host masks and from
-    masks already on the device (re-derived twice).  (ARVX_SAT_SHIFT=1,2 runs the same tests
-    on the per-block tables.)"""
+    masks already on the device (re-derived twice).  W = 63, 64, 127: the last table column
+    (X = W) alone in a tile, in the first tile, at a tile's end."""
     import torch
     N, V = 40, 5
     s = np.float32(0.512 / N)
