@@ -164,7 +164,6 @@ def main():
         zlo, zhi = sharding.slab_of(Z, world, rank)
         nvox_global = X * Y * Z
         flags = capi.CARVE_NO_CULL if (args.no_cull or no_cull) else 0
-        # allreduce: striped (load-balanced) slabs; allgather needs contiguous ones
         # striped (load-balanced) slabs wherever the collective can place scattered words;
         # the plain all-gather needs contiguous ones
         layout = "striped" if (world > 1 and collective != "allgather") else "slab"
@@ -237,14 +236,16 @@ def main():
         gc.disable()
         barrier()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step(i)
-        drain()
-        barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        gc.enable()
+        try:
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(i)
+            drain()
+            barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            gc.enable()
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
