@@ -10,8 +10,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "arvx_ctx.h"
@@ -58,6 +60,38 @@ using arvx::Ctx;
         if (!(ctx)) return fail(ARVX_ERR_INVALID, "null context");   \
         ARVX_HIP(hipSetDevice((ctx)->device));                       \
     } while (0)
+
+// ---- streams ----------------------------------------------------------------------------
+// hipStreamCreate / hipStreamDestroy cost 1.4 - 2.2 ms each on this stack (rocprofv3
+// --hip-trace of tools/cpp/arvx_bench6: more than the whole carve of its largest model), and a
+// drop-in caller makes a context per Model (src/main.cpp:306-440 builds eight in a row): the
+// streams of destroyed contexts are kept per device and handed to the next context.
+namespace {
+std::mutex g_stream_mutex;
+std::vector<std::pair<int, hipStream_t>> g_idle_streams;  // (device, stream), idle and drained
+
+hipError_t acquire_stream(int device, hipStream_t *out) {
+    {
+        std::lock_guard<std::mutex> lock(g_stream_mutex);
+        for (size_t i = 0; i < g_idle_streams.size(); ++i)
+            if (g_idle_streams[i].first == device) {
+                *out = g_idle_streams[i].second;
+                g_idle_streams.erase(g_idle_streams.begin() + i);
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void release_stream(int device, hipStream_t s) {  // s: synchronised by the caller
+    std::lock_guard<std::mutex> lock(g_stream_mutex);
+    if (g_idle_streams.size() < 64) {
+        g_idle_streams.emplace_back(device, s);
+        return;
+    }
+    (void)hipStreamDestroy(s);
+}
+}  // namespace
 
 // ---- bit-plane helpers (bitplane_kernels.h) ----------------------------------------------
 
@@ -193,7 +227,7 @@ int arvx_ctx_create_slab(arvx_ctx **out, int device, int X, int Y, int Z, float 
     c->ze1 = z_end < Z ? z_end + 1 : Z;
     c->nvox = (size_t)X * Y * (size_t)(z_end - z_begin);
     c->nvox_ext = (size_t)X * Y * (size_t)(c->ze1 - c->ze0);
-    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    hipError_t e = acquire_stream(device, &c->own_stream);
     if (e != hipSuccess) {
         delete c;
         return arvx::fail_hip(e, "hipStreamCreate", __FILE__, __LINE__);
@@ -255,7 +289,10 @@ int arvx_ctx_destroy(arvx_ctx *ctx) {
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_coarse) (void)hipFree(ctx->d_coarse);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->own_stream) {
+        (void)hipStreamSynchronize(ctx->own_stream);
+        release_stream(ctx->device, ctx->own_stream);
+    }
     delete ctx;
     return ARVX_OK;
 }
