@@ -71,7 +71,8 @@ std::mutex g_stream_mutex;
 std::vector<std::pair<int, hipStream_t>> g_idle_streams;  // (device, stream), idle and drained
 
 hipError_t acquire_stream(int device, hipStream_t *out) {
-    {
+    static const bool no_reuse = getenv("ARVX_NO_STREAM_REUSE") != nullptr;  // A/B
+    if (!no_reuse) {
         std::lock_guard<std::mutex> lock(g_stream_mutex);
         for (size_t i = 0; i < g_idle_streams.size(); ++i)
             if (g_idle_streams[i].first == device) {
@@ -84,8 +85,9 @@ hipError_t acquire_stream(int device, hipStream_t *out) {
 }
 
 void release_stream(int device, hipStream_t s) {  // s: synchronised by the caller
+    static const bool no_reuse = getenv("ARVX_NO_STREAM_REUSE") != nullptr;
     std::lock_guard<std::mutex> lock(g_stream_mutex);
-    if (g_idle_streams.size() < 64) {
+    if (!no_reuse && g_idle_streams.size() < 64) {
         g_idle_streams.emplace_back(device, s);
         return;
     }
