@@ -6,8 +6,9 @@
 //   void reconstructClosestColor(...same five...) / reconstructAvgColor(...)
 //   (reference src/VoxelCarving.h:19,31; src/ColorReconstruction.h:131,142)
 //
-// Only compiled where OpenCV (core, calib3d) is installed; this image has none,
-// so this header is NOT covered by the repo's tests.  The per-view
+// Only compiled where OpenCV (core, calib3d) is installed; this image has none: the repo's
+// tests only TYPE-CHECK this header against mock declarations of the cv::Mat members it uses
+// (tests/cpp/mock_opencv, tests/test_cpp_host.py); it has never run.  The per-view
 // pre-processing is done with OpenCV itself, exactly as the reference does it
 // (src/VoxelCarving.cpp:25-36): pose = estimatePoseFromImage(...).inv(),
 // cv::undistort on mask and image, intr = cameraMatrix as CV_32F; and

@@ -35,6 +35,18 @@ def test_calibration_file_reader(host_bin):
     assert r.returncode == 0 and "calibration ok" in r.stdout, r.stderr
 
 
+def test_opencv_dropin_header_type_checks():
+    """include/arvx/opencv_dropin.hpp (the reference's cv::Mat signatures) against mock
+    DECLARATIONS of the few cv::Mat members it uses (tests/cpp/mock_opencv: not OpenCV, nothing
+    computed): names, types and default arguments still fit the C++ layer underneath."""
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror",
+                        "-I" + os.path.join(ROOT, "tests", "cpp", "mock_opencv"),
+                        "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "cpp", "dropin_typecheck.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def write_scene(path, X, Y, Z, s, K, Rt, masks, images, st0):
     m4 = masks if masks.ndim == 4 else masks[..., None]
     V, H, W, C = m4.shape
