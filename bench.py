@@ -11,7 +11,7 @@ the 1-bit background planes and the summed-area tables the carve kernels read --
 rebuilt inside every timed step (arvx_set_views_device), then arvx_carve runs.
 `value` / `ms_per_step` are that whole step; `carve_kernel_ms` is the carve alone and
 `views_kernel_ms` the derivation, both by HIP events on the launch stream, recorded on
-every (K/5)-th timed step (the events themselves cost GPU time between dependent kernels).
+five of the K timed steps (the events themselves cost GPU time between dependent kernels).
 
 metric  Mvoxel-views/s = voxels x views / carve time  (BASELINE.json)
 N = 1   512^3 grid x 36 views (the configuration the metric is quoted on)
@@ -154,7 +154,7 @@ def main():
     # HIP events inside the timed region: every event is a marker packet between two dependent
     # kernels, and three of them per step cost 13.6 us of a 0.146 ms step (measured: all /
     # carve only / none = 0.1456 / 0.1402 / 0.1320 ms per step).  They are therefore recorded on
-    # a sample of the timed steps -- every EV_STRIDE-th, at least five of them.
+    # a sample of the timed steps: five of them (fewer when K < 20), evenly spaced.
     EV = {"none": 0, "carve": 1, "all": 2}[os.environ.get("ARVX_BENCH_EVENTS", "all")]
 
     def run_config(base, V, steps, warmup, collective, no_cull=False):
@@ -182,9 +182,10 @@ def main():
         if world > 1 and collective != "none":
             ex = sharding.OccupancyExchange(X, Y, Z, world, rank, dev, mode=collective, buffers=2,
                                             layout=layout, codec=ctx)
-        ev_stride = max(1, steps // 5)
-        ev = {i: tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
-              for i in range(0, steps, ev_stride)}
+        n_ev = max(1, min(5, steps // 4))  # timed steps that carry events, evenly spaced
+        ev = {(2 * k + 1) * steps // (2 * n_ev): tuple(torch.cuda.Event(enable_timing=True)
+                                                       for _ in range(3))
+              for k in range(n_ev)}
         nstep = [0]
         merge_ok = [None]
 
