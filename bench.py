@@ -220,6 +220,13 @@ def main():
                 ex.wait_all(verify=False)
             torch.cuda.synchronize()
 
+        # (the interpreter's cyclic collector pauses for 40-85 ms once torch is loaded -- seen at
+        # the 543rd set_views_device call, tools/host_probe.py -- and a pause that long drains
+        # the launch queue: no collections inside the timed region.  Collected BEFORE the warm-up
+        # steps: the collection itself leaves the GPU idle for tens of milliseconds, and the
+        # steps that follow an idle period run slower)
+        gc.collect()
+        gc.disable()
         for _ in range(warmup):
             step()
         drain()
@@ -230,11 +237,6 @@ def main():
                 drain()
             # packets start at the worst-case size; size them to what this scene needs
             packet_cap = ex.retune((nstep[0] - 1) % 2)
-        # (the interpreter's cyclic collector pauses for 40-85 ms once torch is loaded -- seen at
-        # the 543rd set_views_device call, tools/host_probe.py -- and a pause that long drains
-        # the launch queue: no collections inside the timed region)
-        gc.collect()
-        gc.disable()
         barrier()
         torch.cuda.synchronize()
         try:
