@@ -1078,7 +1078,8 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
     // a_r = p0[y] + ((p1[x] + p2[z]) + p3) (row_sum): the inner sum q depends on x and z
     // only, so it is formed once per (x, z) of the lane -- 4 x 2 values per row -- and a voxel
     // costs ONE fp64 add per row.  p1 is an exact product, so fma(m1, wx, p2) IS
-    // round(p1 + p2).
+    // round(p1 + p2).  (Tried and dropped: forming q only for the columns j whose blocks are
+    // projected -- the branches cost more than the sums they skip, carve +2..3 %.)
     double p0[2][3];
 #pragma unroll
     for (int byi = 0; byi < 2; ++byi)
