@@ -95,6 +95,41 @@ def test_fast_carve_golden(arvx, name):
     assert np.array_equal(got, g["fast_state"])
 
 
+@pytest.mark.parametrize("dims", [(2112, 8, 9), (4160, 3, 5), (2050, 17, 8)])
+def test_fast_carve_wide_grids(arvx, oracle, dims):
+    """More than 32 tiles along x: the records <-> bit plane conversions take the tiles of a row
+    in chunks; more than 64: no whole-tile pre-pass (its rows of tiles are 64-bit words)."""
+    X, Y, Z = dims
+    V, W, H = 3, 200, 60
+    s = np.float32(0.512 / X)
+    _, _, M = scenes.random_cameras(V, 0.512, seed=X, W=W, H=H)
+    masks = scenes.noise_masks(V, H, W, block=6, p_bg=0.7, seed=X + 1)
+    rng = np.random.default_rng(X)
+    for state in (None, np.where(rng.random((Z, Y, X)) < 0.03, 3, 1).astype(np.uint8)):
+        want = oracle.fast_carve(X, Y, Z, s, M, masks, state=state)
+        assert_same(gpu_fast(arvx, X, Y, Z, s, M, masks, state=state), want, f"{dims}")
+
+
+def test_dense_carve_after_fast_carve(arvx, oracle):
+    """fastCarve leaves the model as records; a dense carve, a byte download and a second
+    greedy carve on top of it start from that state."""
+    N, V = 48, 4
+    sc = scenes.small_sphere(N, V)
+    rng = np.random.default_rng(5)
+    state = np.where(rng.random((N, N, N)) < 0.04, 3, 1).astype(np.uint8)
+    with arvx.Context(N, N, N, sc.voxel_size) as ctx:
+        ctx.set_views(sc.M, sc.masks)
+        ctx.upload_state(state)
+        ctx.fast_carve()
+        st = oracle.fast_carve(N, N, N, sc.voxel_size, sc.M, sc.masks, state=state)
+        ctx.carve_views(0, 2)
+        st = oracle.carve(N, N, N, sc.voxel_size, sc.M[:2], sc.masks[:2], state=st)
+        assert_same(ctx.download_state(), st, "dense after greedy")
+        ctx.fast_carve()
+        st = oracle.fast_carve(N, N, N, sc.voxel_size, sc.M, sc.masks, state=st)
+        assert_same(ctx.download_state(), st, "greedy after dense")
+
+
 def test_fast_carve_rejects_slabs(arvx):
     sc = scenes.small_sphere(16, 3)
     with arvx.Context(16, 16, 16, sc.voxel_size, z_range=(0, 8)) as ctx:
