@@ -550,6 +550,19 @@ def test_view_preprocessing_paths(arvx, oracle, W, H, C):
             assert_same(ctx.download_state(), want, f"{W}x{H}x{C} device masks")
 
 
+@pytest.mark.parametrize("dims", [(2112, 8, 9), (8, 2112, 9), (9, 8, 2112), (4160, 3, 5)])
+def test_long_thin_grids(arvx, oracle, dims):
+    """One extent far beyond the others: thousands of tiles / coarse tiles along a single axis."""
+    X, Y, Z = dims
+    V, W, H = 4, 200, 60
+    s = np.float32(0.512 / max(dims))
+    _, _, M = scenes.random_cameras(V, 0.512, seed=sum(dims), W=W, H=H)
+    masks = scenes.noise_masks(V, H, W, block=6, p_bg=0.6, seed=X + 2)
+    want = oracle.carve(X, Y, Z, s, M, masks)
+    for flags in (0, arvx.CARVE_NO_CULL):
+        assert_same(run_gpu(arvx, X, Y, Z, s, M, masks, flags=flags), want, f"{dims} flags {flags}")
+
+
 def test_view_by_view_on_random_states_many_seeds(arvx, oracle):
     """One view at a time on random pre-carved states (every combination of occupied / seen),
     re-synchronised with the oracle after every view: single-view launches have only a handful
