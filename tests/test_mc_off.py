@@ -234,7 +234,7 @@ def test_gpu_mesh_colour_rules(arvx, oracle):
     """Colour pass colours, UNSEEN paint (explicit bit2 and apply_unseen), closure colours and
     the `i + 1` quirk: device triangles == oracle triangles on random models with w in {0, 1}."""
     rng = np.random.default_rng(23)
-    for dims in [(12, 9, 7), (40, 33, 20), (64, 64, 8), (1, 1, 1)]:
+    for dims in [(12, 9, 7), (40, 33, 20), (64, 64, 8), (1, 1, 1), (2100, 3, 4), (3, 4, 2100)]:
         X, Y, Z = dims
         rgba = random_coloured_model(rng, X, Y, Z, False)
         occ = rgba[:, 3] != 0
