@@ -526,7 +526,8 @@ def test_fuzz_against_oracle(arvx, oracle):
 
 @pytest.mark.parametrize("W,H,C", [(64, 3, 1), (128, 50, 3), (192, 117, 1), (640, 480, 3),
                                    (96, 64, 3), (65, 64, 1), (64, 600, 1), (130, 129, 4),
-                                   (96, 70, 1), (70, 33, 1), (63, 40, 1), (127, 70, 3)])
+                                   (96, 70, 1), (70, 33, 1), (63, 40, 1), (127, 70, 3),
+                                   (2000, 1500, 1), (4100, 70, 3)])
 def test_view_preprocessing_paths(arvx, oracle, W, H, C):
     """Bit planes and summed-area tables (csrc/views_kernels.h) for image widths that are and
     are not multiples of 64 (tile columns of the table kernels), heights above and below one
