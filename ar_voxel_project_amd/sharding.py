@@ -44,13 +44,14 @@ import torch.distributed as dist
 
 
 def grid_for(world: int, base: int) -> Tuple[int, int, int]:
-    """Grid holding ~world * base^3 voxels: X = Y = a multiple of 8 close to
-    base * world^(1/3), Z the nearest multiple of 8*world, so that all slabs are
-    equal and start on a 32-voxel boundary of the packed plane."""
+    """Grid holding ~world * base^3 voxels: X = Y = the multiple of 32 closest to
+    base * world^(1/3) (rows of whole 32-bit words of the packed plane: the kernels' widest
+    paths), Z the multiple of 8*world that keeps the volume, so that all slabs are equal and
+    start on a 32-voxel boundary of the packed plane."""
     if world == 1:
         return base, base, base
-    n = int(round(base * world ** (1.0 / 3.0) / 8.0)) * 8
-    z = max(1, int(round(n / (8.0 * world)))) * 8 * world
+    n = max(32, int(round(base * world ** (1.0 / 3.0) / 32.0)) * 32)
+    z = max(1, int(round(world * float(base) ** 3 / (n * n) / (8.0 * world)))) * 8 * world
     return n, n, z
 
 

@@ -25,7 +25,7 @@ def test_grid_and_slabs():
     assert sharding.grid_for(1, 512) == (512, 512, 512)
     for world in (2, 4, 8):
         X, Y, Z = sharding.grid_for(world, 512)
-        assert Z % (8 * world) == 0 and X % 8 == 0
+        assert Z % (8 * world) == 0 and X % 32 == 0
         ratio = X * Y * Z / (world * 512 ** 3)
         assert 0.93 < ratio < 1.07, (world, X, Y, Z, ratio)
         slabs = [sharding.slab_of(Z, world, r) for r in range(world)]

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""What ONE rank of an N-GPU job does per step, timed on one GPU without the collective:
+views + carve of the rank's stripes of the (N x 512^3)-voxel grid, pack, compress, expand of
+`world` packets (its own, repeated).  python tools/rank_step_time.py [world=8] [views=36]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from ar_voxel_project_amd import capi, sharding, synthetic as syn  # noqa: E402
+
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+V = int(sys.argv[2]) if len(sys.argv) > 2 else 36
+X, Y, Z = sharding.grid_for(world, 512)
+sc = syn.sphere_scene(max(X, Y, Z), V)
+dev = torch.device("cuda", 0)
+stream = torch.cuda.Stream(device=dev)
+torch.cuda.set_stream(stream)
+for rank in (0, world // 2):
+    ctx = capi.Context(X, Y, Z, sc.voxel_size, stripes=(world, rank))
+    ctx.set_stream(stream.cuda_stream)
+    d_masks = torch.from_numpy(sc.masks).to(dev)
+    ctx.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
+    n64 = X * Y * (Z // world) // 64
+    wpg = X * Y * 8 // 64
+    local = torch.zeros(n64, dtype=torch.int64, device=dev)
+    full = torch.zeros(n64 * world, dtype=torch.int64, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    ctx.reset(); ctx.carve(); ctx.pack_occupancy(local.data_ptr())
+    pk = torch.zeros(capi.occupancy_packet_words(n64, n64), dtype=torch.int64, device=dev)
+    ctx.occupancy_compress(local.data_ptr(), n64, pk.data_ptr(), n64)
+    torch.cuda.synchronize()
+    need = int(pk[0]); cap = need + need // 4 + 16
+    S = capi.occupancy_packet_words(n64, cap)
+    pks = torch.zeros(world * S, dtype=torch.int64, device=dev)
+    for q in range(world):
+        ctx.occupancy_compress(local.data_ptr(), n64, pks[q * S:].data_ptr(), cap)
+    names = ["views", "carve", "pack", "compress", "expand"]
+    best = [1e9] * 5
+    for _ in range(8):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        ctx.reset()
+        ev[0].record(stream)
+        ctx.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
+        ev[1].record(stream)
+        ctx.carve()
+        ev[2].record(stream)
+        ctx.pack_occupancy(local.data_ptr())
+        ev[3].record(stream)
+        ctx.occupancy_compress(local.data_ptr(), n64, pks.data_ptr(), cap)
+        ev[4].record(stream)
+        ctx.occupancy_expand_striped(pks.data_ptr(), world, n64, cap, wpg, full.data_ptr(), flag.data_ptr())
+        ev[5].record(stream)
+        torch.cuda.synchronize()
+        for k in range(5):
+            best[k] = min(best[k], ev[k].elapsed_time(ev[k + 1]))
+    print(f"world {world} rank {rank}: grid {X}x{Y}x{Z} x {V} views, packet {S * 8 / 1e6:.2f} MB of "
+          f"{n64 * 8 / 1e6:.2f} MB | " + " | ".join(f"{n} {b * 1e3:.1f} us" for n, b in zip(names, best))
+          + f" | sum {sum(best) * 1e3:.1f} us", flush=True)
+    ctx.close()
