@@ -28,7 +28,7 @@ COLOR_AVERAGE = 1
 SYMBOLS = [
     "arvx_version", "arvx_last_error", "arvx_device_count", "arvx_projection_assoc",
     "arvx_ctx_create", "arvx_ctx_create_slab", "arvx_ctx_create_striped", "arvx_ctx_destroy",
-    "arvx_ctx_set_stream", "arvx_ctx_synchronize", "arvx_ctx_voxels",
+    "arvx_ctx_set_stream", "arvx_ctx_set_exchange_stream", "arvx_ctx_synchronize", "arvx_ctx_voxels",
     "arvx_compose_projection", "arvx_set_views", "arvx_set_views_device",
     "arvx_set_images", "arvx_state_reset", "arvx_state_upload",
     "arvx_state_download", "arvx_state_device_ptr", "arvx_state_upload_halo",
@@ -100,6 +100,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                             C.c_float, C.c_int, C.c_int]
     lib.arvx_ctx_destroy.argtypes = [p]
     lib.arvx_ctx_set_stream.argtypes = [p, p]
+    if hasattr(lib, "arvx_ctx_set_exchange_stream"):
+        lib.arvx_ctx_set_exchange_stream.argtypes = [p, p]
     lib.arvx_ctx_synchronize.argtypes = [p]
     lib.arvx_ctx_voxels.argtypes = [p, C.POINTER(C.c_int64)]
     lib.arvx_compose_projection.argtypes = [f32p, f32p, f32p]
@@ -380,6 +382,11 @@ class Context:
 
     def set_stream(self, stream_ptr: int) -> None:
         self._ck(self._lib.arvx_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_exchange_stream(self, stream_ptr: int) -> None:
+        """pack_occupancy*, occupancy_compress / _expand* launch on this stream (0: the
+        context's); the caller orders it against the context's stream with events."""
+        self._ck(self._lib.arvx_ctx_set_exchange_stream(self._h, C.c_void_p(stream_ptr)))
 
     def synchronize(self) -> None:
         self._ck(self._lib.arvx_ctx_synchronize(self._h))

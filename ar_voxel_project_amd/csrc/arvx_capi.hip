@@ -61,6 +61,18 @@ using arvx::Ctx;
         ARVX_HIP(hipSetDevice((ctx)->device));                       \
     } while (0)
 
+// The entry points of the occupancy hand-off (pack / compress / expand) launch on the
+// context's exchange stream when the caller has set one: everything they launch inside goes
+// there, and the caller orders the two streams with events.
+struct ExchangeStreamScope {
+    Ctx *ctx;
+    hipStream_t saved;
+    explicit ExchangeStreamScope(Ctx *c) : ctx(c), saved(c->stream) {
+        if (c->xstream) c->stream = c->xstream;
+    }
+    ~ExchangeStreamScope() { ctx->stream = saved; }
+};
+
 // ---- streams ----------------------------------------------------------------------------
 // hipStreamCreate / hipStreamDestroy cost 1.4 - 2.2 ms each on this stack (rocprofv3
 // --hip-trace of tools/cpp/arvx_bench6: more than the whole carve of its largest model), and a
@@ -303,6 +315,12 @@ int arvx_ctx_set_stream(arvx_ctx *ctx, void *hip_stream) {
     ARVX_CHECK_CTX(ctx);
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return ARVX_OK;
+}
+
+int arvx_ctx_set_exchange_stream(arvx_ctx *ctx, void *hip_stream) {
+    ARVX_CHECK_CTX(ctx);
+    ctx->xstream = (hipStream_t)hip_stream;
     return ARVX_OK;
 }
 
@@ -754,6 +772,7 @@ int arvx_state_device_ptr(arvx_ctx *ctx, void **ptr, size_t *bytes) {
 
 int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
     ARVX_CHECK_CTX(ctx);
+    ExchangeStreamScope exchange_scope(ctx);
     if (!dev_words) return fail(ARVX_ERR_INVALID, "null dev_words");
     if (ctx->X % 32 == 0 && (uintptr_t)dev_words % 4 == 0 && (ctx->rec_valid || !ctx->bytes_valid)) {
         // straight from the records: 2 bits per voxel in, 1 out
@@ -804,6 +823,7 @@ int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
 
 int arvx_pack_occupancy_global(arvx_ctx *ctx, void *dev_global_words) {
     ARVX_CHECK_CTX(ctx);
+    ExchangeStreamScope exchange_scope(ctx);
     if (!dev_global_words) return fail(ARVX_ERR_INVALID, "null dev_global_words");
     const size_t plane = (size_t)ctx->X * ctx->Y;
     if (plane % 64) return fail(ARVX_ERR_INVALID, "X*Y must be a multiple of 64");
@@ -854,6 +874,7 @@ int64_t arvx_occupancy_packet_words(int64_t n_words64, int64_t cap_words64) {
 int arvx_occupancy_compress(arvx_ctx *ctx, const void *dev_words, int64_t n_words64,
                             void *dev_packet, int64_t cap_words64) {
     ARVX_CHECK_CTX(ctx);
+    ExchangeStreamScope exchange_scope(ctx);
     if (!dev_words || !dev_packet || n_words64 <= 0 || cap_words64 < 0)
         return fail(ARVX_ERR_INVALID, "bad argument");
     if (((uintptr_t)dev_words | (uintptr_t)dev_packet) & 7u)
@@ -881,6 +902,7 @@ int arvx_occupancy_expand(arvx_ctx *ctx, const void *dev_packets, int world, int
                           int64_t n_words64, int64_t cap_words64, void *dev_full_words,
                           int *dev_overflow) {
     ARVX_CHECK_CTX(ctx);
+    ExchangeStreamScope exchange_scope(ctx);
     if (!dev_packets || !dev_full_words || !dev_overflow || world < 1 || self_rank < 0 ||
         self_rank >= world || n_words64 <= 0 || cap_words64 < 0)
         return fail(ARVX_ERR_INVALID, "bad argument");
@@ -901,6 +923,7 @@ int arvx_occupancy_expand_striped(arvx_ctx *ctx, const void *dev_packets, int wo
                                   int64_t n_words64, int64_t cap_words64, int64_t words_per_group,
                                   void *dev_full_words, int *dev_overflow) {
     ARVX_CHECK_CTX(ctx);
+    ExchangeStreamScope exchange_scope(ctx);
     if (!dev_packets || !dev_full_words || !dev_overflow || world < 1 || n_words64 <= 0 ||
         cap_words64 < 0 || words_per_group < 2 || (words_per_group & 1) ||
         n_words64 % words_per_group)

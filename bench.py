@@ -22,6 +22,9 @@ N > 1   one rank per GPU; rank r carves Z slab r of a grid that holds N x 512^3
         by one kernel on the receivers) over striped, load-balanced slabs,
         --collective allgather for the plain in-place all-gather of contiguous slabs,
         --collective allreduce for the north star's all-reduce (striped slabs).
+        The hand-off of step k (pack, compress, collective, expand) runs on a second
+        stream beside step k + 1 (arvx_ctx_set_exchange_stream); every job's hand-off
+        is inside the timed region.
 
 The JSON line also carries `roofline` (algorithmic HBM bytes of SURVEY 8d / the
 carve kernel's launch time measured with HIP events on its own stream) and
@@ -188,6 +191,15 @@ def main():
               for k in range(n_ev)}
         nstep = [0]
         merge_ok = [None]
+        # N > 1: the hand-off of job k -- pack, compress, the collective, expand: HBM-bound
+        # kernels, 78 us of a rank's 176 us at 8 GPUs when they run behind the carve
+        # (tools/rank_step_time.py) -- goes to a stream of its own and runs beside the views
+        # and the carve of job k + 1.  Two events order the streams: the pack waits for the
+        # carve whose records it reads, the next carve for that pack.
+        side = torch.cuda.Stream(device=dev) if ex is not None else None
+        if side is not None:
+            ctx.set_exchange_stream(side.cuda_stream)
+        packed = [None]  # recorded on `side` behind the latest pack
 
         def step(i=None):
             # one job: fresh model -> carve all views -> (N>1) merge the occupancy of
@@ -202,22 +214,31 @@ def main():
             ctx.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
             if i is not None and EV >= 1:
                 ev[i][1].record(stream)
+            if packed[0] is not None:
+                stream.wait_event(packed[0])  # the previous job's pack has read the records
             ctx.carve(flags)
             if i is not None and EV >= 1:
                 ev[i][2].record(stream)
             if ex is not None:
                 b = nstep[0] % 2
-                ex.prepare(b, verify=False)  # compressed: overflow is checked after drain()
-                if collective == "compressed":  # the rank's planes in local order -> one packet
-                    ctx.pack_occupancy(ex.local[b].data_ptr())
-                else:
-                    ctx.pack_occupancy_global(ex.full[b].data_ptr())
-                ex.launch(b, async_op=True)
+                carved = torch.cuda.Event()
+                carved.record(stream)
+                with torch.cuda.stream(side):
+                    side.wait_event(carved)
+                    ex.prepare(b, verify=False)  # compressed: overflow is checked after drain()
+                    if collective == "compressed":  # the rank's planes in local order -> a packet
+                        ctx.pack_occupancy(ex.local[b].data_ptr())
+                    else:
+                        ctx.pack_occupancy_global(ex.full[b].data_ptr())
+                    packed[0] = torch.cuda.Event()
+                    packed[0].record(side)
+                    ex.launch(b, async_op=True)
             nstep[0] += 1
 
         def drain():
             if ex is not None:
-                ex.wait_all(verify=False)
+                with torch.cuda.stream(side):
+                    ex.wait_all(verify=False)
             torch.cuda.synchronize()
 
         # (the interpreter's cyclic collector pauses for 40-85 ms once torch is loaded -- seen at

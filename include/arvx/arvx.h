@@ -95,6 +95,12 @@ int arvx_ctx_create_striped(arvx_ctx **out, int device, int X, int Y, int Z,
 int arvx_ctx_destroy(arvx_ctx *ctx);
 /* Launch on a caller-owned hipStream_t (borrowed); NULL = context's own. */
 int arvx_ctx_set_stream(arvx_ctx *ctx, void *hip_stream);
+/* A stream of its own for the occupancy hand-off (arvx_pack_occupancy[_global],
+ * arvx_occupancy_compress / _expand[_striped]): a multi-GPU job runs the exchange of job k --
+ * pack, compress, the collective, expand -- beside the carve of job k + 1.  The caller orders
+ * the two streams with events: the pack reads the state the carve wrote (it must wait for the
+ * carve, and the next carve for the pack).  NULL: back on the context's stream. */
+int arvx_ctx_set_exchange_stream(arvx_ctx *ctx, void *hip_stream);
 int arvx_ctx_synchronize(arvx_ctx *ctx);
 /* Voxels held by this context (slab). */
 int arvx_ctx_voxels(const arvx_ctx *ctx, int64_t *count);

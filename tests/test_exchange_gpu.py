@@ -139,6 +139,64 @@ def test_carved_slabs_round_trip():
     c.close()
 
 
+def test_exchange_stream_pipeline():
+    """arvx_ctx_set_exchange_stream: the hand-off of job k (pack, compress, expand) on a second
+    stream beside the carve of job k + 1, ordered by two events -- as bench.py and a
+    multi-GPU caller run it.  Jobs alternate between two scenes; every expanded plane must be
+    the packed occupancy of ITS job."""
+    from ar_voxel_project_amd import capi
+    X = Y = Z = 64
+    scs = [scenes.small_sphere(64, 6, W=160, H=120), scenes.syn.box_scene((64, 64, 64), 5)]
+    n = X * Y * Z // 64
+    cap = n
+    S = capi.occupancy_packet_words(n, cap)
+    main, side = torch.cuda.Stream(), torch.cuda.Stream()
+    want = []
+    with capi.Context(X, Y, Z, scs[0].voxel_size) as c:  # reference planes, one stream
+        for sc in scs:
+            c.set_views(sc.M, sc.masks)
+            c.reset()
+            c.carve()
+            d = torch.zeros(n, dtype=torch.int64, device="cuda")
+            _settle()
+            c.pack_occupancy(d.data_ptr())
+            c.synchronize()
+            want.append(d.clone())
+    assert not torch.equal(want[0], want[1])
+    d_masks = [torch.from_numpy(np.ascontiguousarray(sc.masks)).cuda() for sc in scs]
+    jobs = 8
+    words = [torch.zeros(n, dtype=torch.int64, device="cuda") for _ in range(2)]
+    packet = [torch.zeros(S, dtype=torch.int64, device="cuda") for _ in range(2)]
+    full = [torch.zeros(n, dtype=torch.int64, device="cuda") for _ in range(jobs)]
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _settle()
+    with capi.Context(X, Y, Z, scs[0].voxel_size) as c:
+        c.set_stream(main.cuda_stream)
+        c.set_exchange_stream(side.cuda_stream)
+        packed = None
+        for k in range(jobs):
+            sc, b = scs[k % 2], k % 2
+            c.reset()
+            c.set_views_device(sc.M, d_masks[k % 2].data_ptr(), sc.W, sc.H, 1)
+            if packed is not None:
+                main.wait_event(packed)  # the previous pack has read the records
+            c.carve()
+            carved = torch.cuda.Event()
+            carved.record(main)
+            side.wait_event(carved)
+            c.pack_occupancy(words[b].data_ptr())
+            packed = torch.cuda.Event()
+            packed.record(side)
+            c.occupancy_compress(words[b].data_ptr(), n, packet[b].data_ptr(), cap)
+            c.occupancy_expand_striped(packet[b].data_ptr(), 1, n, cap, n, full[k].data_ptr(),
+                                       flag.data_ptr())
+        torch.cuda.synchronize()
+        c.set_exchange_stream(0)
+    assert not flag.item()
+    for k in range(jobs):
+        assert torch.equal(full[k], want[k % 2]), f"job {k}"
+
+
 @pytest.mark.parametrize("wpg,groups,world", [(2, 3, 2), (32, 5, 3), (1024, 4, 8)])
 def test_expand_striped_matches_restatement(ctx, wpg, groups, world):
     """Striped slabs: word i of rank q lands at ((i / wpg) * world + q) * wpg + i % wpg, for

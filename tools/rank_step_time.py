@@ -58,4 +58,38 @@ for rank in (0, world // 2):
     print(f"world {world} rank {rank}: grid {X}x{Y}x{Z} x {V} views, packet {S * 8 / 1e6:.2f} MB of "
           f"{n64 * 8 / 1e6:.2f} MB | " + " | ".join(f"{n} {b * 1e3:.1f} us" for n, b in zip(names, best))
           + f" | sum {sum(best) * 1e3:.1f} us", flush=True)
+    # the same work as a pipeline: hand-off of step k on a side stream beside step k + 1
+    import time
+    side = torch.cuda.Stream(device=dev)
+
+    def run(overlap, steps=100):
+        ctx.set_exchange_stream(side.cuda_stream if overlap else 0)
+        packed = None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.reset()
+            ctx.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
+            if overlap and packed is not None:
+                stream.wait_event(packed)
+            ctx.carve()
+            if overlap:
+                carved = torch.cuda.Event()
+                carved.record(stream)
+                side.wait_event(carved)
+            ctx.pack_occupancy(local.data_ptr())
+            if overlap:
+                packed = torch.cuda.Event()
+                packed.record(side)
+            ctx.occupancy_compress(local.data_ptr(), n64, pks.data_ptr(), cap)
+            ctx.occupancy_expand_striped(pks.data_ptr(), world, n64, cap, wpg, full.data_ptr(),
+                                         flag.data_ptr())
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e6
+
+    for _ in range(2):
+        a, b = run(False), run(True)
+    print(f"world {world} rank {rank}: per step, hand-off behind the carve {a:.1f} us, beside the next "
+          f"step {b:.1f} us", flush=True)
+    ctx.set_exchange_stream(0)
     ctx.close()
