@@ -324,12 +324,6 @@ int arvx_ctx_set_exchange_stream(arvx_ctx *ctx, void *hip_stream) {
     return ARVX_OK;
 }
 
-int arvx_ctx_set_carve_marker(arvx_ctx *ctx, void *hip_event) {
-    ARVX_CHECK_CTX(ctx);
-    ctx->carve_marker = (hipEvent_t)hip_event;
-    return ARVX_OK;
-}
-
 int arvx_ctx_synchronize(arvx_ctx *ctx) {
     ARVX_CHECK_CTX(ctx);
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
@@ -1074,7 +1068,6 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         ARVX_HIP(hipMemsetAsync(ctx->d_timeline, 0, (size_t)pgrid * 4 * 64, ctx->stream));
         p.timeline = (unsigned long long *)ctx->d_timeline;
 #endif
-        if (ctx->carve_marker) ARVX_HIP(hipEventRecord(ctx->carve_marker, ctx->stream));
         if (blocks)
             hipLaunchKernelGGL(arvx::carve_exact_blocks_kernel, dim3(pgrid), dim3(256), 0,
                                ctx->stream, p);

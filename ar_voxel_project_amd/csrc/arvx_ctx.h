@@ -53,7 +53,6 @@ struct Ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t xstream = nullptr;  // arvx_ctx_set_exchange_stream: the occupancy hand-off (null: stream)
-    hipEvent_t carve_marker = nullptr;  // arvx_ctx_set_carve_marker: recorded in front of the exact kernel
 
     // The state lives in one of two forms (csrc/arvx_device.h): sub-tile RECORDS, 2 bits per
     // voxel -- what the carve kernels read and write --, and the one-byte-per-voxel plane of

@@ -62,17 +62,9 @@ for rank in (0, world // 2):
     import time
     side = torch.cuda.Stream(device=dev)
 
-    import ctypes as C
-    lib = capi.load_library()
-    lib.arvx_ctx_set_carve_marker.argtypes = [C.c_void_p, C.c_void_p]
-    markers = [torch.cuda.Event() for _ in range(2)]
-    for m in markers:
-        m.record(stream)  # (creates the underlying event)
-
     def run(overlap, steps=100):
         ctx.set_exchange_stream(side.cuda_stream if overlap else 0)
         packed = None
-        pending = None  # hand-off of the previous step, waiting for this step's marker
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -80,16 +72,7 @@ for rank in (0, world // 2):
             ctx.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
             if overlap and packed is not None:
                 stream.wait_event(packed)
-            mk = markers[_ % 2]
-            if overlap == 2:
-                lib.arvx_ctx_set_carve_marker(ctx._h, C.c_void_p(mk.cuda_event))
             ctx.carve()
-            if overlap == 2 and pending:
-                # the previous step's compress + expand start with THIS step's exact kernel
-                side.wait_event(mk)
-                ctx.occupancy_compress(local.data_ptr(), n64, pks.data_ptr(), cap)
-                ctx.occupancy_expand_striped(pks.data_ptr(), world, n64, cap, wpg,
-                                             full.data_ptr(), flag.data_ptr())
             if overlap:
                 carved = torch.cuda.Event()
                 carved.record(stream)
@@ -98,19 +81,15 @@ for rank in (0, world // 2):
             if overlap:
                 packed = torch.cuda.Event()
                 packed.record(side)
-            if overlap == 2:
-                pending = True
-            else:
-                ctx.occupancy_compress(local.data_ptr(), n64, pks.data_ptr(), cap)
-                ctx.occupancy_expand_striped(pks.data_ptr(), world, n64, cap, wpg,
-                                             full.data_ptr(), flag.data_ptr())
+            ctx.occupancy_compress(local.data_ptr(), n64, pks.data_ptr(), cap)
+            ctx.occupancy_expand_striped(pks.data_ptr(), world, n64, cap, wpg, full.data_ptr(),
+                                         flag.data_ptr())
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps * 1e6
 
-    for _rep in range(2):
-        a, b, c = run(0), run(1), run(2)
-    lib.arvx_ctx_set_carve_marker(ctx._h, None)
+    for _ in range(2):
+        a, b = run(False), run(True)
     print(f"world {world} rank {rank}: per step, hand-off behind the carve {a:.1f} us, beside the next "
-          f"step {b:.1f} us, compress + expand beside the next exact kernel {c:.1f} us", flush=True)
+          f"step {b:.1f} us", flush=True)
     ctx.set_exchange_stream(0)
     ctx.close()
