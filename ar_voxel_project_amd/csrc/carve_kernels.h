@@ -250,7 +250,15 @@ __device__ __forceinline__ void coarse_fill(const CarveParams &p, const int ct, 
                 w[k] = pair;
             }
         }
-        dst[i] = make_uint4(w[0], w[1], w[2], w[3]);
+        // (non-temporal: 16 KB of constants per coarse tile that the carve itself never reads
+        // again must not push the views' tables and bit planes out of the L2)
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 v;
+        v.x = w[0];
+        v.y = w[1];
+        v.z = w[2];
+        v.w = w[3];
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst + i));
     }
 }
 

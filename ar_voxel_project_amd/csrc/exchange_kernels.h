@@ -151,7 +151,14 @@ __global__ __launch_bounds__(256) void occ_expand_kernel(const unsigned long lon
         // (striped: i is even and wpg is even, so i and i + 1 lie in the same group)
         const long long at_dst = wpg ? ((i / wpg) * world + q) * wpg + i % wpg : i;
         if (pair_ok && i + 1 < n) {
-            *reinterpret_cast<ulonglong2 *>(dst + at_dst) = make_ulonglong2(w0, w1);
+            // (the merged plane is written once per job and read by nobody on this device while
+            // the next carve runs: non-temporal, so that it does not push the views' tables and
+            // bit planes out of the L2)
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            u64x2 v;
+            v.x = w0;
+            v.y = w1;
+            __builtin_nontemporal_store(v, reinterpret_cast<u64x2 *>(dst + at_dst));
         } else {
             dst[at_dst] = w0;
             if (i + 1 < n) dst[at_dst + 1] = w1;
