@@ -119,37 +119,27 @@ static int ensure_scratch(Ctx *ctx, size_t need) {
     return ARVX_OK;
 }
 
-static int need_bytes(Ctx *ctx);
+static int need_rec(Ctx *ctx);
 static void carve_geometry(const Ctx *ctx, arvx::CarveParams &p);
 
-// The context's planes ze0 .. ze0 + g.Z - 1 as ONE bit plane (bitplane_kernels.h) under PRED:
-// straight from the records when they hold the state, else from the byte plane (which alone
-// can carry bit2, the host's UNSEEN paint).
-template <int PRED>
-static int launch_bit_pack(Ctx *ctx, const arvx::BitGrid &g, int apply_unseen,
-                           unsigned long long *bits) {
+// the paint plane where it takes part (null: nobody is painted)
+static const unsigned long long *paint_plane(const Ctx *ctx) {
+    return ctx->paint_valid ? (const unsigned long long *)ctx->pool_paint.p : nullptr;
+}
+
+// The context's planes ze0 .. ze0 + g.Z - 1 as bit planes (bitplane_kernels.h) from the
+// records: `occ` = occupied, or what the closure calls occupied; `unseen` (may be null) = the
+// voxels whose colour is UNSEEN_COLOR.
+static int launch_bit_pack(Ctx *ctx, const arvx::BitGrid &g, int closure_occupied, int apply_unseen,
+                           unsigned long long *occ, unsigned long long *unseen) {
+    if (int rc = need_rec(ctx)) return rc;
     const size_t nwords = (size_t)g.XW * g.Y * g.Z;
-    if (ctx->rec_valid) {
-        arvx::CarveParams p;
-        carve_geometry(ctx, p);
-        p.rec = ctx->d_rec;
-        hipLaunchKernelGGL(arvx::bitgrid_from_rec_kernel, dim3((unsigned)((nwords + 255) / 256)),
-                           dim3(256), 0, ctx->stream, p, 0, g.Z,
-                           (PRED == arvx::kBitClosureOccupied && apply_unseen) ? 1 : 0, bits);
-        ARVX_HIP(hipGetLastError());
-        return ARVX_OK;
-    }
-    if (int rc = need_bytes(ctx)) return rc;
-    const uint8_t *state = ctx->d_state;
-    if (g.X % 32 == 0 && ((uintptr_t)state & 15u) == 0)
-        hipLaunchKernelGGL(arvx::bit_pack32_kernel<PRED>, dim3((unsigned)((nwords * 2 + 255) / 256)),
-                           dim3(256), 0, ctx->stream, state, g, apply_unseen, bits);
-    else if (g.X % 8 == 0)
-        hipLaunchKernelGGL(arvx::bit_pack8_kernel<PRED>, dim3((unsigned)((nwords * 8 + 255) / 256)),
-                           dim3(256), 0, ctx->stream, state, g, apply_unseen, bits);
-    else
-        hipLaunchKernelGGL(arvx::bit_pack_kernel<PRED>, dim3((unsigned)((nwords + 3) / 4)),
-                           dim3(256), 0, ctx->stream, state, g, apply_unseen, bits);
+    arvx::CarveParams p;
+    carve_geometry(ctx, p);
+    p.rec = ctx->d_rec;
+    hipLaunchKernelGGL(arvx::bitgrid_from_rec_kernel, dim3((unsigned)((nwords + 255) / 256)),
+                       dim3(256), 0, ctx->stream, p, 0, g.Z, closure_occupied, apply_unseen,
+                       closure_occupied ? paint_plane(ctx) : nullptr, occ, unseen);
     ARVX_HIP(hipGetLastError());
     return ARVX_OK;
 }
@@ -171,10 +161,11 @@ static int bit_compact_count(Ctx *ctx, const unsigned long long *bits, size_t nw
 }
 
 static int bit_compact_write(Ctx *ctx, const unsigned long long *bits, size_t nwords,
-                             const arvx::BitGrid &g, const long long *d_off, int *d_index) {
+                             const arvx::BitGrid &g, const long long *d_off, int *d_index,
+                             int *d_rank) {
     const int nblk = (int)((nwords + arvx::kBitChunk - 1) / arvx::kBitChunk);
     hipLaunchKernelGGL(arvx::bit_write_kernel, dim3(nblk), dim3(256), 0, ctx->stream, bits, nwords,
-                       g, d_off, d_index);
+                       g, d_off, d_index, d_rank);
     ARVX_HIP(hipGetLastError());
     return ARVX_OK;
 }
@@ -247,12 +238,12 @@ int arvx_ctx_create_slab(arvx_ctx **out, int device, int X, int Y, int Z, float 
         return arvx::fail_hip(e, "hipStreamCreate", __FILE__, __LINE__);
     }
     c->stream = c->own_stream;
-    e = hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long));
+    e = hipMalloc(&c->d_stats, 16 * sizeof(unsigned long long));  // 8 counters + flags
     if (e != hipSuccess) {
         arvx_ctx_destroy(c);
         return arvx::fail_hip(e, "hipMalloc(stats)", __FILE__, __LINE__);
     }
-    c->fresh_pending = true;  // a fresh Model exists only as this flag: see need_rec / need_bytes
+    c->fresh_pending = true;  // a fresh Model exists only as this flag: see need_rec
     e = hipMemsetAsync(c->d_stats, 0, 64, c->stream);
     if (e != hipSuccess) {
         arvx_ctx_destroy(c);
@@ -315,6 +306,9 @@ int arvx_ctx_set_stream(arvx_ctx *ctx, void *hip_stream) {
     ARVX_CHECK_CTX(ctx);
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    // the carve's alternating list counters are zeroed by the PREVIOUS carve in stream order:
+    // on another stream they start over (launch_carve zeroes both when the layout is unset)
+    ctx->carve_layout = 0;
     return ARVX_OK;
 }
 
@@ -592,7 +586,7 @@ static int ensure_records(Ctx *ctx, void **buf, size_t *cap) {
     return ARVX_OK;
 }
 
-// The state as records: what the carve works on.
+// The state as records: what every stage works on.
 static int need_rec(Ctx *ctx) {
     void *buf = ctx->d_rec;
     if (int rc = ensure_records(ctx, &buf, &ctx->rec_bytes)) return rc;
@@ -601,92 +595,105 @@ static int need_rec(Ctx *ctx) {
     arvx::CarveParams g;
     carve_geometry(ctx, g);
     g.rec = ctx->d_rec;
-    if (ctx->bytes_valid) {
-        hipLaunchKernelGGL(arvx::rec_from_bytes_kernel,
-                           dim3((unsigned)((size_t)g.tilesX * g.tilesY * g.tilesZ)), dim3(256), 0,
-                           ctx->stream, g, (const uint8_t *)ctx->d_state);
-    } else {  // a fresh model: all occupied, none seen
-        g.flags = 4u | 16u;
-        hipLaunchKernelGGL(arvx::carve_fill_kernel,
-                           dim3((unsigned)((size_t)g.coarseX * g.coarseY * g.coarseZ)), dim3(256), 0,
-                           ctx->stream, g);
-        ctx->fresh_pending = false;
-    }
+    g.flags = 4u | 16u;  // a fresh model: all occupied, none seen
+    hipLaunchKernelGGL(arvx::carve_fill_kernel,
+                       dim3((unsigned)((size_t)g.coarseX * g.coarseY * g.coarseZ)), dim3(256), 0,
+                       ctx->stream, g);
     ARVX_HIP(hipGetLastError());
+    ctx->fresh_pending = false;
     ctx->rec_valid = true;
     return ARVX_OK;
 }
 
-// The state as one byte per voxel: what the C-ABI's state calls and the stages that are not
-// ported to records yet work on.
-static int need_bytes(Ctx *ctx) {
-    if (!ctx->d_state) ARVX_HIP(hipMalloc(&ctx->d_state, ctx->nvox_ext));
-    if (ctx->bytes_valid) return ARVX_OK;
-    if (ctx->rec_valid) {
-        arvx::CarveParams g;
-        carve_geometry(ctx, g);
-        g.rec = ctx->d_rec;
-        hipLaunchKernelGGL(arvx::rec_to_bytes_kernel,
-                           dim3((unsigned)((size_t)g.tilesX * g.tilesY * g.tilesZ)), dim3(256), 0,
-                           ctx->stream, g, ctx->d_state);
-        ARVX_HIP(hipGetLastError());
-    } else {  // a fresh model
-        ARVX_HIP(hipMemsetAsync(ctx->d_state, 0x01, ctx->nvox_ext, ctx->stream));
-        ctx->fresh_pending = false;
-    }
-    ctx->bytes_valid = true;
+// every call that changes occupied / seen bits goes through here: results derived from the
+// old state are dropped
+static void state_changes(Ctx *ctx, bool keeps_paint) {
+    ctx->color_ready = false;
+    ctx->closure_ready = false;
+    if (!keeps_paint) ctx->paint_valid = false;
+}
+
+// Bytes of local planes [zl0, zl0 + nz), already in the staging buffer, into the records
+// (+ bit2 into the paint plane).  Ends with a host synchronisation.
+static int bytes_into_records(Ctx *ctx, int zl0, int nz) {
+    if (int rc = need_rec(ctx)) return rc;
+    arvx::CarveParams g;
+    carve_geometry(ctx, g);
+    g.rec = ctx->d_rec;
+    const size_t pw = (size_t)((ctx->X + 63) / 64) * ctx->Y * (size_t)(ctx->ze1 - ctx->ze0);
+    const bool had = ctx->pool_paint.cap >= pw * 8 && ctx->paint_valid;
+    ARVX_HIP(ctx->pool_paint.reserve(pw * 8));
+    if (!had) ARVX_HIP(hipMemsetAsync(ctx->pool_paint.p, 0, pw * 8, ctx->stream));
+    int *d_any = (int *)(ctx->d_stats + 8);
+    ARVX_HIP(hipMemsetAsync(d_any, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(arvx::rec_from_bytes_kernel,
+                       dim3((unsigned)((size_t)g.tilesX * g.tilesY * g.tilesZ)), dim3(256), 0,
+                       ctx->stream, g, (const uint8_t *)ctx->d_state, zl0, nz,
+                       (unsigned long long *)ctx->pool_paint.p, d_any);
+    ARVX_HIP(hipGetLastError());
+    int any = 0;
+    ARVX_HIP(hipMemcpyAsync(&any, d_any, sizeof any, hipMemcpyDeviceToHost, ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));  // (also: the host bytes may go away)
+    ctx->paint_valid = had || any != 0;
     return ARVX_OK;
 }
 
-// the byte plane is about to be written by its user
-static int own_bytes(Ctx *ctx) {
-    if (int rc = need_bytes(ctx)) return rc;
-    ctx->rec_valid = false;
+// the byte staging buffer holds the current state of local planes [zl0, zl0 + nz)
+static int records_into_bytes(Ctx *ctx, int zl0, int nz) {
+    if (int rc = need_rec(ctx)) return rc;
+    if (!ctx->d_state) ARVX_HIP(hipMalloc(&ctx->d_state, ctx->nvox_ext));
+    arvx::CarveParams g;
+    carve_geometry(ctx, g);
+    g.rec = ctx->d_rec;
+    hipLaunchKernelGGL(arvx::rec_to_bytes_kernel,
+                       dim3((unsigned)((size_t)g.tilesX * g.tilesY * g.tilesZ)), dim3(256), 0,
+                       ctx->stream, g, ctx->d_state, zl0, nz, paint_plane(ctx));
+    ARVX_HIP(hipGetLastError());
     return ARVX_OK;
 }
 
 int arvx_state_reset(arvx_ctx *ctx) {
     ARVX_CHECK_CTX(ctx);
-    ctx->color_ready = false;
-    ctx->closure_ready = false;
-    ctx->fresh_pending = true;  // materialised by need_rec / need_bytes, or never (a carve of a
-    ctx->rec_valid = false;     // fresh model writes every record)
-    ctx->bytes_valid = false;
+    state_changes(ctx, false);
+    ctx->fresh_pending = true;  // materialised by need_rec, or never (a carve of a fresh model
+    ctx->rec_valid = false;     // writes every record)
     return ARVX_OK;
 }
 
 int arvx_state_upload(arvx_ctx *ctx, const uint8_t *state) {
     ARVX_CHECK_CTX(ctx);
     if (!state) return fail(ARVX_ERR_INVALID, "null state");
-    if (int mrc = own_bytes(ctx)) return mrc;  // (halo planes keep what they hold)
-    ctx->color_ready = false;
-    ctx->closure_ready = false;
+    if (!ctx->d_state) ARVX_HIP(hipMalloc(&ctx->d_state, ctx->nvox_ext));
+    // paint of the owned planes is replaced; what the halo planes hold stays
+    const bool halo_paint = ctx->paint_valid && ctx->nvox_ext != ctx->nvox;
+    state_changes(ctx, halo_paint);
     ARVX_HIP(hipMemcpyAsync(ctx->owned(), state, ctx->nvox, hipMemcpyHostToDevice, ctx->stream));
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
-    return ARVX_OK;
+    return bytes_into_records(ctx, ctx->z0 - ctx->ze0, ctx->z1 - ctx->z0);
 }
 
 int arvx_state_upload_halo(arvx_ctx *ctx, const uint8_t *plane_below, const uint8_t *plane_above) {
     ARVX_CHECK_CTX(ctx);
     const size_t plane = (size_t)ctx->X * ctx->Y;
     if (ctx->stripe_world > 1) return fail(ARVX_ERR_STATE, "striped slabs keep no halo planes");
-    if (int mrc = own_bytes(ctx)) return mrc;
-    ctx->color_ready = false;
-    ctx->closure_ready = false;
-    if (plane_below && ctx->ze0 < ctx->z0)
+    if (!ctx->d_state) ARVX_HIP(hipMalloc(&ctx->d_state, ctx->nvox_ext));
+    state_changes(ctx, true);
+    if (plane_below && ctx->ze0 < ctx->z0) {
         ARVX_HIP(hipMemcpyAsync(ctx->d_state, plane_below, plane, hipMemcpyHostToDevice,
                                 ctx->stream));
-    if (plane_above && ctx->ze1 > ctx->z1)
+        if (int rc = bytes_into_records(ctx, 0, 1)) return rc;
+    }
+    if (plane_above && ctx->ze1 > ctx->z1) {
         ARVX_HIP(hipMemcpyAsync(ctx->owned() + ctx->nvox, plane_above, plane,
                                 hipMemcpyHostToDevice, ctx->stream));
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+        if (int rc = bytes_into_records(ctx, ctx->z1 - ctx->ze0, 1)) return rc;
+    }
     return ARVX_OK;
 }
 
 int arvx_state_download(arvx_ctx *ctx, uint8_t *state) {
     ARVX_CHECK_CTX(ctx);
     if (!state) return fail(ARVX_ERR_INVALID, "null state");
-    if (int mrc = need_bytes(ctx)) return mrc;
+    if (int mrc = records_into_bytes(ctx, ctx->z0 - ctx->ze0, ctx->z1 - ctx->z0)) return mrc;
     ARVX_HIP(hipMemcpyAsync(state, ctx->owned(), ctx->nvox, hipMemcpyDeviceToHost, ctx->stream));
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
     return ARVX_OK;
@@ -696,8 +703,7 @@ int arvx_state_upload_planes(arvx_ctx *ctx, const uint32_t *occ, const uint32_t 
     ARVX_CHECK_CTX(ctx);
     if (!occ || !seen) return fail(ARVX_ERR_INVALID, "null plane");
     if (int mrc = need_rec(ctx)) return mrc;  // (halo planes keep what they hold)
-    ctx->color_ready = false;
-    ctx->closure_ready = false;
+    state_changes(ctx, false);
     const int nz = ctx->z1 - ctx->z0;
     const size_t nwords = (size_t)((ctx->X + 31) / 32) * ctx->Y * nz;
     if (int rc = ensure_scratch(ctx, 2 * nwords * sizeof(uint32_t) + 64)) return rc;
@@ -710,7 +716,6 @@ int arvx_state_upload_planes(arvx_ctx *ctx, const uint32_t *occ, const uint32_t 
     hipLaunchKernelGGL(arvx::rec_from_planes_kernel, dim3((unsigned)((nwords + 255) / 256)),
                        dim3(256), 0, ctx->stream, g, ctx->z0 - ctx->ze0, nz, d_occ, d_seen);
     ARVX_HIP(hipGetLastError());
-    ctx->bytes_valid = false;
     ARVX_HIP(hipStreamSynchronize(ctx->stream));  // the host planes may go away
     return ARVX_OK;
 }
@@ -738,14 +743,13 @@ int arvx_state_download_planes(arvx_ctx *ctx, uint32_t *occ, uint32_t *seen) {
 int arvx_handle_unseen(arvx_ctx *ctx) {
     ARVX_CHECK_CTX(ctx);
     if (int mrc = need_rec(ctx)) return mrc;
-    ctx->closure_ready = false;
+    ctx->closure_ready = false;  // (colours and paint stay: only never-seen voxels change)
     arvx::CarveParams g;
     carve_geometry(ctx, g);
     const size_t nrec = arvx::rec_count(g);
     hipLaunchKernelGGL(arvx::rec_handle_unseen_kernel, dim3((unsigned)((nrec * 32 + 255) / 256)),
                        dim3(256), 0, ctx->stream, (uint32_t *)ctx->d_rec, nrec);
     ARVX_HIP(hipGetLastError());
-    ctx->bytes_valid = false;
     return ARVX_OK;
 }
 
@@ -764,7 +768,7 @@ int arvx_host_unregister(void *ptr) {
 int arvx_state_device_ptr(arvx_ctx *ctx, void **ptr, size_t *bytes) {
     if (!ctx || !ptr) return fail(ARVX_ERR_INVALID, "null argument");
     ARVX_HIP(hipSetDevice(ctx->device));
-    if (int mrc = need_bytes(ctx)) return mrc;
+    if (int mrc = records_into_bytes(ctx, ctx->z0 - ctx->ze0, ctx->z1 - ctx->z0)) return mrc;
     *ptr = ctx->owned();
     if (bytes) *bytes = ctx->nvox;
     return ARVX_OK;
@@ -774,7 +778,7 @@ int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
     ARVX_CHECK_CTX(ctx);
     ExchangeStreamScope exchange_scope(ctx);
     if (!dev_words) return fail(ARVX_ERR_INVALID, "null dev_words");
-    if (ctx->X % 32 == 0 && (uintptr_t)dev_words % 4 == 0 && (ctx->rec_valid || !ctx->bytes_valid)) {
+    if (ctx->X % 32 == 0 && (uintptr_t)dev_words % 4 == 0) {
         // straight from the records: 2 bits per voxel in, 1 out
         if (int mrc = need_rec(ctx)) return mrc;
         arvx::CarveParams g;
@@ -788,8 +792,7 @@ int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
         ARVX_HIP(hipGetLastError());
         return ARVX_OK;
     }
-    if (ctx->X % 8 == 0 && ((size_t)ctx->X * ctx->Y) % 32 == 0 && (uintptr_t)dev_words % 4 == 0 &&
-        (ctx->rec_valid || !ctx->bytes_valid)) {
+    if (ctx->X % 8 == 0 && ((size_t)ctx->X * ctx->Y) % 32 == 0 && (uintptr_t)dev_words % 4 == 0) {
         if (int mrc = need_rec(ctx)) return mrc;
         arvx::CarveParams g;
         carve_geometry(ctx, g);
@@ -802,7 +805,8 @@ int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
         ARVX_HIP(hipGetLastError());
         return ARVX_OK;
     }
-    if (int mrc = need_bytes(ctx)) return mrc;
+    // odd row lengths: through the byte form
+    if (int mrc = records_into_bytes(ctx, ctx->z0 - ctx->ze0, ctx->z1 - ctx->z0)) return mrc;
     if (ctx->nvox % 32 == 0 && (uintptr_t)ctx->owned() % 16 == 0 && (uintptr_t)dev_words % 4 == 0) {
         const size_t nwords = ctx->nvox / 32;
         hipLaunchKernelGGL(arvx::pack_occupancy32_kernel, dim3((unsigned)((nwords + 255) / 256)),
@@ -827,7 +831,7 @@ int arvx_pack_occupancy_global(arvx_ctx *ctx, void *dev_global_words) {
     if (!dev_global_words) return fail(ARVX_ERR_INVALID, "null dev_global_words");
     const size_t plane = (size_t)ctx->X * ctx->Y;
     if (plane % 64) return fail(ARVX_ERR_INVALID, "X*Y must be a multiple of 64");
-    if (ctx->X % 32 == 0 && (ctx->rec_valid || !ctx->bytes_valid)) {
+    if (ctx->X % 32 == 0) {
         if (int mrc = need_rec(ctx)) return mrc;
         arvx::CarveParams g;
         carve_geometry(ctx, g);
@@ -840,7 +844,7 @@ int arvx_pack_occupancy_global(arvx_ctx *ctx, void *dev_global_words) {
         ARVX_HIP(hipGetLastError());
         return ARVX_OK;
     }
-    if (ctx->X % 8 == 0 && (ctx->rec_valid || !ctx->bytes_valid)) {  // (X * Y % 64 == 0 above)
+    if (ctx->X % 8 == 0) {  // (X * Y % 64 == 0 above)
         if (int mrc = need_rec(ctx)) return mrc;
         arvx::CarveParams g;
         carve_geometry(ctx, g);
@@ -853,7 +857,7 @@ int arvx_pack_occupancy_global(arvx_ctx *ctx, void *dev_global_words) {
         ARVX_HIP(hipGetLastError());
         return ARVX_OK;
     }
-    if (int mrc = need_bytes(ctx)) return mrc;
+    if (int mrc = records_into_bytes(ctx, ctx->z0 - ctx->ze0, ctx->z1 - ctx->z0)) return mrc;
     // plane % 64 == 0 and an aligned allocation: every plane starts on an 8-byte boundary
     const size_t nbytes = ctx->nvox / 8;
     hipLaunchKernelGGL(arvx::pack_occupancy_global8_kernel, dim3((unsigned)((nbytes + 255) / 256)),
@@ -881,10 +885,12 @@ int arvx_occupancy_compress(arvx_ctx *ctx, const void *dev_words, int64_t n_word
         return fail(ARVX_ERR_INVALID, "buffers must be 8-byte aligned");
     const long long n = n_words64, nb = (n + 63) / 64;
     const int nwg = (int)((nb + arvx::kOccGroupsPerWg - 1) / arvx::kOccGroupsPerWg);
-    if (int rc = ensure_scratch(ctx, (size_t)(nwg + 1) * sizeof(long long) +
-                                         (size_t)nwg * sizeof(int) + 64))
-        return rc;
-    long long *d_wgoff = (long long *)ctx->d_scratch;  // nwg + 1 offsets, last = total
+    // a buffer of its own: this call may run on the exchange stream beside the views / carve of
+    // the next job, whose tables live in d_scratch (arvx_ctx_set_exchange_stream).  Growing it
+    // frees the old one, which hipFree orders after everything the device has in flight.
+    ARVX_HIP(ctx->pool_xscratch.reserve((size_t)(nwg + 1) * sizeof(long long) +
+                                        (size_t)nwg * sizeof(int) + 64));
+    long long *d_wgoff = (long long *)ctx->pool_xscratch.p;  // nwg + 1 offsets, last = total
     int *d_wgsum = (int *)(d_wgoff + nwg + 1);
     hipLaunchKernelGGL(arvx::occ_classify_kernel, dim3(nwg), dim3(256), 0, ctx->stream,
                        (const unsigned long long *)dev_words, n, (unsigned long long *)dev_packet,
@@ -978,6 +984,7 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         if (ctx->ncu <= 0) ctx->ncu = 256;
     }
     const int ncu = ctx->ncu;
+    size_t layout_when_done = 0;
     if (cull) {
         const size_t words = ncoarse * p.nchunks;
         // coarse masks | coarse codes | undecided list | two list counters
@@ -1018,7 +1025,10 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
             p.undecidedCount = lst + 64 * (ctx->carve_seq & 1);
             p.undecidedCountNext = lst + 64 * ((ctx->carve_seq + 1) & 1);
             p.undecidedList = lst + 2 * 64;
-            ++ctx->carve_seq;
+            // (carve_seq advances once all launches of this carve are enqueued; a failure in
+            // between leaves the layout unset, so that the next carve zeroes both counters)
+            ctx->carve_layout = 0;
+            layout_when_done = need;
             int *base = (int *)((uint8_t *)ctx->d_coarse + off_work);
             p.workCount = base;
             p.poolNext = base + nctr;
@@ -1074,6 +1084,8 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         else
             hipLaunchKernelGGL(arvx::carve_exact_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, p);
         ARVX_HIP(hipGetLastError());
+        ctx->carve_layout = layout_when_done;
+        ++ctx->carve_seq;
         return ARVX_OK;
     }
 #ifdef ARVX_TIMELINE
@@ -1097,8 +1109,7 @@ int arvx_carve_views(arvx_ctx *ctx, int first, int count, unsigned flags) {
         return fail(ARVX_ERR_INVALID, "view range [%d,%d) outside [0,%d)", first, first + count,
                     ctx->V);
     if (count == 0) return ARVX_OK;
-    ctx->color_ready = false;
-    ctx->closure_ready = false;
+    state_changes(ctx, false);
     const bool fresh = ctx->fresh_pending;
     if (fresh) {  // the kernels write every record of the grid; nothing is read
         void *buf = ctx->d_rec;
@@ -1109,7 +1120,6 @@ int arvx_carve_views(arvx_ctx *ctx, int first, int count, unsigned flags) {
     }
     ctx->fresh_pending = false;
     ctx->rec_valid = true;
-    ctx->bytes_valid = false;
     return launch_carve(ctx, ctx->d_rec, first, count, flags, fresh);
 }
 
@@ -1167,8 +1177,6 @@ int arvx_set_images(arvx_ctx *ctx, const uint8_t *const *images, size_t stride) 
 
 int arvx_color(arvx_ctx *ctx, int mode) {
     ARVX_CHECK_CTX(ctx);
-    if (!ctx->rec_valid)  // (a state that came in as bytes; records are used where they exist)
-        if (int mrc = need_bytes(ctx)) return mrc;
     if (!ctx->cameras_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
     if (!ctx->images_ready) return fail(ARVX_ERR_STATE, "arvx_set_images has not been called");
     if (!ctx->has_campos) return fail(ARVX_ERR_STATE, "arvx_set_views was given no campos");
@@ -1184,15 +1192,19 @@ int arvx_color(arvx_ctx *ctx, int mode) {
     const arvx::BitGrid gext{ctx->X, ctx->Y, Zext, XW}, gown{ctx->X, ctx->Y, Zown, XW};
     const size_t nw_ext = (size_t)XW * ctx->Y * Zext, nw_own = (size_t)XW * ctx->Y * Zown;
     const int nblk = (int)((nw_own + arvx::kBitChunk - 1) / arvx::kBitChunk);
-    if (int rc = ensure_scratch(ctx, (nw_ext + nw_own) * sizeof(unsigned long long) +
+    if (int rc = ensure_scratch(ctx, nw_ext * sizeof(unsigned long long) +
                                          (size_t)(nblk + 1) * sizeof(long long) +
                                          (size_t)nblk * sizeof(int) + 64))
         return rc;
+    // the surface plane stays with the context: with its ranks it is the index of the colour
+    // list (closure and mesh look colours up through it)
+    ARVX_HIP(ctx->pool_col_bits.reserve(nw_own * sizeof(unsigned long long)));
+    ARVX_HIP(ctx->pool_col_rank.reserve(nw_own * sizeof(int)));
     unsigned long long *d_occ = (unsigned long long *)ctx->d_scratch;
-    unsigned long long *d_surf = d_occ + nw_ext;
-    long long *d_off = (long long *)(d_surf + nw_own);
+    unsigned long long *d_surf = (unsigned long long *)ctx->pool_col_bits.p;
+    long long *d_off = (long long *)(d_occ + nw_ext);
     int *d_cnt = (int *)(d_off + nblk + 1);
-    if (int rc = launch_bit_pack<arvx::kBitOccupied>(ctx, gext, 0, d_occ)) return rc;
+    if (int rc = launch_bit_pack(ctx, gext, 0, 0, d_occ, nullptr)) return rc;
     hipLaunchKernelGGL(arvx::bit_surface_kernel, dim3((unsigned)((nw_own + 255) / 256)), dim3(256),
                        0, ctx->stream, d_occ, gext, ctx->z0 - ctx->ze0, Zown, d_surf);
     ARVX_HIP(hipGetLastError());
@@ -1208,7 +1220,8 @@ int arvx_color(arvx_ctx *ctx, int mode) {
         ctx->d_surf_depth = (float *)ctx->pool_surf_depth.p;
         ARVX_HIP(ctx->pool_surf_has.reserve((size_t)total));
         ctx->d_surf_has = (uint8_t *)ctx->pool_surf_has.p;
-        if (int rc = bit_compact_write(ctx, d_surf, nw_own, gown, d_off, ctx->d_surf_index))
+        if (int rc = bit_compact_write(ctx, d_surf, nw_own, gown, d_off, ctx->d_surf_index,
+                                       (int *)ctx->pool_col_rank.p))
             return rc;
         arvx::VoteParams vp;
         vp.index = ctx->d_surf_index;
@@ -1302,8 +1315,12 @@ int arvx_surface_depth_download(arvx_ctx *ctx, float *depth) {
 // Model::voxels of the owned voxels, built on the device in chunks and copied out.
 int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen) {
     ARVX_CHECK_CTX(ctx);
-    if (int mrc = need_bytes(ctx)) return mrc;
+    if (int mrc = need_rec(ctx)) return mrc;
     if (!rgba) return fail(ARVX_ERR_INVALID, "null rgba");
+    arvx::CarveParams g;
+    carve_geometry(ctx, g);
+    g.rec = ctx->d_rec;
+    const int zown = ctx->z0 - ctx->ze0;
     if (ctx->closure_ready && (apply_unseen != 0) != (ctx->closure_unseen != 0))
         return fail(ARVX_ERR_STATE, "arvx_closure was computed with apply_unseen=%d",
                     ctx->closure_unseen);
@@ -1315,8 +1332,8 @@ int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen) {
     for (size_t i0 = 0; i0 < ctx->nvox && rc == ARVX_OK; i0 += chunk) {
         const size_t n = std::min(chunk, ctx->nvox - i0);
         const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 16384);
-        hipLaunchKernelGGL(arvx::export_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream,
-                           ctx->owned(), i0, n, d_out, apply_unseen);
+        hipLaunchKernelGGL(arvx::export_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, g,
+                           zown, i0, n, paint_plane(ctx), d_out, apply_unseen);
         if (ctx->color_ready && ctx->surf_count > 0) {
             const auto &idx = ctx->h_surf_index;
             const long long first =
@@ -1329,8 +1346,8 @@ int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen) {
                 hipLaunchKernelGGL(arvx::export_scatter_kernel,
                                    dim3((unsigned)((last - first + 255) / 256)), dim3(256), 0,
                                    ctx->stream, ctx->d_surf_index, ctx->d_surf_rgb,
-                                   ctx->d_surf_has, first, last, ctx->owned(), i0, d_out,
-                                   apply_unseen);
+                                   ctx->d_surf_has, first, last, g, zown, paint_plane(ctx), i0,
+                                   d_out, apply_unseen);
         }
         if (ctx->closure_ready && ctx->clo_count > 0) {
             const auto &idx = ctx->h_clo_index;
@@ -1447,77 +1464,113 @@ int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const flo
                                 hipMemcpyHostToDevice, ctx->stream));
         ARVX_HIP(hipMemsetAsync(ctx->d_surf_depth, 0, (size_t)n * sizeof(float), ctx->stream));
         ARVX_HIP(hipMemsetAsync(ctx->d_surf_has, 1, (size_t)n, ctx->stream));
+        // the list's plane + ranks (what arvx_color leaves behind)
+        const int XW = (ctx->X + 63) / 64;
+        const arvx::BitGrid gown{ctx->X, ctx->Y, ctx->z1 - ctx->z0, XW};
+        const size_t nw = (size_t)XW * gown.Y * gown.Z;
+        const int nblk = (int)((nw + arvx::kBitChunk - 1) / arvx::kBitChunk);
+        ARVX_HIP(ctx->pool_col_bits.reserve(nw * sizeof(unsigned long long)));
+        ARVX_HIP(ctx->pool_col_rank.reserve(nw * sizeof(int)));
+        if (int rc = ensure_scratch(ctx, (size_t)(nblk + 1) * sizeof(long long) +
+                                             (size_t)nblk * sizeof(int) + 64))
+            return rc;
+        unsigned long long *bits = (unsigned long long *)ctx->pool_col_bits.p;
+        long long *d_off = (long long *)ctx->d_scratch;
+        int *d_cnt = (int *)(d_off + nblk + 1);
+        ARVX_HIP(hipMemsetAsync(bits, 0, nw * sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(arvx::bits_from_index_kernel, dim3((unsigned)((n + 255) / 256)),
+                           dim3(256), 0, ctx->stream, ctx->d_surf_index, (long long)n, gown, bits);
+        ARVX_HIP(hipGetLastError());
+        long long total = 0;
+        if (int rc = bit_compact_count(ctx, bits, nw, d_cnt, d_off, &total)) return rc;
+        if (int rc = bit_compact_write(ctx, bits, nw, gown, d_off, nullptr,
+                                       (int *)ctx->pool_col_rank.p))
+            return rc;
         ARVX_HIP(hipStreamSynchronize(ctx->stream));
     }
     ctx->color_ready = true;
     return ARVX_OK;
 }
 
+// the context's sparse lists as plane + rank (empty: nulls)
+static arvx::SparseList colour_list(const Ctx *ctx) {
+    if (!ctx->color_ready || ctx->surf_count <= 0) return arvx::SparseList{nullptr, nullptr};
+    return arvx::SparseList{(const unsigned long long *)ctx->pool_col_bits.p,
+                            (const int *)ctx->pool_col_rank.p};
+}
+static arvx::SparseList closure_list(const Ctx *ctx) {
+    if (!ctx->closure_ready || ctx->clo_count <= 0) return arvx::SparseList{nullptr, nullptr};
+    return arvx::SparseList{(const unsigned long long *)ctx->pool_clo_bits.p,
+                            (const int *)ctx->pool_clo_rank.p};
+}
+
 int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     ARVX_CHECK_CTX(ctx);
-    if (int mrc = own_bytes(ctx)) return mrc;  // closure_mark_kernel sets bits in the plane
     if (kernel_size < 1 || kernel_size % 2 != 1 || kernel_size > 9)
         return fail(ARVX_ERR_INVALID, "kernel size %d (odd, 1..9)", kernel_size);
     if (ctx->z0 != 0 || ctx->z1 != ctx->Z || ctx->stripe_world > 1)
         return fail(ARVX_ERR_STATE, "arvx_closure needs the whole grid in one context");
     if (ctx->closure_ready)
         return fail(ARVX_ERR_STATE, "closure already applied to this model state");
+    if (int mrc = need_rec(ctx)) return mrc;
     ctx->free_closure();
-    arvx::ClosureParams cp;
-    cp.state = ctx->d_state;
-    cp.X = ctx->X;
-    cp.Y = ctx->Y;
-    cp.Z = ctx->Z;
-    cp.radius = (kernel_size - 1) / 2;
-    cp.apply_unseen = apply_unseen ? 1 : 0;
-    cp.col_index = ctx->color_ready ? ctx->d_surf_index : nullptr;
-    cp.col_rgb = ctx->color_ready ? ctx->d_surf_rgb : nullptr;
-    cp.col_has = ctx->color_ready ? ctx->d_surf_has : nullptr;
-    cp.ncol = ctx->color_ready ? ctx->surf_count : 0;
     // filled = dilate(occupied, box of radius r) and not occupied, on bit planes
-    const int XW = (cp.X + 63) / 64;
-    const arvx::BitGrid g{cp.X, cp.Y, cp.Z, XW};
-    const size_t nwords = (size_t)XW * cp.Y * cp.Z;
+    const int XW = (ctx->X + 63) / 64;
+    const arvx::BitGrid g{ctx->X, ctx->Y, ctx->Z, XW};
+    const size_t nwords = (size_t)XW * g.Y * g.Z;
     const int nblk = (int)((nwords + arvx::kBitChunk - 1) / arvx::kBitChunk);
-    const size_t nrows = (size_t)cp.Y * cp.Z;
-    if (int rc = ensure_scratch(ctx, 3 * nwords * sizeof(unsigned long long) +
+    const int radius = (kernel_size - 1) / 2;
+    const bool paints = apply_unseen || ctx->paint_valid;  // somebody is UNSEEN_COLOR
+    if (int rc = ensure_scratch(ctx, 4 * nwords * sizeof(unsigned long long) +
                                          (size_t)(nblk + 1) * sizeof(long long) +
-                                         (size_t)(nblk + nrows + 1) * sizeof(int) + 64))
+                                         (size_t)nblk * sizeof(int) + 64))
         return rc;
+    ARVX_HIP(ctx->pool_clo_bits.reserve(nwords * sizeof(unsigned long long)));
+    ARVX_HIP(ctx->pool_clo_rank.reserve(nwords * sizeof(int)));
     unsigned long long *d_occ = (unsigned long long *)ctx->d_scratch;
-    unsigned long long *d_a = d_occ + nwords, *d_b = d_a + nwords;
+    unsigned long long *d_unseen = d_occ + nwords, *d_a = d_unseen + nwords, *d_b = d_a + nwords;
+    unsigned long long *d_fill = (unsigned long long *)ctx->pool_clo_bits.p;
     long long *d_off = (long long *)(d_b + nwords);
     int *d_cnt = (int *)(d_off + nblk + 1);
-    int *d_rows = d_cnt + nblk;
-    cp.row_start = d_rows;
-    hipLaunchKernelGGL(arvx::closure_rows_kernel, dim3((unsigned)((nrows + 256) / 256)), dim3(256),
-                       0, ctx->stream, cp.col_index, cp.ncol, cp.X, (long long)nrows, d_rows);
-    ARVX_HIP(hipGetLastError());
-    if (int rc = launch_bit_pack<arvx::kBitClosureOccupied>(ctx, g, cp.apply_unseen, d_occ))
+    if (int rc = launch_bit_pack(ctx, g, 1, apply_unseen ? 1 : 0, d_occ, paints ? d_unseen : nullptr))
         return rc;
     const unsigned gw = (unsigned)((nwords + 255) / 256);
     hipLaunchKernelGGL(arvx::bit_dilate_x_kernel, dim3(gw), dim3(256), 0, ctx->stream, d_occ, g,
-                       cp.radius, d_a);
+                       radius, d_a);
     hipLaunchKernelGGL(arvx::bit_dilate_yz_kernel, dim3(gw), dim3(256), 0, ctx->stream, d_a, g,
-                       cp.radius, 1, (const unsigned long long *)nullptr, d_b);
+                       radius, 1, (const unsigned long long *)nullptr, d_b);
     hipLaunchKernelGGL(arvx::bit_dilate_yz_kernel, dim3(gw), dim3(256), 0, ctx->stream, d_b, g,
-                       cp.radius, 2, (const unsigned long long *)d_occ, d_a);
+                       radius, 2, (const unsigned long long *)d_occ, d_fill);
     ARVX_HIP(hipGetLastError());
     long long total = 0;
-    if (int rc = bit_compact_count(ctx, d_a, nwords, d_cnt, d_off, &total)) return rc;
+    if (int rc = bit_compact_count(ctx, d_fill, nwords, d_cnt, d_off, &total)) return rc;
     ctx->clo_count = total;
     if (total > 0) {
         ARVX_HIP(ctx->pool_clo_index.reserve((size_t)total * sizeof(int)));
         ctx->d_clo_index = (int *)ctx->pool_clo_index.p;
         ARVX_HIP(ctx->pool_clo_rgba.reserve((size_t)total * sizeof(float4)));
         ctx->d_clo_rgba = (void *)ctx->pool_clo_rgba.p;
-        if (int rc = bit_compact_write(ctx, d_a, nwords, g, d_off, ctx->d_clo_index)) return rc;
+        if (int rc = bit_compact_write(ctx, d_fill, nwords, g, d_off, ctx->d_clo_index,
+                                       (int *)ctx->pool_clo_rank.p))
+            return rc;
+        arvx::ClosureParams cp;
+        cp.g = g;
+        cp.occ = d_occ;
+        cp.unseen = paints ? d_unseen : nullptr;
+        cp.radius = radius;
+        cp.col = colour_list(ctx);
+        cp.col_rgb = ctx->d_surf_rgb;
+        cp.col_has = ctx->d_surf_has;
         hipLaunchKernelGGL(arvx::closure_fill_kernel, dim3((unsigned)((total + 255) / 256)),
                            dim3(256), 0, ctx->stream, cp, ctx->d_clo_index, total,
                            (float4 *)ctx->d_clo_rgba);
         ARVX_HIP(hipGetLastError());
-        hipLaunchKernelGGL(arvx::closure_mark_kernel, dim3((unsigned)((total + 255) / 256)),
-                           dim3(256), 0, ctx->stream, ctx->d_state, ctx->d_clo_index, total);
+        // the filled voxels are occupied from now on (their w is count / count = 1)
+        arvx::CarveParams rp;
+        carve_geometry(ctx, rp);
+        rp.rec = ctx->d_rec;
+        hipLaunchKernelGGL(arvx::rec_or_bitgrid_kernel, dim3(gw), dim3(256), 0, ctx->stream, rp, 0,
+                           g.Z, d_fill);
         ARVX_HIP(hipGetLastError());
         ctx->h_clo_index.resize((size_t)total);
         ARVX_HIP(hipMemcpyAsync(ctx->h_clo_index.data(), ctx->d_clo_index,
@@ -1525,7 +1578,7 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
         ARVX_HIP(hipStreamSynchronize(ctx->stream));
     }
     ctx->closure_ready = true;
-    ctx->closure_unseen = cp.apply_unseen;
+    ctx->closure_unseen = apply_unseen ? 1 : 0;
     return ARVX_OK;
 }
 
@@ -1554,12 +1607,11 @@ int arvx_closure_download(arvx_ctx *ctx, int64_t *index, float *rgba) {
 int arvx_mc_cells(arvx_ctx *ctx, int64_t *count) {
     ARVX_CHECK_CTX(ctx);
     if (!count) return fail(ARVX_ERR_INVALID, "null argument");
-    if (int mrc = need_bytes(ctx)) return mrc;
+    if (int mrc = need_rec(ctx)) return mrc;
     if (ctx->stripe_world > 1)
         return fail(ARVX_ERR_STATE, "the cell walk needs contiguous slabs (neighbour planes)");
     ctx->free_mc();
     arvx::McParams mp;
-    mp.state = ctx->d_state;
     mp.X = ctx->X;
     mp.Y = ctx->Y;
     mp.Z = ctx->Z;
@@ -1582,13 +1634,15 @@ int arvx_mc_cells(arvx_ctx *ctx, int64_t *count) {
     long long *d_boff = d_off + ncol;                   // nsb + 1 block offsets, last = total
     int *d_cnt = (int *)(d_boff + nsb + 1);
     int *d_bsum = d_cnt + ncol;
-    if (ctx->X % 4 == 0)
-        hipLaunchKernelGGL(arvx::mc_zpack_kernel<4>, dim3((unsigned)((nzw / 4 + 255) / 256)),
-                           dim3(256), 0, ctx->stream, mp);
-    else
-        hipLaunchKernelGGL(arvx::mc_zpack_kernel<1>, dim3((unsigned)((nzw + 255) / 256)), dim3(256),
-                           0, ctx->stream, mp);
-    ARVX_HIP(hipGetLastError());
+    {
+        arvx::CarveParams g;
+        carve_geometry(ctx, g);
+        g.rec = ctx->d_rec;
+        hipLaunchKernelGGL(arvx::mc_zpack_rec_kernel,
+                           dim3((unsigned)((size_t)g.tilesX * g.tilesY * mp.ZW)), dim3(256), 0,
+                           ctx->stream, g, mp);
+        ARVX_HIP(hipGetLastError());
+    }
     const unsigned nblk = (unsigned)((ncol + 255) / 256);
     hipLaunchKernelGGL(arvx::mc_count_kernel, dim3(nblk), dim3(256), 0, ctx->stream, mp, d_cnt);
     ARVX_HIP(hipGetLastError());
@@ -1669,18 +1723,15 @@ int arvx_mc_mesh(arvx_ctx *ctx, int apply_unseen, int64_t *triangles) {
         ARVX_HIP(ctx->pool_mesh_verts.reserve((size_t)total * 9 * sizeof(float)));
         ARVX_HIP(ctx->pool_mesh_rgb.reserve((size_t)total * 3 * sizeof(unsigned)));
         arvx::McMeshParams mp;
-        mp.state = ctx->d_state;  // (arvx_mc_cells made the byte plane current)
-        mp.X = ctx->X;
-        mp.Y = ctx->Y;
-        mp.Z = ctx->Z;
+        carve_geometry(ctx, mp.g);
+        mp.g.rec = ctx->d_rec;
+        mp.paint = paint_plane(ctx);
         mp.apply_unseen = apply_unseen ? 1 : 0;
-        mp.col_index = ctx->color_ready ? ctx->d_surf_index : nullptr;
-        mp.col_rgb = ctx->color_ready ? ctx->d_surf_rgb : nullptr;
-        mp.col_has = ctx->color_ready ? ctx->d_surf_has : nullptr;
-        mp.ncol = ctx->color_ready ? ctx->surf_count : 0;
-        mp.clo_index = ctx->closure_ready ? ctx->d_clo_index : nullptr;
-        mp.clo_rgba = ctx->closure_ready ? (const float4 *)ctx->d_clo_rgba : nullptr;
-        mp.nclo = ctx->closure_ready ? ctx->clo_count : 0;
+        mp.col = colour_list(ctx);
+        mp.col_rgb = ctx->d_surf_rgb;
+        mp.col_has = ctx->d_surf_has;
+        mp.clo = closure_list(ctx);
+        mp.clo_rgba = (const float4 *)ctx->d_clo_rgba;
         hipLaunchKernelGGL(arvx::mc_mesh_kernel, dim3(nblk), dim3(256), 0, ctx->stream, mp,
                            (const int4 *)ctx->d_mc_cells, (long long)n, d_off,
                            (float *)ctx->pool_mesh_verts.p, (unsigned *)ctx->pool_mesh_rgb.p);
@@ -1712,8 +1763,7 @@ int arvx_fast_carve(arvx_ctx *ctx) {
     if (ctx->z0 != 0 || ctx->z1 != ctx->Z || ctx->stripe_world > 1)
         return fail(ARVX_ERR_STATE,
                     "arvx_fast_carve needs the whole grid in one context (connectivity is global)");
-    ctx->color_ready = false;
-    ctx->closure_ready = false;
+    state_changes(ctx, false);
     arvx::FloodParams fp;
     // a fresh model (the usual case: src/main.cpp calls fastCarve on a new Model) is neither
     // filled nor read: the kernels know its records, and flood_apply_rec_kernel writes them all
@@ -1820,7 +1870,6 @@ int arvx_fast_carve(arvx_ctx *ctx) {
     ARVX_HIP(hipGetLastError());
     ctx->fresh_pending = false;  // the records now hold every voxel's state
     ctx->rec_valid = true;
-    ctx->bytes_valid = false;
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
     return ARVX_OK;
 }

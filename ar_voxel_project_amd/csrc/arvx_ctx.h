@@ -54,15 +54,18 @@ struct Ctx {
     hipStream_t stream = nullptr;
     hipStream_t xstream = nullptr;  // arvx_ctx_set_exchange_stream: the occupancy hand-off (null: stream)
 
-    // The state lives in one of two forms (csrc/arvx_device.h): sub-tile RECORDS, 2 bits per
-    // voxel -- what the carve kernels read and write --, and the one-byte-per-voxel plane of
-    // the C-ABI, allocated and converted on demand for the calls that exchange bytes.
+    // The state lives in sub-tile RECORDS (csrc/arvx_device.h), 2 bits per voxel: what every
+    // stage reads and writes.  The one-byte-per-voxel plane of the C-ABI (arvx_state_upload /
+    // _download / _device_ptr) is a staging buffer, allocated on demand and converted from / to
+    // the records inside those calls; bit2 of uploaded bytes (voxel painted UNSEEN_COLOR by a
+    // host Model) is kept beside the records as one bit plane (`paint`).
     uint16_t *d_rec = nullptr;   // records of planes ze0..ze1-1 (+ padding to whole coarse tiles)
     size_t rec_bytes = 0;
-    bool rec_valid = false;      // d_rec holds the current state
-    uint8_t *d_state = nullptr;  // byte plane, planes ze0..ze1-1 (lazy)
-    bool bytes_valid = false;    // d_state holds the current state
+    bool rec_valid = false;      // d_rec holds the current state (else: fresh_pending)
+    uint8_t *d_state = nullptr;  // byte staging, planes ze0..ze1-1 (lazy)
     uint8_t *owned() const { return d_state + (size_t)(z0 - ze0) * X * Y; }
+    DevPool pool_paint;          // bit plane (bitplane_kernels.h layout) over planes ze0..ze1-1
+    bool paint_valid = false;    // some voxel is painted: the plane takes part in the stages
     int ncu = 0;                 // compute units of the device (cached)
     int carve_seq = 0;           // parity of the undecided-list counters (carve_coarse_kernel)
     size_t carve_layout = 0;     // d_coarse layout those counters were zeroed for
@@ -75,8 +78,11 @@ struct Ctx {
     void *d_coarse = nullptr;    // coarse pre-pass masks of the carve kernel
     size_t coarse_bytes = 0;
     unsigned long long *d_stats = nullptr;
-    void *d_scratch = nullptr;
+    void *d_scratch = nullptr;  // work buffer of the calls on `stream`
     size_t scratch_bytes = 0;
+    // work buffer of the hand-off calls (arvx_occupancy_compress): they may run on `xstream`
+    // BESIDE a set_views / carve on `stream`, so they never touch d_scratch
+    DevPool pool_xscratch;
     void *d_flood = nullptr;  // work buffer of arvx_fast_carve, kept between calls
     size_t flood_bytes = 0;
 
@@ -104,6 +110,8 @@ struct Ctx {
     std::vector<int> h_surf_index;    // host copy (ascending)
     std::vector<uint8_t> h_surf_has;
     bool color_ready = false;
+    // the list as plane + rank (bitplane_kernels.h, sparse_find) over the owned planes
+    DevPool pool_col_bits, pool_col_rank;
 
     // closure (dilation) result: filled voxels, ascending index
     int *d_clo_index = nullptr;
@@ -112,6 +120,7 @@ struct Ctx {
     bool closure_ready = false;
     int closure_unseen = 0;
     std::vector<int> h_clo_index;
+    DevPool pool_clo_bits, pool_clo_rank;  // the filled voxels as plane + rank
 
     // marching-cubes hand-off: active cells (x, y, z, cube index), reference order
     void *d_mc_cells = nullptr;
@@ -132,6 +141,12 @@ struct Ctx {
         pool_raw_masks.release();
         pool_mesh_verts.release();
         pool_mesh_rgb.release();
+        pool_xscratch.release();
+        pool_paint.release();
+        pool_col_bits.release();
+        pool_col_rank.release();
+        pool_clo_bits.release();
+        pool_clo_rank.release();
     }
     void free_mc() {
         d_mc_cells = nullptr;

@@ -62,7 +62,36 @@ struct arvx_mgpu {
     int64_t cap64 = 0, packet_words = 0;
     std::vector<Rank> r;
     float carve_ms = 0.f, merge_ms = 0.f;
+    // a collective was enqueued on some devices and not on others (an error in the middle of a
+    // group): the communicators cannot be trusted any more, every later carve is refused
+    bool broken = false;
 };
+
+namespace {
+// ncclGroupStart ... ncclGroupEnd around the per-device calls of ONE collective: the group is
+// always closed, and a failure inside it marks the handle unusable instead of leaving some
+// devices waiting in a collective the others never entered.
+template <class PerRank>
+int grouped(arvx_mgpu *m, PerRank per_rank) {
+    ncclResult_t r = ncclGroupStart();
+    if (r != ncclSuccess)
+        return fail(ARVX_ERR_RCCL, std::string("ncclGroupStart: ") + ncclGetErrorString(r));
+    ncclResult_t bad = ncclSuccess;
+    for (Rank &k : m->r) {
+        bad = per_rank(k);
+        if (bad != ncclSuccess) break;
+    }
+    r = ncclGroupEnd();
+    if (bad != ncclSuccess || r != ncclSuccess) {
+        m->broken = true;
+        for (Rank &k : m->r)
+            if (k.comm) (void)ncclCommAbort(k.comm), k.comm = nullptr;
+        return fail(ARVX_ERR_RCCL, std::string("collective failed (handle is unusable now): ") +
+                                       ncclGetErrorString(bad != ncclSuccess ? bad : r));
+    }
+    return ARVX_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -204,12 +233,10 @@ static int merge_allreduce(arvx_mgpu *m) {
         MG_HIP(hipMemsetAsync(k.d_full, 0, m->full_words * 4, k.stream));
         MG_ARVX(arvx_pack_occupancy_global(k.ctx, k.d_full));
     }
-    MG_NCCL(ncclGroupStart());
-    for (Rank &k : m->r)
-        MG_NCCL(ncclAllReduce(k.d_full, k.d_full, m->full_words, ncclInt32, ncclSum, k.comm,
-                              k.stream));
-    MG_NCCL(ncclGroupEnd());
-    return ARVX_OK;
+    return grouped(m, [&](Rank &k) {
+        return ncclAllReduce(k.d_full, k.d_full, m->full_words, ncclInt32, ncclSum, k.comm,
+                             k.stream);
+    });
 }
 
 int arvx_mgpu_carve(arvx_mgpu *m, unsigned flags, int merge, int *fell_back) {
@@ -217,6 +244,8 @@ int arvx_mgpu_carve(arvx_mgpu *m, unsigned flags, int merge, int *fell_back) {
     if (merge != ARVX_MERGE_ALLREDUCE && merge != ARVX_MERGE_COMPRESSED)
         return fail(ARVX_ERR_INVALID, "unknown merge");
     if (fell_back) *fell_back = 0;
+    if (m->broken)
+        return fail(ARVX_ERR_RCCL, "an earlier collective failed half-way: destroy this handle");
     for (Rank &k : m->r) {  // all devices carve at once: the calls only enqueue
         MG_HIP(hipSetDevice(k.device));
         MG_HIP(hipEventRecord(k.e0, k.stream));
@@ -235,11 +264,11 @@ int arvx_mgpu_carve(arvx_mgpu *m, unsigned flags, int merge, int *fell_back) {
             MG_ARVX(arvx_occupancy_compress(k.ctx, k.d_local, (int64_t)m->local_words64, k.d_packet,
                                             m->cap64));
         }
-        MG_NCCL(ncclGroupStart());
-        for (Rank &k : m->r)
-            MG_NCCL(ncclAllGather(k.d_packet, k.d_packets, (size_t)m->packet_words, ncclUint64,
-                                  k.comm, k.stream));
-        MG_NCCL(ncclGroupEnd());
+        if (int rc = grouped(m, [&](Rank &k) {
+                return ncclAllGather(k.d_packet, k.d_packets, (size_t)m->packet_words, ncclUint64,
+                                     k.comm, k.stream);
+            }))
+            return rc;
         for (Rank &k : m->r) {
             MG_HIP(hipSetDevice(k.device));
             MG_ARVX(arvx_occupancy_expand_striped(k.ctx, k.d_packets, m->n,

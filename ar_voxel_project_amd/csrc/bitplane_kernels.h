@@ -6,7 +6,14 @@
 // Layout: a voxel row (fixed y,z) is XW = ceil(X/64) 64-bit words, voxel x at bit
 // x%64 of word x/64; bits past X are zero.  Rows follow each other in (z, y)
 // order, so ascending word/bit order is ascending flat index x + X*(y + Y*z).
-// A 512^3 plane is 16 MiB and stays in L2; the byte plane is read once to build it.
+// A 512^3 plane is 16 MiB and stays in L2; the planes are built from the state records
+// (state_kernels.h, bitgrid_from_rec_kernel).
+//
+// A sparse per-voxel list (the colour pass's colours, the closure's filled voxels) is the ordered
+// compaction of such a plane: entry k belongs to the k-th set bit.  Next to the plane the
+// context keeps `rank`, one int per word = number of set bits before that word, so that the
+// list position of a voxel is rank[word] + popcount(bits below it): one lookup instead of a
+// binary search (sparse_find).
 #pragma once
 
 #include "arvx_device.h"
@@ -17,89 +24,6 @@ struct BitGrid {
     int X, Y, Z;  // Z = planes held in this bit plane
     int XW;
 };
-
-enum BitPred {
-    kBitOccupied = 0,  // state bit0
-    // what the closure calls occupied: bit0, or painted UNSEEN_COLOR (bit2 from a host
-    // Model; or never seen when handleUnseen ran before: w = 1, src/Model.cpp:42)
-    kBitClosureOccupied = 1,
-};
-
-// predicate on 8 state bytes at once -> 0x01 in every byte that satisfies it
-template <int PRED>
-__device__ __forceinline__ unsigned long long bit_pred8(unsigned long long s, int apply_unseen) {
-    const unsigned long long one = 0x0101010101010101ull;
-    if (PRED == kBitOccupied) return s & one;
-    unsigned long long m = s | (s >> 2);
-    if (apply_unseen) m |= ~(s >> 1);
-    return m & one;
-}
-template <int PRED>
-__device__ __forceinline__ bool bit_pred1(uint8_t s, int apply_unseen) {
-    if (PRED == kBitOccupied) return s & 1u;
-    return (s & 1u) || (s & 4u) || (apply_unseen && !(s & 2u));
-}
-
-// X % 8 == 0: one thread turns 8 voxels into one byte of the plane (8-byte load)
-template <int PRED>
-__global__ __launch_bounds__(256) void bit_pack8_kernel(const uint8_t *__restrict__ state,
-                                                        const BitGrid g, int apply_unseen,
-                                                        unsigned long long *__restrict__ bits) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int rowBytes = g.XW * 8;
-    const size_t nrows = (size_t)g.Y * g.Z;
-    if (t >= nrows * rowBytes) return;
-    const size_t row = t / rowBytes;
-    const int b8 = (int)(t % rowBytes);
-    uint8_t b = 0;
-    if (b8 * 8 < g.X) {
-        const unsigned long long s =
-            *(const unsigned long long *)(state + row * g.X + (size_t)b8 * 8);
-        // byte j's bit 0 -> bit j
-        b = (uint8_t)((bit_pred8<PRED>(s, apply_unseen) * 0x0102040810204080ull) >> 56);
-    }
-    ((uint8_t *)bits)[t] = b;
-}
-
-// X % 32 == 0 and a 16-byte aligned plane: one thread turns 32 voxels into one 32-bit half of
-// a word of the plane (two 16-byte loads)
-template <int PRED>
-__global__ __launch_bounds__(256) void bit_pack32_kernel(const uint8_t *__restrict__ state,
-                                                         const BitGrid g, int apply_unseen,
-                                                         unsigned long long *__restrict__ bits) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int rowHalves = g.XW * 2;
-    const size_t nrows = (size_t)g.Y * g.Z;
-    if (t >= nrows * rowHalves) return;
-    const size_t row = t / rowHalves;
-    const int h = (int)(t % rowHalves);
-    uint32_t w = 0;
-    if (h * 32 < g.X) {
-        const ulonglong2 *src = (const ulonglong2 *)(state + row * g.X + (size_t)h * 32);
-        const ulonglong2 a = src[0], b = src[1];
-        const unsigned long long mul = 0x0102040810204080ull;
-        w = (uint32_t)((bit_pred8<PRED>(a.x, apply_unseen) * mul) >> 56) |
-            ((uint32_t)((bit_pred8<PRED>(a.y, apply_unseen) * mul) >> 56) << 8) |
-            ((uint32_t)((bit_pred8<PRED>(b.x, apply_unseen) * mul) >> 56) << 16) |
-            ((uint32_t)((bit_pred8<PRED>(b.y, apply_unseen) * mul) >> 56) << 24);
-    }
-    ((uint32_t *)bits)[t] = w;
-}
-
-// any X: one wave per word
-template <int PRED>
-__global__ __launch_bounds__(256) void bit_pack_kernel(const uint8_t *__restrict__ state,
-                                                       const BitGrid g, int apply_unseen,
-                                                       unsigned long long *__restrict__ bits) {
-    const size_t wv = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const size_t nrows = (size_t)g.Y * g.Z;
-    if (wv >= nrows * g.XW) return;
-    const size_t row = wv / g.XW;
-    const int x = (int)(wv % g.XW) * 64 + (threadIdx.x & 63);
-    const bool o = (x < g.X) && bit_pred1<PRED>(state[row * g.X + x], apply_unseen);
-    const unsigned long long b = __ballot(o);
-    if ((threadIdx.x & 63) == 0) bits[wv] = b;
-}
 
 __device__ __forceinline__ unsigned long long bit_word(const unsigned long long *bits,
                                                        const BitGrid &g, int xw, int y, int z) {
@@ -183,11 +107,13 @@ __global__ __launch_bounds__(256) void bit_count_kernel(const unsigned long long
     if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// index[k] = flat index (x + X*row) of the k-th set bit, ascending
+// index[k] = flat index (x + X*row) of the k-th set bit, ascending; rank[w] = set bits before
+// word w.  Either output may be null.
 __global__ __launch_bounds__(256) void bit_write_kernel(const unsigned long long *__restrict__ bits,
                                                         size_t nwords, const BitGrid g,
                                                         const long long *__restrict__ offsets,
-                                                        int *__restrict__ index) {
+                                                        int *__restrict__ index,
+                                                        int *__restrict__ rank) {
     __shared__ int wtot[4];
     const size_t base = (size_t)blockIdx.x * kBitChunk;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -206,7 +132,8 @@ __global__ __launch_bounds__(256) void bit_write_kernel(const unsigned long long
         __syncthreads();
         long long slot = run + sc - n;
         for (int v = 0; v < wave; ++v) slot += wtot[v];
-        if (b) {
+        if (rank && w < nwords) rank[w] = (int)slot;
+        if (b && index) {
             const size_t row = w / g.XW;
             const int x0 = (int)(w % g.XW) * 64;
             const int first = (int)(row * g.X) + x0;
@@ -218,6 +145,33 @@ __global__ __launch_bounds__(256) void bit_write_kernel(const unsigned long long
         run += wtot[0] + wtot[1] + wtot[2] + wtot[3];
         __syncthreads();
     }
+}
+
+// the plane of a list that came from the host (arvx_colors_upload): bit index[k] set
+__global__ __launch_bounds__(256) void bits_from_index_kernel(const int *__restrict__ index,
+                                                              long long n, const BitGrid g,
+                                                              unsigned long long *__restrict__ bits) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int i = index[k];
+    const int x = i % g.X;
+    const size_t row = (size_t)(i / g.X);
+    atomicOr(bits + row * g.XW + (x >> 6), 1ull << (x & 63));
+}
+
+// a sparse list as plane + rank (null plane: empty list)
+struct SparseList {
+    const unsigned long long *bits;
+    const int *rank;
+};
+// position of voxel (x, row) in the list, or -1
+__device__ __forceinline__ int sparse_find(const SparseList &l, int XW, int x, size_t row) {
+    if (!l.bits) return -1;
+    const size_t w = row * XW + (x >> 6);
+    const unsigned long long b = l.bits[w];
+    const int sh = x & 63;
+    if (!((b >> sh) & 1ull)) return -1;
+    return l.rank[w] + __popcll(b & ((1ull << sh) - 1ull));
 }
 
 }  // namespace arvx

@@ -1,4 +1,4 @@
-// color_kernels.h -- per-voxel colour vote and model export for gfx950.
+// color_kernels.h -- per-voxel colour vote for gfx950 (model export: state_kernels.h).
 //
 // Replaces the reference's colour pass: the `voxel_pass` loops of
 // src/ColorReconstruction.h:34-74 plus the bodies of reconstructClosestColor
@@ -123,33 +123,6 @@ __global__ __launch_bounds__(256) void color_vote_kernel(const VoteParams p) {
     p.rgb[3 * t] = o0;
     p.rgb[3 * t + 1] = o1;
     p.rgb[3 * t + 2] = o2;
-}
-
-// Model::voxels for owned voxels [i0, i0+n): MODEL_COLOR where occupied, zero
-// where carved (reference src/Model.cpp:9-14, src/VoxelCarving.cpp:52) and,
-// with apply_unseen, UNSEEN_COLOR where never seen (src/Model.cpp:36-47).
-__global__ __launch_bounds__(256) void export_fill_kernel(const uint8_t *__restrict__ state_own,
-                                                          size_t i0, size_t n,
-                                                          float4 *__restrict__ out,
-                                                          int apply_unseen) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
-        const uint8_t st = state_own[i0 + k];
-        float4 v = (st & 1u) ? make_float4(50.f, 168.f, 141.f, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (apply_unseen && !(st & 2u)) v = make_float4(204.f, 0.f, 0.f, 1.f);
-        out[k] = v;
-    }
-}
-
-__global__ __launch_bounds__(256) void export_scatter_kernel(
-    const int *__restrict__ index, const float *__restrict__ rgb, const uint8_t *__restrict__ has,
-    long long first, long long last, const uint8_t *__restrict__ state_own, size_t i0,
-    float4 *__restrict__ out, int apply_unseen) {
-    const long long e = first + (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= last || !has[e]) return;
-    const size_t i = (size_t)index[e];
-    if (apply_unseen && !(state_own[i] & 2u)) return;  // handleUnseen runs after colouring
-    out[i - i0] = make_float4(rgb[3 * e], rgb[3 * e + 1], rgb[3 * e + 2], 1.f);
 }
 
 }  // namespace arvx

@@ -10,7 +10,8 @@
 // src/VoxelCarving.cpp:67) "w < threshold" is "not occupied".
 //
 // The occupancy is first packed ALONG Z: one 64-bit word holds 64 consecutive planes
-// of one voxel column (mc_zpack_kernel; the byte plane is read once, coalesced).
+// of one voxel column (mc_zpack_rec_kernel: the state records are read once, whole records,
+// and transposed through LDS).
 // One lane then owns one (x,y) column of cells and walks it 64 cells at a time: the
 // eight corner bits of 64 cells are eight words (four voxel columns, each shifted by
 // 0 and 1 plane), "triangulates" is any & ~all, counting is a popcount.  Lanes run
@@ -24,9 +25,8 @@
 namespace arvx {
 
 struct McParams {
-    const uint8_t *state;  // planes ze0 .. ze1-1 of the grid
     int X, Y, Z;
-    int ze0, ze1;
+    int ze0, ze1;  // planes the context's records hold
     int cz0, cz1;  // cells with z in [cz0, cz1) are listed by this context
     // z-packed occupancy: word (w, y, x), bit b = voxel (x, y, cz0 + 64 w + b) occupied;
     // planes outside the grid are empty.  ZW words per column cover planes cz0 .. cz1.
@@ -34,42 +34,57 @@ struct McParams {
     int ZW;
 };
 
-// COLS = 4: a lane packs 4 neighbouring columns from dword loads (X % 4 == 0);
-// COLS = 1: one column from byte loads.
-template <int COLS>
-__global__ __launch_bounds__(256) void mc_zpack_kernel(const McParams p) {
-    const int xg = p.X / COLS;  // column groups per row
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (size_t)xg * p.Y * p.ZW) return;
-    const int gx = (int)(t % xg);
-    const int y = (int)((t / xg) % p.Y);
-    const int w = (int)(t / ((size_t)xg * p.Y));
-    const size_t plane = (size_t)p.X * p.Y;
-    const uint8_t *col = p.state + (size_t)y * p.X + (size_t)gx * COLS;
-    unsigned long long acc[COLS];
+// One workgroup per tile column (64 x 8 voxel columns) and word w: the occ halves of the (up
+// to) nine tiles that the word's 64 planes touch go to LDS -- whole 128-byte loads --, then
+// every thread assembles the words of two columns, one bit per plane.  Lanes of a wave run
+// along x, so the stores are whole rows of words.
+__global__ __launch_bounds__(256) void mc_zpack_rec_kernel(const CarveParams g, const McParams p) {
+    __shared__ uint16_t occ[9][4][66];  // [tile along z][sub-tile][entry]; 66: no bank conflicts
+    const int tx = blockIdx.x % g.tilesX, ty = (blockIdx.x / g.tilesX) % g.tilesY,
+              w = blockIdx.x / (g.tilesX * g.tilesY);
+    const int zbase = p.cz0 + 64 * w;  // global plane of bit 0
+    const int lbase = zbase - p.ze0;   // ... as a local plane of the records (may be negative)
+    const int tz_lo = (lbase >= 0 ? lbase : lbase - 7) / 8;  // floor
+    const int off = lbase - 8 * tz_lo;                        // 0..7
+    {
+        const int sub = threadIdx.x >> 6, r = threadIdx.x & 63;
 #pragma unroll
-    for (int c = 0; c < COLS; ++c) acc[c] = 0ull;
-    const int zbase = p.cz0 + 64 * w;
-#pragma clang loop vectorize(disable) unroll(disable)
-    for (int b0 = 0; b0 < 64; b0 += 16) {
-        unsigned v[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {  // 16 planes in flight; invalid planes read plane ze0
-            const int zg = zbase + b0 + k;
-            const bool ok = zg >= 0 && zg < p.Z && zg <= p.cz1;
-            const uint8_t *q = col + (size_t)((ok ? zg : p.ze0) - p.ze0) * plane;
-            const unsigned raw = (COLS == 4) ? *(const unsigned *)q : (unsigned)*q;
-            v[k] = ok ? raw : 0u;
+        for (int j = 0; j < 9; ++j) {
+            const int tz = tz_lo + j;
+            uint16_t e = 0;
+            if (tz >= 0 && tz < g.tilesZ) e = g.rec[rec_index(g, tx, ty, tz, sub) * kRecU16 + r];
+            occ[j][sub][r] = e;
         }
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-#pragma unroll
-            for (int c = 0; c < COLS; ++c)
-                acc[c] |= (unsigned long long)((v[k] >> (8 * c)) & 1u) << (b0 + k);
     }
-    unsigned long long *out = p.zbits + ((size_t)w * p.Y + y) * p.X + (size_t)gx * COLS;
+    __syncthreads();
+    // planes of this word that exist for this context: inside the grid and not above cz1
+    unsigned long long valid = ~0ull;
+    {
+        const int lo = zbase < 0 ? -zbase : 0;  // first valid bit
+        const int top = (p.Z - 1 < p.cz1 ? p.Z - 1 : p.cz1) - zbase;  // last valid bit
+        if (top < 0 || lo > 63) valid = 0ull;
+        else {
+            valid = (lo ? (~0ull << lo) : ~0ull);
+            if (top < 63) valid &= (1ull << (top + 1)) - 1ull;
+        }
+    }
 #pragma unroll
-    for (int c = 0; c < COLS; ++c) out[c] = acc[c];
+    for (int k = 0; k < 2; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        const int xl = c & 63, yl = c >> 6;
+        const int x = tx * kTileX + xl, y = ty * kTileY + yl;
+        if (x >= p.X || y >= p.Y) continue;
+        const int sub = xl >> 4, bit = xl & 15;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int b = 0; b < 32; ++b) {
+            const int l0 = off + b, l1 = off + 32 + b;
+            lo |= (((uint32_t)occ[l0 >> 3][sub][(l0 & 7) * 8 + yl] >> bit) & 1u) << b;
+            hi |= (((uint32_t)occ[l1 >> 3][sub][(l1 & 7) * 8 + yl] >> bit) & 1u) << b;
+        }
+        const unsigned long long word = ((unsigned long long)hi << 32 | lo) & valid;
+        p.zbits[((size_t)w * p.Y + y) * p.X + x] = word;
+    }
 }
 
 __device__ __forceinline__ bool mc_column_of_thread(const McParams &p, int &cx, int &cy) {

@@ -13,12 +13,15 @@
 //
 // A voxel's colour as Model::get would return it (src/main.cpp:262-299 order): UNSEEN_COLOR if
 // handleUnseen painted it, else the closure's mean colour if the closure filled it, else the
-// colour pass's result if it has one, else MODEL_COLOR.  The two sparse lists are sorted by flat
-// index: binary searches.
+// colour pass's result if it has one, else MODEL_COLOR.  The two sparse lists are ordered
+// compactions of bit planes the context keeps with per-word ranks (bitplane_kernels.h,
+// sparse_find): one lookup each; the voxel's seen bit comes straight from its record.
 #pragma once
 
 #include "arvx/mc_tables.hpp"
 #include "arvx_device.h"
+#include "bitplane_kernels.h"
+#include "state_kernels.h"
 
 namespace arvx {
 
@@ -41,42 +44,27 @@ constexpr McTriTable make_mc_tri_table() {
 __constant__ McTriTable kMcTri = make_mc_tri_table();
 
 struct McMeshParams {
-    const uint8_t *state;  // whole grid, bit0 occupied, bit1 seen, bit2 painted UNSEEN
-    int X, Y, Z;
+    CarveParams g;         // the state records (whole grid)
+    const unsigned long long *paint;  // voxels painted UNSEEN_COLOR by the host (null: none)
     int apply_unseen;      // never-seen voxels are painted UNSEEN_COLOR
-    const int *col_index;  // colour pass: ascending flat index, rgb, has-sample flag
+    SparseList col;        // colour pass: plane + rank, rgb, has-sample flag
     const float *col_rgb;
     const uint8_t *col_has;
-    long long ncol;
-    const int *clo_index;  // closure: ascending flat index, rgba
+    SparseList clo;        // closure: plane + rank, rgba
     const float4 *clo_rgba;
-    long long nclo;
 };
-
-__device__ __forceinline__ long long mc_find(const int *__restrict__ idx, long long n, int key) {
-    long long lo = 0, hi = n;
-    while (lo < hi) {
-        const long long mid = (lo + hi) >> 1;
-        if (idx[mid] < key) lo = mid + 1;
-        else hi = mid;
-    }
-    return (lo < n && idx[lo] == key) ? lo : -1;
-}
 
 // rgb of an occupied voxel
 __device__ inline float3 mc_voxel_rgb(const McMeshParams &p, int x, int y, int z) {
-    const int i = x + p.X * (y + p.Y * z);
-    const uint8_t st = p.state[i];
-    if ((st & 4u) || (p.apply_unseen && !(st & 2u))) return make_float3(204.f, 0.f, 0.f);
-    if (p.nclo) {
-        const long long k = mc_find(p.clo_index, p.nclo, i);
-        if (k >= 0) return make_float3(p.clo_rgba[k].x, p.clo_rgba[k].y, p.clo_rgba[k].z);
-    }
-    if (p.ncol) {
-        const long long k = mc_find(p.col_index, p.ncol, i);
-        if (k >= 0 && p.col_has[k])
-            return make_float3(p.col_rgb[3 * k], p.col_rgb[3 * k + 1], p.col_rgb[3 * k + 2]);
-    }
+    const int X = p.g.X, Y = p.g.Y, XW = (X + 63) >> 6;
+    if (plane_bit(p.paint, X, Y, x, y, z) || (p.apply_unseen && !(rec_state(p.g, x, y, z) & 2u)))
+        return make_float3(204.f, 0.f, 0.f);
+    const size_t row = (size_t)z * Y + y;
+    int k = sparse_find(p.clo, XW, x, row);
+    if (k >= 0) return make_float3(p.clo_rgba[k].x, p.clo_rgba[k].y, p.clo_rgba[k].z);
+    k = sparse_find(p.col, XW, x, row);
+    if (k >= 0 && p.col_has[k])
+        return make_float3(p.col_rgb[3 * k], p.col_rgb[3 * k + 1], p.col_rgb[3 * k + 2]);
     return make_float3(50.f, 168.f, 141.f);
 }
 

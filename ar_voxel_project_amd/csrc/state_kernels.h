@@ -17,15 +17,25 @@ __global__ __launch_bounds__(256) void rec_init_kernel(uint32_t *__restrict__ re
         rec32[i] = (i & 32) ? 0xffffffffu : 0u;  // 32 words occ, 32 words seen
 }
 
-// one workgroup per tile, one wave per sub-tile, lane = entry r = (z & 7) * 8 + (y & 7)
+// one workgroup per tile, one wave per sub-tile, lane = entry r = (z & 7) * 8 + (y & 7).
+// `bytes` holds the context's planes (plane 0 = local plane 0); only local planes
+// [zl0, zl0 + nz) are converted (an upload of the owned planes leaves the halo planes alone,
+// arvx_state_upload_halo converts one plane).  bit2 of a byte (painted UNSEEN_COLOR by a host
+// Model) has no place in a record: it goes to the `paint` bit plane (layout of
+// bitplane_kernels.h over the context's planes, XW = ceil(X / 64) words per row), and *any
+// is set when one was found.
 __global__ __launch_bounds__(256) void rec_from_bytes_kernel(const CarveParams p,
-                                                             const uint8_t *__restrict__ bytes) {
+                                                             const uint8_t *__restrict__ bytes,
+                                                             int zl0, int nz,
+                                                             unsigned long long *__restrict__ paint,
+                                                             int *__restrict__ any) {
     const int tx = blockIdx.x % p.tilesX, ty = (blockIdx.x / p.tilesX) % p.tilesY,
               tz = blockIdx.x / (p.tilesX * p.tilesY);
     const int wave = threadIdx.x >> 6, r = threadIdx.x & 63;
     const int x0 = tx * kTileX + wave * kSubX, y = ty * kTileY + (r & 7), z = tz * kTileZ + (r >> 3);
-    uint32_t occ = 0, seen = 0xffffu;
-    if (x0 < p.X && y < p.Y && z < p.Z) {
+    if (y >= p.Y || z < zl0 || z >= zl0 + nz || z >= p.Z) return;  // (outside the grid: kept "finished")
+    uint32_t occ = 0, seen = 0xffffu, pnt = 0;
+    if (x0 < p.X) {
         const uint8_t *src = bytes + ((size_t)z * p.Y + y) * p.X + x0;
         uint8_t b[16];
         if ((p.X & 15) == 0 && ((uintptr_t)bytes & 15u) == 0) {
@@ -39,25 +49,39 @@ __global__ __launch_bounds__(256) void rec_from_bytes_kernel(const CarveParams p
         for (int j = 0; j < 16; ++j) {
             occ |= (uint32_t)(b[j] & 1u) << j;
             seen |= (uint32_t)((b[j] >> 1) & 1u) << j;
+            pnt |= (uint32_t)((b[j] >> 2) & 1u) << j;
         }
+        uint16_t *rec = p.rec + rec_index(p, tx, ty, tz, wave) * kRecU16;
+        rec[r] = (uint16_t)occ;
+        rec[64 + r] = (uint16_t)seen;
+        if (pnt) atomicOr(any, 1);
     }
-    uint16_t *rec = p.rec + rec_index(p, tx, ty, tz, wave) * kRecU16;
-    rec[r] = (uint16_t)occ;
-    rec[64 + r] = (uint16_t)seen;
+    // the sub-tile's 16 bits of the row's word tx (zeros behind the end of the row)
+    const int XW = (p.X + 63) >> 6;
+    reinterpret_cast<uint16_t *>(paint + ((size_t)z * p.Y + y) * XW + tx)[wave] = (uint16_t)pnt;
 }
 
+// records (+ paint plane, may be null) -> bytes, local planes [zl0, zl0 + nz)
 __global__ __launch_bounds__(256) void rec_to_bytes_kernel(const CarveParams p,
-                                                           uint8_t *__restrict__ bytes) {
+                                                           uint8_t *__restrict__ bytes, int zl0,
+                                                           int nz,
+                                                           const unsigned long long *__restrict__ paint) {
     const int tx = blockIdx.x % p.tilesX, ty = (blockIdx.x / p.tilesX) % p.tilesY,
               tz = blockIdx.x / (p.tilesX * p.tilesY);
     const int wave = threadIdx.x >> 6, r = threadIdx.x & 63;
     const int x0 = tx * kTileX + wave * kSubX, y = ty * kTileY + (r & 7), z = tz * kTileZ + (r >> 3);
-    if (x0 >= p.X || y >= p.Y || z >= p.Z) return;
+    if (x0 >= p.X || y >= p.Y || z >= p.Z || z < zl0 || z >= zl0 + nz) return;
     const uint16_t *rec = p.rec + rec_index(p, tx, ty, tz, wave) * kRecU16;
     const uint32_t occ = rec[r], seen = rec[64 + r];
+    uint32_t pnt = 0;
+    if (paint) {
+        const int XW = (p.X + 63) >> 6;
+        pnt = reinterpret_cast<const uint16_t *>(paint + ((size_t)z * p.Y + y) * XW + tx)[wave];
+    }
     uint8_t b[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) b[j] = (uint8_t)(((occ >> j) & 1u) | (((seen >> j) & 1u) << 1));
+    for (int j = 0; j < 16; ++j)
+        b[j] = (uint8_t)(((occ >> j) & 1u) | (((seen >> j) & 1u) << 1) | (((pnt >> j) & 1u) << 2));
     uint8_t *dst = bytes + ((size_t)z * p.Y + y) * p.X + x0;
     if ((p.X & 15) == 0 && ((uintptr_t)bytes & 15u) == 0) {
         *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(b);
@@ -66,6 +90,19 @@ __global__ __launch_bounds__(256) void rec_to_bytes_kernel(const CarveParams p,
         for (int j = 0; j < 16; ++j)
             if (x0 + j < p.X) dst[j] = b[j];
     }
+}
+
+// one voxel's state bits (bit0 occupied, bit1 seen) straight from its record; lz = local plane
+__device__ __forceinline__ uint32_t rec_state(const CarveParams &p, int x, int y, int lz) {
+    const uint16_t *rec = p.rec + rec_index(p, x >> 6, y >> 3, lz >> 3, (x >> 4) & 3) * kRecU16;
+    const int r = (lz & 7) * 8 + (y & 7), b = x & 15;
+    return ((rec[r] >> b) & 1u) | (((rec[64 + r] >> b) & 1u) << 1);
+}
+// one bit of a plane in the layout of bitplane_kernels.h (null plane: 0)
+__device__ __forceinline__ uint32_t plane_bit(const unsigned long long *__restrict__ bits, int X,
+                                              int Y, int x, int y, int lz) {
+    if (!bits) return 0u;
+    return (uint32_t)((bits[((size_t)lz * Y + y) * ((X + 63) >> 6) + (x >> 6)] >> (x & 63)) & 1ull);
 }
 
 // Flat packed occupancy of local planes [zl0, zl0 + nz) from the records; X % 32 == 0.
@@ -120,12 +157,18 @@ __global__ __launch_bounds__(256) void pack_occupancy_rec8_kernel(const CarvePar
     out[dst / 4] = word;
 }
 
-// Records -> one bit plane in the layout of bitplane_kernels.h (rows padded to 64-bit words,
-// XW = ceil(X / 64) words per row): local planes [zl0, zl0 + nz).  closure_occupied: occupied
-// OR never seen (what the closure calls occupied after handleUnseen), else occupied.
-__global__ __launch_bounds__(256) void bitgrid_from_rec_kernel(const CarveParams p, int zl0, int nz,
-                                                               int closure_occupied,
-                                                               unsigned long long *__restrict__ bits) {
+// Records -> bit planes in the layout of bitplane_kernels.h (rows padded to 64-bit words,
+// XW = ceil(X / 64) words per row): local planes [zl0, zl0 + nz).
+//   occ_out     occupied; with closure_occupied: what the closure calls occupied -- occupied,
+//               or painted UNSEEN_COLOR by the host (`paint`, may be null; indexed by the
+//               context's planes), or, with apply_unseen, never seen (handleUnseen gives
+//               those w = 1, src/Model.cpp:42)
+//   unseen_out  (may be null) the voxels whose colour is UNSEEN_COLOR: painted, or with
+//               apply_unseen never seen
+__global__ __launch_bounds__(256) void bitgrid_from_rec_kernel(
+    const CarveParams p, int zl0, int nz, int closure_occupied, int apply_unseen,
+    const unsigned long long *__restrict__ paint, unsigned long long *__restrict__ occ_out,
+    unsigned long long *__restrict__ unseen_out) {
     const int XW = (p.X + 63) >> 6;
     const size_t n = (size_t)XW * p.Y * nz;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -133,17 +176,42 @@ __global__ __launch_bounds__(256) void bitgrid_from_rec_kernel(const CarveParams
     const int xw = (int)(i % XW), y = (int)((i / XW) % p.Y), zi = (int)(i / ((size_t)XW * p.Y));
     const int z = zl0 + zi, r = (z & 7) * 8 + (y & 7);
     const uint16_t *rec = p.rec + rec_index(p, xw, y >> 3, z >> 3, 0) * kRecU16;
-    unsigned long long w = 0;
+    unsigned long long o = 0, u = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {  // the tile's four sub-tiles: 16 voxels each
         if (64 * xw + 16 * k >= p.X) break;
-        unsigned long long e = rec[k * kRecU16 + r];
-        if (closure_occupied) e |= (unsigned long long)(uint16_t)~rec[k * kRecU16 + 64 + r];
-        w |= e << (16 * k);
+        o |= (unsigned long long)rec[k * kRecU16 + r] << (16 * k);
+        if (apply_unseen) u |= (unsigned long long)(uint16_t)~rec[k * kRecU16 + 64 + r] << (16 * k);
     }
+    if (paint) u |= paint[((size_t)z * p.Y + y) * XW + xw];
+    if (closure_occupied) o |= u;
     const int nx = p.X - 64 * xw;  // voxels behind the end of the row: zero
-    if (nx < 64) w &= (1ull << nx) - 1ull;
-    bits[i] = w;
+    if (nx < 64) {
+        o &= (1ull << nx) - 1ull;
+        u &= (1ull << nx) - 1ull;
+    }
+    occ_out[i] = o;
+    if (unseen_out) unseen_out[i] = u;
+}
+
+// occ |= bits for local planes [zl0, zl0 + nz): the closure's filled voxels become occupied
+// (bits: layout of bitplane_kernels.h over those planes)
+__global__ __launch_bounds__(256) void rec_or_bitgrid_kernel(const CarveParams p, int zl0, int nz,
+                                                             const unsigned long long *__restrict__ bits) {
+    const int XW = (p.X + 63) >> 6;
+    const size_t n = (size_t)XW * p.Y * nz;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long w = bits[i];
+    if (!w) return;
+    const int xw = (int)(i % XW), y = (int)((i / XW) % p.Y), zi = (int)(i / ((size_t)XW * p.Y));
+    const int z = zl0 + zi, r = (z & 7) * 8 + (y & 7);
+    uint16_t *rec = p.rec + rec_index(p, xw, y >> 3, z >> 3, 0) * kRecU16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint16_t e = (uint16_t)(w >> (16 * k));
+        if (e) rec[k * kRecU16 + r] |= e;
+    }
 }
 
 // Model::handleUnseen on records: occ |= ~seen (voxels outside the grid are kept "seen")
@@ -199,6 +267,44 @@ __global__ __launch_bounds__(256) void rec_from_planes_kernel(const CarveParams 
         rec[kRecU16 + r] = (uint16_t)(o >> 16);
         rec[kRecU16 + 64 + r] = (uint16_t)(sn >> 16);
     }
+}
+
+// Model::voxels for owned voxels [i0, i0+n) (flat index over the owned planes; zown = local
+// plane of owned plane 0): MODEL_COLOR where occupied, zero where carved (reference
+// src/Model.cpp:9-14, src/VoxelCarving.cpp:52), UNSEEN_COLOR where the host painted (`paint`,
+// may be null) and, with apply_unseen, where never seen (src/Model.cpp:36-47).
+__global__ __launch_bounds__(256) void export_fill_kernel(const CarveParams p, int zown, size_t i0,
+                                                          size_t n,
+                                                          const unsigned long long *__restrict__ paint,
+                                                          float4 *__restrict__ out,
+                                                          int apply_unseen) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
+        const size_t i = i0 + k;
+        const int x = (int)(i % p.X), y = (int)((i / p.X) % p.Y),
+                  lz = zown + (int)(i / ((size_t)p.X * p.Y));
+        const uint32_t st = rec_state(p, x, y, lz);
+        float4 v = (st & 1u) ? make_float4(50.f, 168.f, 141.f, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (plane_bit(paint, p.X, p.Y, x, y, lz) || (apply_unseen && !(st & 2u)))
+            v = make_float4(204.f, 0.f, 0.f, 1.f);
+        out[k] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void export_scatter_kernel(
+    const int *__restrict__ index, const float *__restrict__ rgb, const uint8_t *__restrict__ has,
+    long long first, long long last, const CarveParams p, int zown,
+    const unsigned long long *__restrict__ paint, size_t i0, float4 *__restrict__ out,
+    int apply_unseen) {
+    const long long e = first + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= last || !has[e]) return;
+    const size_t i = (size_t)index[e];
+    const int x = (int)(i % p.X), y = (int)((i / p.X) % p.Y),
+              lz = zown + (int)(i / ((size_t)p.X * p.Y));
+    // handleUnseen runs after colouring
+    if (plane_bit(paint, p.X, p.Y, x, y, lz) || (apply_unseen && !(rec_state(p, x, y, lz) & 2u)))
+        return;
+    out[i - i0] = make_float4(rgb[3 * e], rgb[3 * e + 1], rgb[3 * e + 2], 1.f);
 }
 
 }  // namespace arvx

@@ -20,7 +20,15 @@
  *
  * State plane: one byte per voxel, index x + X*(y + Y*z) (Model::flatten,
  * reference src/Model.h:104-106), bit0 = occupied (voxels[i].w != 0),
- * bit1 = seen (seen[i]).
+ * bit1 = seen (seen[i]).  That is the EXCHANGE form of arvx_state_upload / _download; on the
+ * device the state lives as 2 bits per voxel (or use the bit planes of
+ * arvx_state_upload_planes / _download_planes, 8x smaller, which is what the C++ layer does).
+ *
+ * Streams: every call enqueues on the context's stream (arvx_ctx_set_stream) and calls on one
+ * context must not overlap -- with ONE exception: the occupancy hand-off (arvx_pack_occupancy
+ * [_global], arvx_occupancy_compress, _expand[_striped]) may run on the exchange stream
+ * (arvx_ctx_set_exchange_stream) while arvx_set_views_device / arvx_carve of the NEXT job run
+ * on the main stream; those calls share no work buffer with the main stream.
  */
 #ifndef ARVX_H
 #define ARVX_H
@@ -173,7 +181,13 @@ int arvx_handle_unseen(arvx_ctx *ctx);
  * that host code needs no HIP headers. */
 int arvx_host_register(void *ptr, size_t bytes);
 int arvx_host_unregister(void *ptr);
-/* Device address of the owned part of the state plane, for zero-copy consumers. */
+/* A device-side SNAPSHOT of the owned part of the state as one byte per voxel, for consumers
+ * that read it in place.  The context keeps the state as 2-bit records; this call converts
+ * them into a buffer the context owns (enqueued on the context's stream: synchronise or use
+ * that stream before reading).  The pointer is valid until the context is destroyed, its
+ * CONTENT only until the next call that changes the state (carve, fast carve, handleUnseen,
+ * closure, uploads, reset): query again afterwards.  Writes through it are not seen by the
+ * library -- use arvx_state_upload[_planes]. */
 int arvx_state_device_ptr(arvx_ctx *ctx, void **ptr, size_t *bytes);
 /* Slab contexts keep one halo plane on each side that lies inside the grid
  * (z_begin-1 and z_end), because the colour pass needs the six neighbours of
@@ -254,7 +268,8 @@ int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const flo
  * kernel_size^3 box whose new voxels get the mean RGBA of their occupied
  * neighbours.  apply_unseen != 0: the model is taken as it is after
  * handleUnseen().  State bytes may carry bit2 (voxel painted UNSEEN_COLOR by
- * a host Model).  Whole-grid contexts only.  The filled voxels become occupied;
+ * a host Model; kept beside the records as a bit plane until the next carve, plane upload or
+ * reset).  Whole-grid contexts only.  The filled voxels become occupied;
  * arvx_export_model(ctx, ., same apply_unseen) then returns the closed model. */
 int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen);
 int arvx_closure_count(arvx_ctx *ctx, int64_t *count);

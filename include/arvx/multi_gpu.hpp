@@ -21,7 +21,8 @@ namespace arvx {
 // the devices, their contexts and the communicator: keep one for repeated carves of one grid
 class MultiGpuCarver {
    public:
-    MultiGpuCarver(const std::vector<int> &devices, int X, int Y, int Z, float voxel_size) {
+    MultiGpuCarver(const std::vector<int> &devices, int X, int Y, int Z, float voxel_size)
+        : X_(X), Y_(Y), Z_(Z), s_(voxel_size) {
         detail::check(arvx_mgpu_create(&m_, devices.data(), (int)devices.size(), X, Y, Z,
                                        voxel_size),
                       "arvx_mgpu_create");
@@ -36,6 +37,15 @@ class MultiGpuCarver {
                int merge = ARVX_MERGE_ALLREDUCE) {
         const int V = (int)views.size();
         if (!V) throw Error(ARVX_ERR_INVALID, "no views");
+        // the host planes are copied by the grid size the handle was made for
+        if (model.getX() != X_ || model.getY() != Y_ || model.getZ() != Z_ ||
+            model.getSize() != s_)
+            throw Error(ARVX_ERR_INVALID, "model and MultiGpuCarver differ in grid or voxel size");
+        for (const View &v : views)
+            if (!v.mask.data || v.mask.width != views[0].mask.width ||
+                v.mask.height != views[0].mask.height ||
+                v.mask.channels != views[0].mask.channels || v.mask.stride != views[0].mask.stride)
+                throw Error(ARVX_ERR_INVALID, "all masks must share one size and layout");
         std::vector<float> M((size_t)V * 12), cam((size_t)V * 3);
         std::vector<const uint8_t *> masks(V);
         for (int i = 0; i < V; ++i) {
@@ -70,6 +80,8 @@ class MultiGpuCarver {
 
    private:
     arvx_mgpu *m_ = nullptr;
+    int X_, Y_, Z_;
+    float s_;
 };
 
 inline void carve(const Intrinsics &intr, Model &model, const std::vector<View> &views,

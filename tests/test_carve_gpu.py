@@ -623,3 +623,48 @@ def test_bit_plane_transfers(arvx, oracle, dims, zr):
         ctx.carve()  # and the carve continues from them
         again = oracle.carve_planes(X, Y, s, sc.M, sc.masks, ctx.planes, state=st)
         assert_same(ctx.download_state(), again, "carve after uploaded planes")
+
+
+@pytest.mark.parametrize("dims,zr", [((64, 8, 8), None), ((33, 17, 9), None), ((100, 40, 24), (5, 17))])
+def test_byte_plane_is_an_exchange_form(arvx, oracle, dims, zr):
+    """The device keeps records (2 bits per voxel) + a paint bit plane; the byte plane of
+    arvx_state_upload / _download / _device_ptr is converted inside those calls.  Bits 0..2
+    survive an upload -> download round trip (bit2 = painted by a host Model); the paint is
+    dropped by the next carve, as before; arvx_state_device_ptr is a SNAPSHOT: its content is
+    that of the moment of the call, and querying again after a carve gives the new state."""
+    X, Y, Z = dims
+    sc = scenes.small_sphere(32, 5)
+    s = np.float32(0.512 / max(dims))
+    rng = np.random.default_rng(X * 3 + Y)
+    with arvx.Context(X, Y, Z, s, z_range=zr) as ctx:
+        nz = Z if zr is None else zr[1] - zr[0]
+        st = rng.integers(0, 8, size=(nz, Y, X), dtype=np.uint8)
+        ctx.upload_state(st)
+        assert_same(ctx.download_state(), st, "round trip with bit2")
+        st2 = st & 3
+        ctx.upload_state(st2)
+        assert_same(ctx.download_state(), st2, "second upload replaces the paint")
+        ctx.set_views(sc.M, sc.masks)
+        n = ctx.nvox
+        ptr = ctx.state_device_ptr()
+        ctx.synchronize()
+        snap0 = _device_bytes(ptr, n).reshape(st2.shape)
+        assert_same(snap0, st2, "snapshot before the carve")
+        ctx.upload_state(st)  # painted again
+        ctx.carve()
+        want = oracle.carve_planes(X, Y, s, sc.M, sc.masks, ctx.planes, state=st2)
+        assert_same(ctx.download_state(), want, "carve drops the paint, keeps bits 0..1")
+        ptr2 = ctx.state_device_ptr()  # re-queried: the state after the carve
+        ctx.synchronize()
+        assert_same(_device_bytes(ptr2, n).reshape(st2.shape), want, "snapshot after the carve")
+
+
+def _device_bytes(ptr, n):
+    """n bytes at device address ptr -> numpy (hipMemcpy through torch's HIP runtime)."""
+    import ctypes
+    out = np.empty(n, np.uint8)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    rc = hip.hipMemcpy(out.ctypes.data, ctypes.c_void_p(ptr), n, 2)  # hipMemcpyDeviceToHost
+    assert rc == 0, rc
+    return out

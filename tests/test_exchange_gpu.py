@@ -139,14 +139,17 @@ def test_carved_slabs_round_trip():
     c.close()
 
 
-def test_exchange_stream_pipeline():
+@pytest.mark.parametrize("N,V,W,H", [(64, 6, 160, 120), (256, 36, 640, 480)])
+def test_exchange_stream_pipeline(N, V, W, H):
     """arvx_ctx_set_exchange_stream: the hand-off of job k (pack, compress, expand) on a second
-    stream beside the carve of job k + 1, ordered by two events -- as bench.py and a
+    stream beside the views + carve of job k + 1, ordered by two events -- as bench.py and a
     multi-GPU caller run it.  Jobs alternate between two scenes; every expanded plane must be
-    the packed occupancy of ITS job."""
+    the packed occupancy of ITS job.  At 256^3 x 36 views of 640x480 the compress of job k
+    (262 144 words) really runs beside the summed-area-table kernels of job k + 1: the two
+    must not share a work buffer (they once did: ctx->d_scratch)."""
     from ar_voxel_project_amd import capi
-    X = Y = Z = 64
-    scs = [scenes.small_sphere(64, 6, W=160, H=120), scenes.syn.box_scene((64, 64, 64), 5)]
+    X = Y = Z = N
+    scs = [scenes.syn.sphere_scene(N, V, W=W, H=H), scenes.syn.box_scene((N, N, N), V, W=W, H=H)]
     n = X * Y * Z // 64
     cap = n
     S = capi.occupancy_packet_words(n, cap)
