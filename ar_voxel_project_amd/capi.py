@@ -38,7 +38,9 @@ SYMBOLS = [
     "arvx_color", "arvx_surface_count", "arvx_surface_download",
     "arvx_surface_depth_download",
     "arvx_colors_upload", "arvx_closure", "arvx_closure_count", "arvx_closure_download",
+    "arvx_closure_download32",
     "arvx_mc_cells", "arvx_mc_cells_download", "arvx_mc_mesh", "arvx_mc_mesh_download",
+    "arvx_mc_mesh_download_faces",
     "arvx_occupancy_packet_words", "arvx_occupancy_compress", "arvx_occupancy_expand",
     "arvx_occupancy_expand_striped",
     "arvx_export_model", "arvx_get_stats", "arvx_selftest_divide", "arvx_selftest_round",
@@ -439,6 +441,11 @@ class Context:
         if n.value:
             self._ck(self._lib.arvx_closure_download(
                 self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)), _fp(rgba)))
+            i32 = np.empty(n.value, np.int32)  # the 32-bit form must say the same
+            r32 = np.empty_like(rgba)
+            self._lib.arvx_closure_download32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            self._ck(self._lib.arvx_closure_download32(self._h, i32.ctypes.data, r32.ctypes.data))
+            assert np.array_equal(i32, idx) and np.array_equal(r32.view(np.uint32), rgba.view(np.uint32))
         return idx, rgba
 
     def mc_cells(self) -> np.ndarray:
@@ -462,6 +469,15 @@ class Context:
         rgb = np.empty((n.value, 3), np.uint32)
         if n.value:
             self._ck(self._lib.arvx_mc_mesh_download(self._h, verts.ctypes.data, rgb.ctypes.data))
+            # the face-record form must say the same: (3t, 3t+1, 3t+2, r, g, b) per triangle
+            v2 = np.empty_like(verts)
+            faces = np.empty((n.value, 6), np.uint32)
+            self._lib.arvx_mc_mesh_download_faces.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            self._ck(self._lib.arvx_mc_mesh_download_faces(self._h, v2.ctypes.data,
+                                                          faces.ctypes.data))
+            t3 = 3 * np.arange(n.value, dtype=np.uint32)
+            assert np.array_equal(v2, verts) and np.array_equal(faces[:, 3:], rgb)
+            assert np.array_equal(faces[:, :3], t3[:, None] + np.arange(3, dtype=np.uint32))
         return verts, rgb
 
     def export_model(self, apply_unseen: bool = False) -> np.ndarray:

@@ -1561,9 +1561,14 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
         cp.col = colour_list(ctx);
         cp.col_rgb = ctx->d_surf_rgb;
         cp.col_has = ctx->d_surf_has;
-        hipLaunchKernelGGL(arvx::closure_fill_kernel, dim3((unsigned)((total + 255) / 256)),
-                           dim3(256), 0, ctx->stream, cp, ctx->d_clo_index, total,
-                           (float4 *)ctx->d_clo_rgba);
+        if (radius == 1)
+            hipLaunchKernelGGL(arvx::closure_fill_kernel<true>, dim3((unsigned)((total + 255) / 256)),
+                               dim3(256), 0, ctx->stream, cp, ctx->d_clo_index, total,
+                               (float4 *)ctx->d_clo_rgba);
+        else
+            hipLaunchKernelGGL(arvx::closure_fill_kernel<false>, dim3((unsigned)((total + 255) / 256)),
+                               dim3(256), 0, ctx->stream, cp, ctx->d_clo_index, total,
+                               (float4 *)ctx->d_clo_rgba);
         ARVX_HIP(hipGetLastError());
         // the filled voxels are occupied from now on (their w is count / count = 1)
         arvx::CarveParams rp;
@@ -1721,7 +1726,7 @@ int arvx_mc_mesh(arvx_ctx *ctx, int apply_unseen, int64_t *triangles) {
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
     if (total > 0) {
         ARVX_HIP(ctx->pool_mesh_verts.reserve((size_t)total * 9 * sizeof(float)));
-        ARVX_HIP(ctx->pool_mesh_rgb.reserve((size_t)total * 3 * sizeof(unsigned)));
+        ARVX_HIP(ctx->pool_mesh_rgb.reserve((size_t)total * 6 * sizeof(unsigned)));  // face records
         arvx::McMeshParams mp;
         carve_geometry(ctx, mp.g);
         mp.g.rec = ctx->d_rec;
@@ -1732,7 +1737,8 @@ int arvx_mc_mesh(arvx_ctx *ctx, int apply_unseen, int64_t *triangles) {
         mp.col_has = ctx->d_surf_has;
         mp.clo = closure_list(ctx);
         mp.clo_rgba = (const float4 *)ctx->d_clo_rgba;
-        hipLaunchKernelGGL(arvx::mc_mesh_kernel, dim3(nblk), dim3(256), 0, ctx->stream, mp,
+        hipLaunchKernelGGL(arvx::mc_mesh_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0,
+                           ctx->stream, mp,
                            (const int4 *)ctx->d_mc_cells, (long long)n, d_off,
                            (float *)ctx->pool_mesh_verts.p, (unsigned *)ctx->pool_mesh_rgb.p);
         ARVX_HIP(hipGetLastError());
@@ -1748,7 +1754,34 @@ int arvx_mc_mesh_download(arvx_ctx *ctx, float *verts, uint32_t *face_rgb) {
     if (ctx->mesh_tris > 0) {
         ARVX_HIP(hipMemcpyAsync(verts, ctx->pool_mesh_verts.p, (size_t)ctx->mesh_tris * 36,
                                 hipMemcpyDeviceToHost, ctx->stream));
-        ARVX_HIP(hipMemcpyAsync(face_rgb, ctx->pool_mesh_rgb.p, (size_t)ctx->mesh_tris * 12,
+        // r, g, b of the 24-byte face records
+        ARVX_HIP(hipMemcpy2DAsync(face_rgb, 12, (const uint8_t *)ctx->pool_mesh_rgb.p + 12, 24, 12,
+                                  (size_t)ctx->mesh_tris, hipMemcpyDeviceToHost, ctx->stream));
+        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return ARVX_OK;
+}
+
+int arvx_mc_mesh_download_faces(arvx_ctx *ctx, float *verts, uint32_t *faces) {
+    ARVX_CHECK_CTX(ctx);
+    if (!verts || !faces) return fail(ARVX_ERR_INVALID, "null argument");
+    if (ctx->mesh_tris > 0) {
+        ARVX_HIP(hipMemcpyAsync(verts, ctx->pool_mesh_verts.p, (size_t)ctx->mesh_tris * 36,
+                                hipMemcpyDeviceToHost, ctx->stream));
+        ARVX_HIP(hipMemcpyAsync(faces, ctx->pool_mesh_rgb.p, (size_t)ctx->mesh_tris * 24,
+                                hipMemcpyDeviceToHost, ctx->stream));
+        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return ARVX_OK;
+}
+
+int arvx_closure_download32(arvx_ctx *ctx, int32_t *index, float *rgba) {
+    ARVX_CHECK_CTX(ctx);
+    if (!index || !rgba) return fail(ARVX_ERR_INVALID, "null argument");
+    if (!ctx->closure_ready) return fail(ARVX_ERR_STATE, "no closure result (call arvx_closure)");
+    if (ctx->clo_count) {
+        memcpy(index, ctx->h_clo_index.data(), (size_t)ctx->clo_count * sizeof(int32_t));
+        ARVX_HIP(hipMemcpyAsync(rgba, ctx->d_clo_rgba, (size_t)ctx->clo_count * sizeof(float4),
                                 hipMemcpyDeviceToHost, ctx->stream));
         ARVX_HIP(hipStreamSynchronize(ctx->stream));
     }

@@ -73,7 +73,82 @@ __device__ inline int cl_gather(const ClosureParams &p, size_t i, float4 &sum) {
     return count;
 }
 
+// The 3x3x3 box (kernelSize 3, what src/main.cpp:298 passes) without a dependent load per
+// neighbour: the nine voxel rows around the voxel are read as words first -- occupancy, UNSEEN
+// paint, the colour list's plane and ranks: 36 independent loads --, then the colours of nine
+// neighbours at a time (one x offset) are fetched together and added in the reference's order
+// (x offset outermost, then y, then z, src/Postprocessing3d.cpp:31-48).
+__device__ inline int cl_gather3(const ClosureParams &p, size_t i, float4 &sum) {
+    const int X = p.g.X, Y = p.g.Y, Z = p.g.Z, XW = p.g.XW;
+    const int x = (int)(i % X);
+    const size_t t = i / X;
+    const int y = (int)(t % Y), z = (int)(t / Y);
+    const int xw = x >> 6, xb = x & 63;
+    // 3-bit windows of the rows (y + b, z + c): bit a + 1 = voxel x + a
+    unsigned occ3[9], uns3[9], col3[9];
+    int rank_lo[9];          // rank of the window's first listed voxel
+    unsigned long long colw[9];
+    auto window = [&](const unsigned long long *plane, size_t at, bool row_ok) -> unsigned {
+        if (!plane || !row_ok) return 0u;
+        const unsigned long long w = plane[at];
+        unsigned v = xb ? (unsigned)((w >> (xb - 1)) & 7ull) : (unsigned)((w << 1) & 7ull);
+        if (xb == 0 && xw > 0) v |= (unsigned)(plane[at - 1] >> 63);
+        if (xb == 63 && xw + 1 < XW) v |= (unsigned)(plane[at + 1] & 1ull) << 2;
+        return v;
+    };
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int yn = y + r / 3 - 1, zn = z + r % 3 - 1;  // r = 3 * (b + 1) + (c + 1)
+        const bool ok = yn >= 0 && yn < Y && zn >= 0 && zn < Z;
+        const size_t at = ok ? ((size_t)zn * Y + yn) * XW + xw : 0;
+        occ3[r] = window(p.occ, at, ok);
+        uns3[r] = window(p.unseen, at, ok);
+        col3[r] = window(p.col.bits, at, ok);
+        colw[r] = (p.col.bits && ok) ? p.col.bits[at] : 0ull;
+        rank_lo[r] = (p.col.bits && ok) ? p.col.rank[at] : 0;
+    }
+    int count = 0;
+    sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {  // x offset a - 1
+        const int xn = x + a - 1;
+        float3 rgb[9];
+        bool has[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {  // the nine lookups of this x offset, all in flight
+            int k = -1;
+            if ((col3[r] >> a) & 1u) {
+                // position in the list: rank of the voxel's own word + listed voxels below it
+                if (xn >> 6 == xw) {
+                    k = rank_lo[r] + __popcll(colw[r] & ((1ull << (xn & 63)) - 1ull));
+                } else {  // the neighbour lies in the next / previous word of the row
+                    const int yn = y + r / 3 - 1, zn = z + r % 3 - 1;
+                    k = sparse_find(p.col, XW, xn, (size_t)zn * Y + yn);
+                }
+            }
+            has[r] = k >= 0 && p.col_has[k];
+            const int kk = k >= 0 ? k : 0;
+            rgb[r] = (k >= 0) ? make_float3(p.col_rgb[3 * kk], p.col_rgb[3 * kk + 1], p.col_rgb[3 * kk + 2])
+                              : make_float3(0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            if (!((occ3[r] >> a) & 1u)) continue;
+            ++count;
+            float4 v = make_float4(50.f, 168.f, 141.f, 1.f);
+            if (has[r]) v = make_float4(rgb[r].x, rgb[r].y, rgb[r].z, 1.f);
+            if ((uns3[r] >> a) & 1u) v = make_float4(204.f, 0.f, 0.f, 1.f);
+            sum.x = sum.x + v.x;
+            sum.y = sum.y + v.y;
+            sum.z = sum.z + v.z;
+            sum.w = sum.w + v.w;
+        }
+    }
+    return count;
+}
+
 // one thread per filled voxel (index ascending): mean RGBA of its occupied neighbours
+template <bool BOX3>
 __global__ __launch_bounds__(256) void closure_fill_kernel(const ClosureParams p,
                                                            const int *__restrict__ index,
                                                            long long n,
@@ -81,7 +156,7 @@ __global__ __launch_bounds__(256) void closure_fill_kernel(const ClosureParams p
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
     float4 sum;
-    const int count = cl_gather(p, (size_t)index[e], sum);
+    const int count = BOX3 ? cl_gather3(p, (size_t)index[e], sum) : cl_gather(p, (size_t)index[e], sum);
     const float fc = (float)count;  // Eigen `sum /= count`, src/Postprocessing3d.cpp:49-51
     rgba[e] = make_float4(sum.x / fc, sum.y / fc, sum.z / fc, sum.w / fc);
 }

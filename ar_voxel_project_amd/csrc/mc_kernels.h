@@ -35,11 +35,13 @@ struct McParams {
 };
 
 // One workgroup per tile column (64 x 8 voxel columns) and word w: the occ halves of the (up
-// to) nine tiles that the word's 64 planes touch go to LDS -- whole 128-byte loads --, then
-// every thread assembles the words of two columns, one bit per plane.  Lanes of a wave run
-// along x, so the stores are whole rows of words.
+// to) nine tiles that the word's 64 planes touch go to LDS -- whole 128-byte loads, stored
+// with the plane index innermost --, then every thread builds the words of two columns: per
+// tile ONE 16-byte LDS read brings the entries of its eight planes, the column's bit of each
+// is picked two planes at a time.  Lanes of a wave run along x: the stores are whole rows.
 __global__ __launch_bounds__(256) void mc_zpack_rec_kernel(const CarveParams g, const McParams p) {
-    __shared__ uint16_t occ[9][4][66];  // [tile along z][sub-tile][entry]; 66: no bank conflicts
+    // [tile along z][sub-tile][y (padded: 144-byte sub-tile stride, no bank conflicts)][plane]
+    __shared__ __attribute__((aligned(16))) uint16_t occ[9][4][9][8];
     const int tx = blockIdx.x % g.tilesX, ty = (blockIdx.x / g.tilesX) % g.tilesY,
               w = blockIdx.x / (g.tilesX * g.tilesY);
     const int zbase = p.cz0 + 64 * w;  // global plane of bit 0
@@ -48,13 +50,15 @@ __global__ __launch_bounds__(256) void mc_zpack_rec_kernel(const CarveParams g, 
     const int off = lbase - 8 * tz_lo;                        // 0..7
     {
         const int sub = threadIdx.x >> 6, r = threadIdx.x & 63;
+        uint16_t e[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int tz = tz_lo + j;
-            uint16_t e = 0;
-            if (tz >= 0 && tz < g.tilesZ) e = g.rec[rec_index(g, tx, ty, tz, sub) * kRecU16 + r];
-            occ[j][sub][r] = e;
+            e[j] = (tz >= 0 && tz < g.tilesZ) ? g.rec[rec_index(g, tx, ty, tz, sub) * kRecU16 + r]
+                                              : (uint16_t)0;
         }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) occ[j][sub][r & 7][r >> 3] = e[j];
     }
     __syncthreads();
     // planes of this word that exist for this context: inside the grid and not above cz1
@@ -75,15 +79,24 @@ __global__ __launch_bounds__(256) void mc_zpack_rec_kernel(const CarveParams g, 
         const int x = tx * kTileX + xl, y = ty * kTileY + yl;
         if (x >= p.X || y >= p.Y) continue;
         const int sub = xl >> 4, bit = xl & 15;
-        uint32_t lo = 0, hi = 0;
+        uint32_t B[9];  // the column's bit in the eight planes of tile j
 #pragma unroll
-        for (int b = 0; b < 32; ++b) {
-            const int l0 = off + b, l1 = off + 32 + b;
-            lo |= (((uint32_t)occ[l0 >> 3][sub][(l0 & 7) * 8 + yl] >> bit) & 1u) << b;
-            hi |= (((uint32_t)occ[l1 >> 3][sub][(l1 & 7) * 8 + yl] >> bit) & 1u) << b;
+        for (int j = 0; j < 9; ++j) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(&occ[j][sub][yl][0]);
+            const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+            uint32_t byte = 0;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {  // dword h: planes 2h (low half) and 2h + 1 (high half)
+                const uint32_t t = (d[h] >> bit) & 0x00010001u;
+                byte |= ((t | (t >> 15)) & 3u) << (2 * h);
+            }
+            B[j] = byte;
         }
-        const unsigned long long word = ((unsigned long long)hi << 32 | lo) & valid;
-        p.zbits[((size_t)w * p.Y + y) * p.X + x] = word;
+        const uint32_t lo32 = B[0] | (B[1] << 8) | (B[2] << 16) | (B[3] << 24);
+        const uint32_t hi32 = B[4] | (B[5] << 8) | (B[6] << 16) | (B[7] << 24);
+        unsigned long long word = ((unsigned long long)hi32 << 32) | lo32;  // planes 8 tz_lo + 0..63
+        if (off) word = (word >> off) | ((unsigned long long)B[8] << (64 - off));
+        p.zbits[((size_t)w * p.Y + y) * p.X + x] = word & valid;
     }
 }
 

@@ -79,42 +79,69 @@ __device__ __forceinline__ unsigned mc_mean3(float a, float b, float c) {
     return (unsigned)roundf(s / 3.f);
 }
 
-__global__ __launch_bounds__(256) void mc_mesh_kernel(const McMeshParams p,
-                                                      const int4 *__restrict__ cells, long long n,
-                                                      const long long *__restrict__ tri_offset,
-                                                      float *__restrict__ verts,
-                                                      unsigned *__restrict__ face_rgb) {
-    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (c >= n) return;
-    const int4 cell = cells[c];
-    const int idx = cell.w & 255;
+constexpr int kMeshMaxTris = 5;  // Bourke's table: at most five triangles per cell
+
+// One WAVE per workgroup, one cell per lane.  The triangles of 64 consecutive cells are one
+// contiguous range of the output (tri_offset is the exclusive scan of their counts), so the
+// lanes build theirs in LDS and the wave then streams the range out in whole lines: 36 bytes of
+// vertices and 24 bytes of face record per triangle leave as coalesced dword stores instead of
+// twelve scattered ones per triangle.
+//   verts  9 floats per triangle (three fresh vertices, voxel units)
+//   faces  6 uints per triangle: vertex numbers 3t, 3t+1, 3t+2, then r, g, b -- the layout of
+//          the C++ layer's Triangle (include/arvx/marching_cubes.hpp), reference
+//          src/MarchingCubes.h:19-31
+// Only the first two corners' colours are ever used (col[2] = col[1], :506): two voxel lookups
+// per triangle.
+__global__ __launch_bounds__(64) void mc_mesh_kernel(const McMeshParams p,
+                                                     const int4 *__restrict__ cells, long long n,
+                                                     const long long *__restrict__ tri_offset,
+                                                     float *__restrict__ verts,
+                                                     unsigned *__restrict__ faces) {
+    __shared__ float s_vert[64 * kMeshMaxTris * 9];
+    __shared__ unsigned s_rgb[64 * kMeshMaxTris * 3];
+    const int lane = threadIdx.x;
+    const long long c = (long long)blockIdx.x * 64 + lane;
+    const long long c0 = (long long)blockIdx.x * 64;
+    const long long clast = (c0 + 63 < n - 1) ? c0 + 63 : n - 1;
+    const long long base = tri_offset[c0];
     // corner i of ProcessVoxel (src/MarchingCubes.h:537-552); bit i of idx set = NOT in the model
-    const int cx[8] = {1, 0, 0, 1, 1, 0, 0, 1}, cy[8] = {0, 0, 1, 1, 0, 0, 1, 1},
-              cz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
-    float3 col[8];
+    // x offsets of corners 0..7: 1 0 0 1 1 0 0 1; y: 0 0 1 1 0 0 1 1; z: 0 0 0 0 1 1 1 1
+    constexpr unsigned kCx = 0x99u, kCy = 0xCCu, kCz = 0xF0u;
+    if (c < n) {
+        const int4 cell = cells[c];
+        const int idx = cell.w & 255;
+        int t = (int)(tri_offset[c] - base);
+        const int8_t *row = kMcTri.e[idx];
+        for (int k = 0; row[k] >= 0; k += 3, ++t) {
+            int vx[3], vy[3], vz[3];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        col[i] = make_float3(0.f, 0.f, 0.f);
-        if (!((idx >> i) & 1)) col[i] = mc_voxel_rgb(p, cell.x + cx[i], cell.y + cy[i], cell.z + cz[i]);
-    }
-    long long t = tri_offset[c];
-    const int8_t *row = kMcTri.e[idx];
-    for (int k = 0; row[k] >= 0; k += 3, ++t) {
-        int corner[3];
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            const int e = row[k + v];
-            const int a = e & 7, b = mc::kSecondCorner[e];  // e % 8 and its partner (:491)
-            corner[v] = ((idx >> a) & 1) ? b : a;           // the corner that is in the model
-            float *o = verts + 9 * t + 3 * v;
-            o[0] = (float)(cell.x + cx[corner[v]]);
-            o[1] = (float)(cell.y + cy[corner[v]]);
-            o[2] = (float)(cell.z + cz[corner[v]]);
+            for (int v = 0; v < 3; ++v) {
+                const int e = row[k + v];
+                const int a = e & 7, b = mc::kSecondCorner[e];  // e % 8 and its partner (:491)
+                const int cn = ((idx >> a) & 1) ? b : a;         // the corner that is in the model
+                vx[v] = cell.x + (int)((kCx >> cn) & 1u);
+                vy[v] = cell.y + (int)((kCy >> cn) & 1u);
+                vz[v] = cell.z + (int)((kCz >> cn) & 1u);
+                float *o = s_vert + 9 * t + 3 * v;
+                o[0] = (float)vx[v];
+                o[1] = (float)vy[v];
+                o[2] = (float)vz[v];
+            }
+            const float3 q0 = mc_voxel_rgb(p, vx[0], vy[0], vz[0]);
+            const float3 q1 = mc_voxel_rgb(p, vx[1], vy[1], vz[1]);  // col[2] = col[1], :506
+            s_rgb[3 * t] = mc_mean3(q0.x, q1.x, q1.x);
+            s_rgb[3 * t + 1] = mc_mean3(q0.y, q1.y, q1.y);
+            s_rgb[3 * t + 2] = mc_mean3(q0.z, q1.z, q1.z);
         }
-        const float3 c0 = col[corner[0]], c1 = col[corner[1]];  // col[2] = col[1], :506
-        face_rgb[3 * t] = mc_mean3(c0.x, c1.x, c1.x);
-        face_rgb[3 * t + 1] = mc_mean3(c0.y, c1.y, c1.y);
-        face_rgb[3 * t + 2] = mc_mean3(c0.z, c1.z, c1.z);
+    }
+    __syncthreads();
+    const int ntri = (int)(tri_offset[clast] - base) + kMcTri.n[cells[clast].w & 255];
+    float *vo = verts + 9 * base;
+    for (int i = lane; i < 9 * ntri; i += 64) vo[i] = s_vert[i];
+    unsigned *fo = faces + 6 * base;
+    for (int i = lane; i < 6 * ntri; i += 64) {
+        const int t = i / 6, f = i - 6 * t;
+        fo[i] = f < 3 ? (unsigned)(3 * (base + t) + f) : s_rgb[3 * t + f - 3];
     }
 }
 

@@ -275,6 +275,8 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen);
 int arvx_closure_count(arvx_ctx *ctx, int64_t *count);
 /* Filled voxels, ascending flat index, 4 floats RGBA each. */
 int arvx_closure_download(arvx_ctx *ctx, int64_t *index, float *rgba);
+/* The same with 32-bit indices (a grid has at most INT_MAX voxels, Model::flatten). */
+int arvx_closure_download32(arvx_ctx *ctx, int32_t *index, float *rgba);
 
 /* Marching-cubes hand-off.  The reference's marchingCubes() visits every cell
  * (x,y,z) of [-1,X) x [-1,Y) x [-1,Z), x outermost and z innermost
@@ -301,6 +303,10 @@ int arvx_mc_cells_download(arvx_ctx *ctx, int32_t *cells);
  * Runs arvx_mc_cells itself; the order is the reference's. */
 int arvx_mc_mesh(arvx_ctx *ctx, int apply_unseen, int64_t *triangles);
 int arvx_mc_mesh_download(arvx_ctx *ctx, float *verts, uint32_t *face_rgb);
+/* The same triangles with whole face records, 6 uints per triangle: the vertex numbers 3t,
+ * 3t+1, 3t+2, then r, g, b -- the reference's Triangle (src/MarchingCubes.h:19-31), so that a
+ * host mesh takes both arrays without a conversion loop. */
+int arvx_mc_mesh_download_faces(arvx_ctx *ctx, float *verts, uint32_t *faces);
 
 /* Model::voxels as the reference would hold it after carve [+ colour]
  * [+ handleUnseen]: n*4 floats (RGBA), n = slab voxels. */

@@ -22,11 +22,14 @@
 #ifndef ARVX_MARCHING_CUBES_HPP
 #define ARVX_MARCHING_CUBES_HPP
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <fstream>
 #include <string>
 #include <vector>
 
+#include "arvx/host_pool.hpp"
 #include "arvx/mc_tables.hpp"
 #include "arvx/voxel_carving.hpp"
 
@@ -49,6 +52,8 @@ struct Triangle {  // src/MarchingCubes.h:19-31
     unsigned int r, g, b;
 };
 
+// (the two arrays live in recycled page-locked memory, include/arvx/host_pool.hpp: a mesh of
+// 1.3 M triangles is 77 MB that the device writes in the arrays' own layout)
 class SimpleMesh {  // src/MarchingCubes.h:33-92
    public:
     unsigned int AddVertex(const Vec3f &vertex) {
@@ -60,8 +65,8 @@ class SimpleMesh {  // src/MarchingCubes.h:33-92
         m_triangles.push_back(Triangle{idx0, idx1, idx2, r, g, b});
         return (unsigned int)m_triangles.size() - 1;
     }
-    std::vector<Vec3f> &GetVertices() { return m_vertices; }
-    std::vector<Triangle> &GetTriangles() { return m_triangles; }
+    HostVector<Vec3f> &GetVertices() { return m_vertices; }
+    HostVector<Triangle> &GetTriangles() { return m_triangles; }
 
     // The reference ends every line with std::endl (one flush per line); '\n' and one flush at
     // the end give the same bytes.
@@ -89,8 +94,8 @@ class SimpleMesh {  // src/MarchingCubes.h:33-92
     }
 
    private:
-    std::vector<Vec3f> m_vertices;
-    std::vector<Triangle> m_triangles;
+    HostVector<Vec3f> m_vertices;
+    HostVector<Triangle> m_triangles;
 };
 
 struct McCell {
@@ -229,8 +234,22 @@ inline bool ProcessVoxel(Model *model, int x, int y, int z, SimpleMesh *mesh, fl
 inline SimpleMesh marchingCubesMesh(Model *model, float threshold = 0.5f) {
     SimpleMesh mesh;
     if (!(threshold > 0.f)) return mesh;
+#ifdef ARVX_HOST_TRACE  // diagnostic builds: where the host time of this call goes
+    using TraceClock = std::chrono::steady_clock;
+    auto trace_t = TraceClock::now();
+    auto trace = [&](const char *what) {
+        const auto now = TraceClock::now();
+        std::fprintf(stderr, "    [mesh] %-18s %.3f ms\n", what,
+                     std::chrono::duration<double, std::milli>(now - trace_t).count());
+        trace_t = now;
+    };
+#define ARVX_TRACE(what) trace(what)
+#else
+#define ARVX_TRACE(what) (void)0
+#endif
     bool on_device = false;
     (void)model->inside_state(threshold, on_device);
+    ARVX_TRACE("inside_state");
     if (!on_device) {
         for (const McCell &c : marchingCubesCells(*model, threshold))
             ProcessVoxel(model, c.x, c.y, c.z, &mesh, threshold);
@@ -253,21 +272,24 @@ inline SimpleMesh marchingCubesMesh(Model *model, float threshold = 0.5f) {
                       "arvx_colors_upload");
         model->set_colors_on_device(true);
     }
+    ARVX_TRACE("context + colours");
     int64_t n = 0;
     detail::check(arvx_mc_mesh(ctx, (painted && model->paint_is_unseen()) ? 1 : 0, &n),
                   "arvx_mc_mesh");
-    // the device writes a triangle's three corners as nine floats: the mesh's vertex array
+    ARVX_TRACE("arvx_mc_mesh");
+    // the device writes both arrays in the mesh's own layout: a triangle's three corners as
+    // nine floats, its face as (3t, 3t+1, 3t+2, r, g, b)
     static_assert(sizeof(Vec3f) == 3 * sizeof(float), "Vec3f is three packed floats");
-    std::vector<Vec3f> &mv = mesh.GetVertices();
-    std::vector<Triangle> &mt = mesh.GetTriangles();
-    mv.resize((size_t)n * 3);
-    std::vector<uint32_t> rgb((size_t)n * 3);
-    if (n) detail::check(arvx_mc_mesh_download(ctx, &mv[0].v[0], rgb.data()),
-                         "arvx_mc_mesh_download");
+    static_assert(sizeof(Triangle) == 6 * sizeof(uint32_t), "Triangle is six packed uints");
+    HostVector<Vec3f> &mv = mesh.GetVertices();
+    HostVector<Triangle> &mt = mesh.GetTriangles();
+    mv.resize((size_t)n * 3);  // (recycled memory, not zeroed: host_pool.hpp)
     mt.resize((size_t)n);
-    for (size_t t = 0; t < (size_t)n; ++t)
-        mt[t] = Triangle{(unsigned)(3 * t), (unsigned)(3 * t + 1), (unsigned)(3 * t + 2), rgb[3 * t],
-                         rgb[3 * t + 1], rgb[3 * t + 2]};
+    ARVX_TRACE("resize");
+    if (n) detail::check(arvx_mc_mesh_download_faces(ctx, &mv[0].v[0], &mt[0].idx0),
+                         "arvx_mc_mesh_download_faces");
+    ARVX_TRACE("download");
+#undef ARVX_TRACE
     return mesh;
 }
 

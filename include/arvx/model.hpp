@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "arvx/arvx.h"
+#include "arvx/host_pool.hpp"
 
 namespace arvx {
 
@@ -121,8 +122,11 @@ class Model {
         paint_ = o.paint_;
         pristine_ = o.pristine_;
         paint_is_unseen_ = o.paint_is_unseen_;
+        odd_w_ = o.odd_w_;
         cidx_ = o.cidx_;
         cval_ = o.cval_;
+        fidx_ = o.fidx_;
+        fval_ = o.fval_;
         overlay_ = o.overlay_;
         color_lists_ = o.color_lists_;
     }
@@ -130,6 +134,7 @@ class Model {
 
     void set(int x, int y, int z, const Vec4f &v) {  // src/Model.cpp:16-18
         sync_host();
+        if (v.w() != 0.f && v.w() != 1.f) odd_w_ = true;
         const size_t w = word(x, y, z);
         const uint32_t b = 1u << (x & 31);
         if (v.w() != 0) occ_[w] |= b;
@@ -140,7 +145,8 @@ class Model {
                               (v.w() == 0 && v.x() == 0 && v.y() == 0 && v.z() == 0);
         // the two values the bits alone encode need no entry -- unless an explicit colour
         // of this voxel has to be hidden
-        if (by_state && (cidx_.empty() || !std::binary_search(cidx_.begin(), cidx_.end(), i)))
+        if (by_state && !std::binary_search(cidx_.begin(), cidx_.end(), i) &&
+            !std::binary_search(fidx_.begin(), fidx_.end(), i))
             overlay_.erase(i);
         else
             overlay_[i] = v;
@@ -166,6 +172,10 @@ class Model {
         const uint32_t b = 1u << (x & 31);
         if (!(occ_[w] & b)) return Vec4f(0, 0, 0, 0);  // carved (src/VoxelCarving.cpp:52)
         if (!paint_.empty() && (paint_[w] & b)) return unseen_color();
+        if (!fidx_.empty()) {  // filled by the closure (newer than the colour pass's list)
+            auto it = std::lower_bound(fidx_.begin(), fidx_.end(), i);
+            if (it != fidx_.end() && *it == i) return fval_[(size_t)(it - fidx_.begin())];
+        }
         if (!cidx_.empty()) {
             auto it = std::lower_bound(cidx_.begin(), cidx_.end(), i);
             if (it != cidx_.end() && *it == i) return cval_[(size_t)(it - cidx_.begin())];
@@ -308,17 +318,19 @@ class Model {
     void set_sorted(const std::vector<int64_t> &index, const float *rgba, int channels,
                     bool occupy) {
         if (index.empty()) return;
+        fold_closure_list();
         // The planes are only touched to occupy voxels or to clear paint.  Voxels a device stage
         // has just occupied (the closure's: host_stale_) arrive with the planes at the next
         // sync, and they were empty before, hence not painted: nothing to touch.
         const bool touch = (occupy && !host_stale_) || (!occupy && (!paint_.empty() || paint_pending_));
         if (touch) sync_host();
-        std::vector<int> idx(index.size());
-        std::vector<Vec4f> val(index.size());
+        HostVector<int> idx(index.size());
+        HostVector<Vec4f> val(index.size());
         for (size_t k = 0; k < index.size(); ++k) {
             idx[k] = (int)index[k];
             const float *c = rgba + (size_t)channels * k;
             val[k] = Vec4f(c[0], c[1], c[2], channels == 4 ? c[3] : 1.f);
+            if (channels == 4 && c[3] != 0.f && c[3] != 1.f) odd_w_ = true;
         }
         if (touch)
             for (size_t k = 0; k < index.size(); ++k) {
@@ -334,25 +346,37 @@ class Model {
         if (cidx_.empty()) {
             cidx_.swap(idx);
             cval_.swap(val);
-        } else {  // merge, the new values win
-            std::vector<int> mi;
-            std::vector<Vec4f> mv;
-            mi.reserve(cidx_.size() + idx.size());
-            mv.reserve(cidx_.size() + idx.size());
-            size_t a = 0, b = 0;
-            while (a < cidx_.size() || b < idx.size()) {
-                if (b == idx.size() || (a < cidx_.size() && cidx_[a] < idx[b])) {
-                    mi.push_back(cidx_[a]);
-                    mv.push_back(cval_[a++]);
-                } else {
-                    if (a < cidx_.size() && cidx_[a] == idx[b]) ++a;
-                    mi.push_back(idx[b]);
-                    mv.push_back(val[b++]);
-                }
-            }
-            cidx_.swap(mi);
-            cval_.swap(mv);
+        } else {
+            merge_into_colors(idx, val);
         }
+        pristine_ = false;
+    }
+
+    // The closure's result (src/Postprocessing3d.cpp:52-60: model.set for every filled voxel),
+    // ascending flat index, as the device delivers it: kept as a list of its own beside the
+    // colour pass's -- get() looks there first --, so that a million-entry merge is not part of
+    // applyClosure.  The voxels are occupied on the DEVICE already (the caller has said
+    // device_changed_keep_paint()): the host planes get them with the next sync.
+    // unit_w: the caller vouches that every w is 1 (the device's means of w = 1 neighbours are
+    // count / count); otherwise the list is scanned for fractional w (see inside_state).
+    void set_closure_list(HostVector<int> &&index, HostVector<Vec4f> &&rgba, bool unit_w) {
+        fold_closure_list();  // (a second closure: the first one's list joins the colours)
+        if (index.empty()) return;
+        if (!unit_w)
+            for (const Vec4f &v : rgba)
+                if (v.w() != 0.f && v.w() != 1.f) odd_w_ = true;
+        if (!host_stale_) {  // the host planes are current: the voxels become occupied here
+            for (size_t k = 0; k < index.size(); ++k) {
+                const int x = index[k] % size_x, y = (index[k] / size_x) % size_y,
+                          z = index[k] / (size_x * size_y);
+                if (rgba[k].w() != 0) occ_[word(x, y, z)] |= 1u << (x & 31);
+                if (!paint_.empty()) paint_[word(x, y, z)] &= ~(1u << (x & 31));
+            }
+        }
+        if (!overlay_.empty())
+            for (size_t k = 0; k < index.size(); ++k) overlay_.erase(index[k]);
+        fidx_ = std::move(index);
+        fval_ = std::move(rgba);
         pristine_ = false;
     }
 
@@ -380,16 +404,21 @@ class Model {
             rgb.push_back(v.y());
             rgb.push_back(v.z());
         };
-        size_t a = 0, b = 0;
-        while (a < cidx_.size() || b < extra.size()) {
-            if (b == extra.size() || (a < cidx_.size() && cidx_[a] < extra[b].first)) {
-                emit(cidx_[a], cval_[a]);
-                ++a;
-            } else {
-                if (a < cidx_.size() && cidx_[a] == extra[b].first) ++a;
-                emit(extra[b].first, extra[b].second);
-                ++b;
-            }
+        // three sorted sources; on equal indices single set() calls win over the closure's list,
+        // and that over the colour pass's
+        size_t a = 0, f = 0, b = 0;
+        const int kEnd = 0x7fffffff;
+        for (;;) {
+            const int ia = a < cidx_.size() ? cidx_[a] : kEnd, jf = f < fidx_.size() ? fidx_[f] : kEnd,
+                      ib = b < extra.size() ? extra[b].first : kEnd;
+            const int i = std::min(ia, std::min(jf, ib));
+            if (i == kEnd) break;
+            if (ib == i) emit(i, extra[b].second);
+            else if (jf == i) emit(i, fval_[f]);
+            else emit(i, cval_[a]);
+            if (ia == i) ++a;
+            if (jf == i) ++f;
+            if (ib == i) ++b;
         }
         return plain;
     }
@@ -415,11 +444,15 @@ class Model {
     // the complement of src/MarchingCubes.h:481); `same_as_occupancy` tells the caller that the
     // occupancy on the device already is that plane (every w is 0 or 1, 0 < threshold <= 1)
     std::vector<uint8_t> inside_state(float threshold, bool &same_as_occupancy) const {
-        sync_host();
         same_as_occupancy = threshold > 0.f && threshold <= 1.f;
+        // no fractional w was ever stored: nothing to look at (and nothing to bring back from
+        // the device -- this is the path of every model the reference's own pipeline builds)
+        if (same_as_occupancy && !odd_w_) return {};
+        sync_host();
         auto odd = [&](const Vec4f &v) { return v.w() != 0.f && v.w() != 1.f; };
         for (const auto &kv : overlay_) same_as_occupancy = same_as_occupancy && !odd(kv.second);
         for (const Vec4f &v : cval_) same_as_occupancy = same_as_occupancy && !odd(v);
+        for (const Vec4f &v : fval_) same_as_occupancy = same_as_occupancy && !odd(v);
         if (same_as_occupancy) return {};
         std::vector<uint8_t> s(voxels());
         for (int z = 0; z < size_z; ++z)
@@ -428,7 +461,7 @@ class Model {
                     s[(size_t)flatten(x, y, z)] = get(x, y, z).w() >= threshold ? 1 : 0;
         return s;
     }
-    size_t colored_voxels() const { return cidx_.size() + overlay_.size(); }
+    size_t colored_voxels() const { return cidx_.size() + fidx_.size() + overlay_.size(); }
 
     // the two host planes themselves (ceil(X / 32) * Y * Z words each), for stages that fill
     // them from elsewhere (include/arvx/multi_gpu.hpp); call planes_replaced() afterwards
@@ -469,13 +502,16 @@ class Model {
     mutable std::vector<uint32_t> paint_;       // painted UNSEEN_COLOR (empty: none)
     bool pristine_ = true;
     bool paint_is_unseen_ = false;
+    bool odd_w_ = false;  // some colour with w outside {0, 1} was stored (sticky)
     mutable bool paint_pending_ = false;  // handleUnseen ran on the device: derive paint_ at sync
     mutable bool host_stale_ = false;     // the device holds a newer occupancy / seen
     bool device_stale_ = true;            // the host planes changed since the device saw them
     bool colors_on_device_ = false;
     bool closure_on_device_ = false, mc_only_ = false;
-    std::vector<int> cidx_;               // explicit colours, ascending flat index ...
-    std::vector<Vec4f> cval_;
+    HostVector<int> cidx_;                // explicit colours, ascending flat index ...
+    HostVector<Vec4f> cval_;
+    HostVector<int> fidx_;                // ... the closure's filled voxels, likewise ...
+    HostVector<Vec4f> fval_;
     std::unordered_map<int, Vec4f> overlay_;  // ... and what single set() calls stored since
     std::unordered_map<int, std::vector<DCLR>> color_lists_;
     std::shared_ptr<detail::DeviceLink> link_;
@@ -490,6 +526,37 @@ class Model {
         if (x < 0 || x >= size_x || y < 0 || y >= size_y || z < 0 || z >= size_z) return false;
         sync_host();
         return (occ_[word(x, y, z)] >> (x & 31)) & 1u;
+    }
+    // merge a sorted list into the colour list, the new values win
+    void merge_into_colors(const HostVector<int> &idx, const HostVector<Vec4f> &val) {
+        HostVector<int> mi;
+        HostVector<Vec4f> mv;
+        mi.reserve(cidx_.size() + idx.size());
+        mv.reserve(cidx_.size() + idx.size());
+        size_t a = 0, b = 0;
+        while (a < cidx_.size() || b < idx.size()) {
+            if (b == idx.size() || (a < cidx_.size() && cidx_[a] < idx[b])) {
+                mi.push_back(cidx_[a]);
+                mv.push_back(cval_[a++]);
+            } else {
+                if (a < cidx_.size() && cidx_[a] == idx[b]) ++a;
+                mi.push_back(idx[b]);
+                mv.push_back(val[b++]);
+            }
+        }
+        cidx_.swap(mi);
+        cval_.swap(mv);
+    }
+    void fold_closure_list() {
+        if (fidx_.empty()) return;
+        if (cidx_.empty()) {
+            cidx_.swap(fidx_);
+            cval_.swap(fval_);
+        } else {
+            merge_into_colors(fidx_, fval_);
+        }
+        HostVector<int>().swap(fidx_);
+        HostVector<Vec4f>().swap(fval_);
     }
     void host_changed() {
         pristine_ = false;

@@ -47,16 +47,18 @@ inline int applyClosure(Model *model, int kernelSize) {
                   "arvx_closure");
     int64_t n = 0;
     detail::check(arvx_closure_count(ctx, &n), "arvx_closure_count");
-    std::vector<int64_t> fidx((size_t)n);
-    std::vector<float> frgba((size_t)n * 4);
-    if (n) detail::check(arvx_closure_download(ctx, fidx.data(), frgba.data()),
-                         "arvx_closure_download");
+    // straight into the model's own arrays (recycled page-locked memory, host_pool.hpp)
+    static_assert(sizeof(Vec4f) == 4 * sizeof(float), "Vec4f is four packed floats");
+    HostVector<int> fidx((size_t)n);
+    HostVector<Vec4f> frgba((size_t)n);
+    if (n) detail::check(arvx_closure_download32(ctx, fidx.data(), &frgba[0].v[0]),
+                         "arvx_closure_download32");
     std::cout << "LOG - PP: starting erosion." << std::endl;  // a no-op in the reference too
     // the filled voxels: occupied on the device already, with their colours on the host now;
     // the context keeps its closure result, so the model goes back to "host is current" and a
     // second closure starts from a fresh upload
     model->device_changed_keep_paint();
-    model->set_sorted(fidx, frgba.data(), 4, true);
+    model->set_closure_list(std::move(fidx), std::move(frgba), true);
     model->closure_applied();
     detail::timing(kStagePostProcessing, false);
     std::cout << "LOG - PP: postprocessing completed." << std::endl;
