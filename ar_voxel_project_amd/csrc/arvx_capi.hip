@@ -162,10 +162,10 @@ static int bit_compact_count(Ctx *ctx, const unsigned long long *bits, size_t nw
 
 static int bit_compact_write(Ctx *ctx, const unsigned long long *bits, size_t nwords,
                              const arvx::BitGrid &g, const long long *d_off, int *d_index,
-                             int *d_rank) {
+                             arvx::SparseWord *d_words) {
     const int nblk = (int)((nwords + arvx::kBitChunk - 1) / arvx::kBitChunk);
     hipLaunchKernelGGL(arvx::bit_write_kernel, dim3(nblk), dim3(256), 0, ctx->stream, bits, nwords,
-                       g, d_off, d_index, d_rank);
+                       g, d_off, d_index, d_words);
     ARVX_HIP(hipGetLastError());
     return ARVX_OK;
 }
@@ -1199,7 +1199,7 @@ int arvx_color(arvx_ctx *ctx, int mode) {
     // the surface plane stays with the context: with its ranks it is the index of the colour
     // list (closure and mesh look colours up through it)
     ARVX_HIP(ctx->pool_col_bits.reserve(nw_own * sizeof(unsigned long long)));
-    ARVX_HIP(ctx->pool_col_rank.reserve(nw_own * sizeof(int)));
+    ARVX_HIP(ctx->pool_col_rank.reserve(nw_own * sizeof(arvx::SparseWord)));
     unsigned long long *d_occ = (unsigned long long *)ctx->d_scratch;
     unsigned long long *d_surf = (unsigned long long *)ctx->pool_col_bits.p;
     long long *d_off = (long long *)(d_occ + nw_ext);
@@ -1214,14 +1214,14 @@ int arvx_color(arvx_ctx *ctx, int mode) {
     if (total > 0) {
         ARVX_HIP(ctx->pool_surf_index.reserve((size_t)total * sizeof(int)));
         ctx->d_surf_index = (int *)ctx->pool_surf_index.p;
-        ARVX_HIP(ctx->pool_surf_rgb.reserve((size_t)total * 3 * sizeof(float)));
-        ctx->d_surf_rgb = (float *)ctx->pool_surf_rgb.p;
+        ARVX_HIP(ctx->pool_surf_rgb.reserve((size_t)total * sizeof(float4)));
+        ctx->d_surf_rgba = (float4 *)ctx->pool_surf_rgb.p;
         ARVX_HIP(ctx->pool_surf_depth.reserve((size_t)total * sizeof(float)));
         ctx->d_surf_depth = (float *)ctx->pool_surf_depth.p;
         ARVX_HIP(ctx->pool_surf_has.reserve((size_t)total));
         ctx->d_surf_has = (uint8_t *)ctx->pool_surf_has.p;
         if (int rc = bit_compact_write(ctx, d_surf, nw_own, gown, d_off, ctx->d_surf_index,
-                                       (int *)ctx->pool_col_rank.p))
+                                       (arvx::SparseWord *)ctx->pool_col_rank.p))
             return rc;
         arvx::VoteParams vp;
         vp.index = ctx->d_surf_index;
@@ -1237,7 +1237,7 @@ int arvx_color(arvx_ctx *ctx, int mode) {
         vp.campos = ctx->d_campos;
         vp.images = ctx->d_images;
         vp.mode = mode;
-        vp.rgb = ctx->d_surf_rgb;
+        vp.rgba = ctx->d_surf_rgba;
         vp.depth = ctx->d_surf_depth;
         vp.has = ctx->d_surf_has;
         hipLaunchKernelGGL(arvx::color_vote_kernel, dim3((unsigned)((total + 255) / 256)),
@@ -1268,10 +1268,10 @@ int arvx_surface_count(arvx_ctx *ctx, int64_t *count) {
 }
 
 static int surface_fetch(Ctx *ctx, std::vector<float> &rgb, std::vector<float> &depth) {
-    rgb.resize((size_t)ctx->surf_count * 3);
+    rgb.resize((size_t)ctx->surf_count * 4);  // (r, g, b, has) per entry
     depth.resize((size_t)ctx->surf_count);
     if (ctx->surf_count) {
-        ARVX_HIP(hipMemcpyAsync(rgb.data(), ctx->d_surf_rgb, rgb.size() * sizeof(float),
+        ARVX_HIP(hipMemcpyAsync(rgb.data(), ctx->d_surf_rgba, rgb.size() * sizeof(float),
                                 hipMemcpyDeviceToHost, ctx->stream));
         ARVX_HIP(hipMemcpyAsync(depth.data(), ctx->d_surf_depth, depth.size() * sizeof(float),
                                 hipMemcpyDeviceToHost, ctx->stream));
@@ -1291,9 +1291,9 @@ int arvx_surface_download(arvx_ctx *ctx, int64_t *index, float *rgb) {
     for (size_t e = 0; e < ctx->h_surf_has.size(); ++e) {
         if (!ctx->h_surf_has[e]) continue;
         index[k] = ctx->h_surf_index[e];
-        rgb[3 * k] = hrgb[3 * e];
-        rgb[3 * k + 1] = hrgb[3 * e + 1];
-        rgb[3 * k + 2] = hrgb[3 * e + 2];
+        rgb[3 * k] = hrgb[4 * e];
+        rgb[3 * k + 1] = hrgb[4 * e + 1];
+        rgb[3 * k + 2] = hrgb[4 * e + 2];
         ++k;
     }
     return ARVX_OK;
@@ -1345,9 +1345,8 @@ int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen) {
             if (last > first)
                 hipLaunchKernelGGL(arvx::export_scatter_kernel,
                                    dim3((unsigned)((last - first + 255) / 256)), dim3(256), 0,
-                                   ctx->stream, ctx->d_surf_index, ctx->d_surf_rgb,
-                                   ctx->d_surf_has, first, last, g, zown, paint_plane(ctx), i0,
-                                   d_out, apply_unseen);
+                                   ctx->stream, ctx->d_surf_index, ctx->d_surf_rgba, first, last,
+                                   g, zown, paint_plane(ctx), i0, d_out, apply_unseen);
         }
         if (ctx->closure_ready && ctx->clo_count > 0) {
             const auto &idx = ctx->h_clo_index;
@@ -1452,16 +1451,23 @@ int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const flo
     if (n > 0) {
         ARVX_HIP(ctx->pool_surf_index.reserve((size_t)n * sizeof(int)));
         ctx->d_surf_index = (int *)ctx->pool_surf_index.p;
-        ARVX_HIP(ctx->pool_surf_rgb.reserve((size_t)n * 3 * sizeof(float)));
-        ctx->d_surf_rgb = (float *)ctx->pool_surf_rgb.p;
+        ARVX_HIP(ctx->pool_surf_rgb.reserve((size_t)n * sizeof(float4)));
+        ctx->d_surf_rgba = (float4 *)ctx->pool_surf_rgb.p;
         ARVX_HIP(ctx->pool_surf_depth.reserve((size_t)n * sizeof(float)));
         ctx->d_surf_depth = (float *)ctx->pool_surf_depth.p;
         ARVX_HIP(ctx->pool_surf_has.reserve((size_t)n));
         ctx->d_surf_has = (uint8_t *)ctx->pool_surf_has.p;
         ARVX_HIP(hipMemcpyAsync(ctx->d_surf_index, idx.data(), (size_t)n * sizeof(int),
                                 hipMemcpyHostToDevice, ctx->stream));
-        ARVX_HIP(hipMemcpyAsync(ctx->d_surf_rgb, rgb, (size_t)n * 3 * sizeof(float),
+        // three floats per voxel from the host, (r, g, b, has = 1) on the device
+        if (int rc = ensure_scratch(ctx, (size_t)n * 3 * sizeof(float) + 64)) return rc;
+        ARVX_HIP(hipMemcpyAsync(ctx->d_scratch, rgb, (size_t)n * 3 * sizeof(float),
                                 hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(arvx::rgb_to_rgba_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           ctx->stream, (const float *)ctx->d_scratch, (long long)n,
+                           ctx->d_surf_rgba);
+        ARVX_HIP(hipGetLastError());
+        ARVX_HIP(hipStreamSynchronize(ctx->stream));  // (the scratch buffer is reused below)
         ARVX_HIP(hipMemsetAsync(ctx->d_surf_depth, 0, (size_t)n * sizeof(float), ctx->stream));
         ARVX_HIP(hipMemsetAsync(ctx->d_surf_has, 1, (size_t)n, ctx->stream));
         // the list's plane + ranks (what arvx_color leaves behind)
@@ -1470,7 +1476,7 @@ int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const flo
         const size_t nw = (size_t)XW * gown.Y * gown.Z;
         const int nblk = (int)((nw + arvx::kBitChunk - 1) / arvx::kBitChunk);
         ARVX_HIP(ctx->pool_col_bits.reserve(nw * sizeof(unsigned long long)));
-        ARVX_HIP(ctx->pool_col_rank.reserve(nw * sizeof(int)));
+        ARVX_HIP(ctx->pool_col_rank.reserve(nw * sizeof(arvx::SparseWord)));
         if (int rc = ensure_scratch(ctx, (size_t)(nblk + 1) * sizeof(long long) +
                                              (size_t)nblk * sizeof(int) + 64))
             return rc;
@@ -1484,7 +1490,7 @@ int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const flo
         long long total = 0;
         if (int rc = bit_compact_count(ctx, bits, nw, d_cnt, d_off, &total)) return rc;
         if (int rc = bit_compact_write(ctx, bits, nw, gown, d_off, nullptr,
-                                       (int *)ctx->pool_col_rank.p))
+                                       (arvx::SparseWord *)ctx->pool_col_rank.p))
             return rc;
         ARVX_HIP(hipStreamSynchronize(ctx->stream));
     }
@@ -1494,14 +1500,12 @@ int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const flo
 
 // the context's sparse lists as plane + rank (empty: nulls)
 static arvx::SparseList colour_list(const Ctx *ctx) {
-    if (!ctx->color_ready || ctx->surf_count <= 0) return arvx::SparseList{nullptr, nullptr};
-    return arvx::SparseList{(const unsigned long long *)ctx->pool_col_bits.p,
-                            (const int *)ctx->pool_col_rank.p};
+    if (!ctx->color_ready || ctx->surf_count <= 0) return arvx::SparseList{nullptr};
+    return arvx::SparseList{(const arvx::SparseWord *)ctx->pool_col_rank.p};
 }
 static arvx::SparseList closure_list(const Ctx *ctx) {
-    if (!ctx->closure_ready || ctx->clo_count <= 0) return arvx::SparseList{nullptr, nullptr};
-    return arvx::SparseList{(const unsigned long long *)ctx->pool_clo_bits.p,
-                            (const int *)ctx->pool_clo_rank.p};
+    if (!ctx->closure_ready || ctx->clo_count <= 0) return arvx::SparseList{nullptr};
+    return arvx::SparseList{(const arvx::SparseWord *)ctx->pool_clo_rank.p};
 }
 
 int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
@@ -1526,7 +1530,7 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
                                          (size_t)nblk * sizeof(int) + 64))
         return rc;
     ARVX_HIP(ctx->pool_clo_bits.reserve(nwords * sizeof(unsigned long long)));
-    ARVX_HIP(ctx->pool_clo_rank.reserve(nwords * sizeof(int)));
+    ARVX_HIP(ctx->pool_clo_rank.reserve(nwords * sizeof(arvx::SparseWord)));
     unsigned long long *d_occ = (unsigned long long *)ctx->d_scratch;
     unsigned long long *d_unseen = d_occ + nwords, *d_a = d_unseen + nwords, *d_b = d_a + nwords;
     unsigned long long *d_fill = (unsigned long long *)ctx->pool_clo_bits.p;
@@ -1551,7 +1555,7 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
         ARVX_HIP(ctx->pool_clo_rgba.reserve((size_t)total * sizeof(float4)));
         ctx->d_clo_rgba = (void *)ctx->pool_clo_rgba.p;
         if (int rc = bit_compact_write(ctx, d_fill, nwords, g, d_off, ctx->d_clo_index,
-                                       (int *)ctx->pool_clo_rank.p))
+                                       (arvx::SparseWord *)ctx->pool_clo_rank.p))
             return rc;
         arvx::ClosureParams cp;
         cp.g = g;
@@ -1559,8 +1563,7 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
         cp.unseen = paints ? d_unseen : nullptr;
         cp.radius = radius;
         cp.col = colour_list(ctx);
-        cp.col_rgb = ctx->d_surf_rgb;
-        cp.col_has = ctx->d_surf_has;
+        cp.col_rgba = ctx->d_surf_rgba;
         if (radius == 1)
             hipLaunchKernelGGL(arvx::closure_fill_kernel<true>, dim3((unsigned)((total + 255) / 256)),
                                dim3(256), 0, ctx->stream, cp, ctx->d_clo_index, total,
@@ -1733,11 +1736,10 @@ int arvx_mc_mesh(arvx_ctx *ctx, int apply_unseen, int64_t *triangles) {
         mp.paint = paint_plane(ctx);
         mp.apply_unseen = apply_unseen ? 1 : 0;
         mp.col = colour_list(ctx);
-        mp.col_rgb = ctx->d_surf_rgb;
-        mp.col_has = ctx->d_surf_has;
+        mp.col_rgba = ctx->d_surf_rgba;
         mp.clo = closure_list(ctx);
         mp.clo_rgba = (const float4 *)ctx->d_clo_rgba;
-        hipLaunchKernelGGL(arvx::mc_mesh_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0,
+        hipLaunchKernelGGL(arvx::mc_mesh_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                            ctx->stream, mp,
                            (const int4 *)ctx->d_mc_cells, (long long)n, d_off,
                            (float *)ctx->pool_mesh_verts.p, (unsigned *)ctx->pool_mesh_rgb.p);

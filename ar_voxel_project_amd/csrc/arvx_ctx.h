@@ -103,14 +103,14 @@ struct Ctx {
     uint8_t *d_images = nullptr;  // V x H x W x 3, BGR
     bool images_ready = false;
     int *d_surf_index = nullptr;      // compacted flat indices (slab-local)
-    float *d_surf_rgb = nullptr;      // 3 floats per surface voxel
+    float4 *d_surf_rgba = nullptr;    // r, g, b, has-sample flag per surface voxel
     float *d_surf_depth = nullptr;    // minimum sample depth per surface voxel
     uint8_t *d_surf_has = nullptr;    // 1 if the voxel received >= 1 sample
     int64_t surf_count = 0;           // occupied non-inner voxels found
     std::vector<int> h_surf_index;    // host copy (ascending)
     std::vector<uint8_t> h_surf_has;
     bool color_ready = false;
-    // the list as plane + rank (bitplane_kernels.h, sparse_find) over the owned planes
+    // the list's plane and its index (bitplane_kernels.h, SparseWord) over the owned planes
     DevPool pool_col_bits, pool_col_rank;
 
     // closure (dilation) result: filled voxels, ascending index
@@ -120,7 +120,7 @@ struct Ctx {
     bool closure_ready = false;
     int closure_unseen = 0;
     std::vector<int> h_clo_index;
-    DevPool pool_clo_bits, pool_clo_rank;  // the filled voxels as plane + rank
+    DevPool pool_clo_bits, pool_clo_rank;  // the filled voxels' plane and index (SparseWord)
 
     // marching-cubes hand-off: active cells (x, y, z, cube index), reference order
     void *d_mc_cells = nullptr;
@@ -176,7 +176,8 @@ struct Ctx {
     void free_surface() {
         free_closure();
         d_surf_index = nullptr;
-        d_surf_rgb = d_surf_depth = nullptr;
+        d_surf_rgba = nullptr;
+        d_surf_depth = nullptr;
         d_surf_has = nullptr;
         color_ready = false;
         surf_count = 0;

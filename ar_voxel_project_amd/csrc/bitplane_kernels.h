@@ -11,9 +11,9 @@
 //
 // A sparse per-voxel list (the colour pass's colours, the closure's filled voxels) is the ordered
 // compaction of such a plane: entry k belongs to the k-th set bit.  Next to the plane the
-// context keeps `rank`, one int per word = number of set bits before that word, so that the
-// list position of a voxel is rank[word] + popcount(bits below it): one lookup instead of a
-// binary search (sparse_find).
+// context keeps one SparseWord per word -- the word's bits and the number of set bits before
+// it, 16 bytes, ONE load --, so that the list position of a voxel is rank + popcount(bits below
+// it) instead of a binary search (sparse_find).
 #pragma once
 
 #include "arvx_device.h"
@@ -107,13 +107,19 @@ __global__ __launch_bounds__(256) void bit_count_kernel(const unsigned long long
     if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// index[k] = flat index (x + X*row) of the k-th set bit, ascending; rank[w] = set bits before
-// word w.  Either output may be null.
+struct __attribute__((aligned(16))) SparseWord {
+    unsigned long long bits;
+    int rank;  // set bits before this word
+    int pad;
+};
+
+// index[k] = flat index (x + X*row) of the k-th set bit, ascending; words[w] = {bits, set bits
+// before word w}.  Either output may be null.
 __global__ __launch_bounds__(256) void bit_write_kernel(const unsigned long long *__restrict__ bits,
                                                         size_t nwords, const BitGrid g,
                                                         const long long *__restrict__ offsets,
                                                         int *__restrict__ index,
-                                                        int *__restrict__ rank) {
+                                                        SparseWord *__restrict__ words) {
     __shared__ int wtot[4];
     const size_t base = (size_t)blockIdx.x * kBitChunk;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256) void bit_write_kernel(const unsigned long long
         __syncthreads();
         long long slot = run + sc - n;
         for (int v = 0; v < wave; ++v) slot += wtot[v];
-        if (rank && w < nwords) rank[w] = (int)slot;
+        if (words && w < nwords) words[w] = SparseWord{b, (int)slot, 0};
         if (b && index) {
             const size_t row = w / g.XW;
             const int x0 = (int)(w % g.XW) * 64;
@@ -159,19 +165,27 @@ __global__ __launch_bounds__(256) void bits_from_index_kernel(const int *__restr
     atomicOr(bits + row * g.XW + (x >> 6), 1ull << (x & 63));
 }
 
-// a sparse list as plane + rank (null plane: empty list)
+// a sparse list's index (null: empty list)
 struct SparseList {
-    const unsigned long long *bits;
-    const int *rank;
+    const SparseWord *w;
 };
+// position of bit sh of a word in the list, or -1
+__device__ __forceinline__ int sparse_rank(const SparseWord &e, int sh) {
+    if (!((e.bits >> sh) & 1ull)) return -1;
+    return e.rank + __popcll(e.bits & ((1ull << sh) - 1ull));
+}
+__device__ __forceinline__ SparseWord sparse_word(const SparseList &l, size_t at) {
+    const uint4 q = *reinterpret_cast<const uint4 *>(l.w + at);  // one 16-byte load
+    SparseWord e;
+    e.bits = (unsigned long long)q.x | ((unsigned long long)q.y << 32);
+    e.rank = (int)q.z;
+    e.pad = 0;
+    return e;
+}
 // position of voxel (x, row) in the list, or -1
 __device__ __forceinline__ int sparse_find(const SparseList &l, int XW, int x, size_t row) {
-    if (!l.bits) return -1;
-    const size_t w = row * XW + (x >> 6);
-    const unsigned long long b = l.bits[w];
-    const int sh = x & 63;
-    if (!((b >> sh) & 1ull)) return -1;
-    return l.rank[w] + __popcll(b & ((1ull << sh) - 1ull));
+    if (!l.w) return -1;
+    return sparse_rank(sparse_word(l, row * XW + (x >> 6)), x & 63);
 }
 
 }  // namespace arvx

@@ -27,9 +27,8 @@ struct ClosureParams {
     const unsigned long long *occ;     // what the closure calls occupied
     const unsigned long long *unseen;  // voxels whose colour is UNSEEN_COLOR (null: none)
     int radius;                        // (kernelSize - 1) / 2
-    SparseList col;                    // the colour pass's list: plane + rank ...
-    const float *col_rgb;              // ... rgb and has-sample flag per entry
-    const uint8_t *col_has;
+    SparseList col;                    // the colour pass's list: its index ...
+    const float4 *col_rgba;            // ... and r, g, b, has-sample flag per entry
 };
 
 // colour of an occupied voxel as Model::get returns it at src/main.cpp:297
@@ -37,8 +36,10 @@ __device__ inline float4 cl_color(const ClosureParams &p, int x, size_t row) {
     if (p.unseen && ((p.unseen[row * p.g.XW + (x >> 6)] >> (x & 63)) & 1ull))
         return make_float4(204.f, 0.f, 0.f, 1.f);
     const int k = sparse_find(p.col, p.g.XW, x, row);
-    if (k >= 0 && p.col_has[k])
-        return make_float4(p.col_rgb[3 * k], p.col_rgb[3 * k + 1], p.col_rgb[3 * k + 2], 1.f);
+    if (k >= 0) {
+        const float4 c = p.col_rgba[k];
+        if (c.w != 0.f) return make_float4(c.x, c.y, c.z, 1.f);
+    }
     return make_float4(50.f, 168.f, 141.f, 1.f);
 }
 
@@ -75,7 +76,7 @@ __device__ inline int cl_gather(const ClosureParams &p, size_t i, float4 &sum) {
 
 // The 3x3x3 box (kernelSize 3, what src/main.cpp:298 passes) without a dependent load per
 // neighbour: the nine voxel rows around the voxel are read as words first -- occupancy, UNSEEN
-// paint, the colour list's plane and ranks: 36 independent loads --, then the colours of nine
+// paint, the colour list's index words: 27 independent loads --, then the colours of nine
 // neighbours at a time (one x offset) are fetched together and added in the reference's order
 // (x offset outermost, then y, then z, src/Postprocessing3d.cpp:31-48).
 __device__ inline int cl_gather3(const ClosureParams &p, size_t i, float4 &sum) {
@@ -85,9 +86,8 @@ __device__ inline int cl_gather3(const ClosureParams &p, size_t i, float4 &sum) 
     const int y = (int)(t % Y), z = (int)(t / Y);
     const int xw = x >> 6, xb = x & 63;
     // 3-bit windows of the rows (y + b, z + c): bit a + 1 = voxel x + a
-    unsigned occ3[9], uns3[9], col3[9];
-    int rank_lo[9];          // rank of the window's first listed voxel
-    unsigned long long colw[9];
+    unsigned occ3[9], uns3[9];
+    SparseWord colw[9];  // the colour list's word of the row
     auto window = [&](const unsigned long long *plane, size_t at, bool row_ok) -> unsigned {
         if (!plane || !row_ok) return 0u;
         const unsigned long long w = plane[at];
@@ -103,40 +103,33 @@ __device__ inline int cl_gather3(const ClosureParams &p, size_t i, float4 &sum) 
         const size_t at = ok ? ((size_t)zn * Y + yn) * XW + xw : 0;
         occ3[r] = window(p.occ, at, ok);
         uns3[r] = window(p.unseen, at, ok);
-        col3[r] = window(p.col.bits, at, ok);
-        colw[r] = (p.col.bits && ok) ? p.col.bits[at] : 0ull;
-        rank_lo[r] = (p.col.bits && ok) ? p.col.rank[at] : 0;
+        colw[r] = (p.col.w && ok) ? sparse_word(p.col, at) : SparseWord{0ull, 0, 0};
     }
     int count = 0;
     sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {  // x offset a - 1
         const int xn = x + a - 1;
-        float3 rgb[9];
-        bool has[9];
+        float4 rgb[9];  // w = has-sample flag; (0, 0, 0, 0): not in the list
 #pragma unroll
         for (int r = 0; r < 9; ++r) {  // the nine lookups of this x offset, all in flight
             int k = -1;
-            if ((col3[r] >> a) & 1u) {
-                // position in the list: rank of the voxel's own word + listed voxels below it
+            if (p.col.w && ((occ3[r] >> a) & 1u)) {
                 if (xn >> 6 == xw) {
-                    k = rank_lo[r] + __popcll(colw[r] & ((1ull << (xn & 63)) - 1ull));
-                } else {  // the neighbour lies in the next / previous word of the row
+                    k = sparse_rank(colw[r], xn & 63);
+                } else if (xn >= 0 && xn < X) {  // the next / previous word of the row
                     const int yn = y + r / 3 - 1, zn = z + r % 3 - 1;
                     k = sparse_find(p.col, XW, xn, (size_t)zn * Y + yn);
                 }
             }
-            has[r] = k >= 0 && p.col_has[k];
-            const int kk = k >= 0 ? k : 0;
-            rgb[r] = (k >= 0) ? make_float3(p.col_rgb[3 * kk], p.col_rgb[3 * kk + 1], p.col_rgb[3 * kk + 2])
-                              : make_float3(0.f, 0.f, 0.f);
+            rgb[r] = (k >= 0) ? p.col_rgba[k] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             if (!((occ3[r] >> a) & 1u)) continue;
             ++count;
             float4 v = make_float4(50.f, 168.f, 141.f, 1.f);
-            if (has[r]) v = make_float4(rgb[r].x, rgb[r].y, rgb[r].z, 1.f);
+            if (rgb[r].w != 0.f) v = make_float4(rgb[r].x, rgb[r].y, rgb[r].z, 1.f);
             if ((uns3[r] >> a) & 1u) v = make_float4(204.f, 0.f, 0.f, 1.f);
             sum.x = sum.x + v.x;
             sum.y = sum.y + v.y;

@@ -56,7 +56,7 @@ struct VoteParams {
     const float *campos;  // V x 3
     const uint8_t *images;  // V x H x W x 3 BGR
     int mode;
-    float *rgb;    // n x 3
+    float4 *rgba;  // n: r, g, b and 1 if the voxel received >= 1 sample, else 0
     float *depth;  // n   (minimum sample depth)
     uint8_t *has;  // n   (1 if >= 1 sample)
 };
@@ -120,9 +120,7 @@ __global__ __launch_bounds__(256) void color_vote_kernel(const VoteParams p) {
             o2 = roundf((float)sb / fn);
         }
     }
-    p.rgb[3 * t] = o0;
-    p.rgb[3 * t + 1] = o1;
-    p.rgb[3 * t + 2] = o2;
+    p.rgba[t] = make_float4(o0, o1, o2, n ? 1.f : 0.f);
 }
 
 }  // namespace arvx

@@ -26,7 +26,7 @@
 namespace arvx {
 
 struct McTriTable {
-    int8_t e[256][16];  // edge numbers, three per triangle, -1 terminated
+    alignas(16) int8_t e[256][16];  // edge numbers, three per triangle, -1 terminated
     int8_t n[256];      // triangles per cube index
 };
 
@@ -47,24 +47,25 @@ struct McMeshParams {
     CarveParams g;         // the state records (whole grid)
     const unsigned long long *paint;  // voxels painted UNSEEN_COLOR by the host (null: none)
     int apply_unseen;      // never-seen voxels are painted UNSEEN_COLOR
-    SparseList col;        // colour pass: plane + rank, rgb, has-sample flag
-    const float *col_rgb;
-    const uint8_t *col_has;
-    SparseList clo;        // closure: plane + rank, rgba
+    SparseList col;        // colour pass: index, (r, g, b, has-sample flag)
+    const float4 *col_rgba;
+    SparseList clo;        // closure: index, rgba
     const float4 *clo_rgba;
 };
 
 // rgb of an occupied voxel
 __device__ inline float3 mc_voxel_rgb(const McMeshParams &p, int x, int y, int z) {
     const int X = p.g.X, Y = p.g.Y, XW = (X + 63) >> 6;
-    if (plane_bit(p.paint, X, Y, x, y, z) || (p.apply_unseen && !(rec_state(p.g, x, y, z) & 2u)))
+    if (plane_bit(p.paint, X, Y, x, y, z) || (p.apply_unseen && !rec_seen(p.g, x, y, z)))
         return make_float3(204.f, 0.f, 0.f);
     const size_t row = (size_t)z * Y + y;
     int k = sparse_find(p.clo, XW, x, row);
     if (k >= 0) return make_float3(p.clo_rgba[k].x, p.clo_rgba[k].y, p.clo_rgba[k].z);
     k = sparse_find(p.col, XW, x, row);
-    if (k >= 0 && p.col_has[k])
-        return make_float3(p.col_rgb[3 * k], p.col_rgb[3 * k + 1], p.col_rgb[3 * k + 2]);
+    if (k >= 0) {
+        const float4 c = p.col_rgba[k];
+        if (c.w != 0.f) return make_float3(c.x, c.y, c.z);
+    }
     return make_float3(50.f, 168.f, 141.f);
 }
 
@@ -81,67 +82,92 @@ __device__ __forceinline__ unsigned mc_mean3(float a, float b, float c) {
 
 constexpr int kMeshMaxTris = 5;  // Bourke's table: at most five triangles per cell
 
-// One WAVE per workgroup, one cell per lane.  The triangles of 64 consecutive cells are one
-// contiguous range of the output (tri_offset is the exclusive scan of their counts), so the
-// lanes build theirs in LDS and the wave then streams the range out in whole lines: 36 bytes of
-// vertices and 24 bytes of face record per triangle leave as coalesced dword stores instead of
-// twelve scattered ones per triangle.
+// The triangles of the 64 consecutive cells of a wave are one contiguous range of the output
+// (tri_offset is the exclusive scan of their counts).  Three steps per wave, through LDS:
+//   A  lane = cell: the cell's triangles as packed descriptors (corner of the cell, nine corner
+//      offset bits) -- no memory traffic beyond the table row, read as ONE 16-byte load;
+//   B  lane = triangle: the two voxel-colour lookups and the face colour.  Cells have one to
+//      five triangles; per triangle every lane is busy, per cell the wave would wait for its
+//      slowest lane;
+//   C  the range streams out in whole lines: 36 bytes of vertices and 24 bytes of face record
+//      per triangle leave as coalesced dword stores.
 //   verts  9 floats per triangle (three fresh vertices, voxel units)
 //   faces  6 uints per triangle: vertex numbers 3t, 3t+1, 3t+2, then r, g, b -- the layout of
 //          the C++ layer's Triangle (include/arvx/marching_cubes.hpp), reference
 //          src/MarchingCubes.h:19-31
-// Only the first two corners' colours are ever used (col[2] = col[1], :506): two voxel lookups
-// per triangle.
-__global__ __launch_bounds__(64) void mc_mesh_kernel(const McMeshParams p,
-                                                     const int4 *__restrict__ cells, long long n,
-                                                     const long long *__restrict__ tri_offset,
-                                                     float *__restrict__ verts,
-                                                     unsigned *__restrict__ faces) {
-    __shared__ float s_vert[64 * kMeshMaxTris * 9];
-    __shared__ unsigned s_rgb[64 * kMeshMaxTris * 3];
-    const int lane = threadIdx.x;
-    const long long c = (long long)blockIdx.x * 64 + lane;
-    const long long c0 = (long long)blockIdx.x * 64;
+// Only the first two corners' colours are ever used (col[2] = col[1], :506).
+__global__ __launch_bounds__(256) void mc_mesh_kernel(const McMeshParams p,
+                                                      const int4 *__restrict__ cells, long long n,
+                                                      const long long *__restrict__ tri_offset,
+                                                      float *__restrict__ verts,
+                                                      unsigned *__restrict__ faces) {
+    // per wave and triangle: {x + 1 | (y + 1) << 16, z + 1 | offset bits << 16, r, g, b}
+    __shared__ uint32_t s_tri[4][64 * kMeshMaxTris][5];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long c0 = ((long long)blockIdx.x * 4 + wave) * 64;
+    if (c0 >= n) return;  // (no workgroup-wide barrier below: a wave only touches its own part)
+    const long long c = c0 + lane;
     const long long clast = (c0 + 63 < n - 1) ? c0 + 63 : n - 1;
     const long long base = tri_offset[c0];
+    const int ntri = (int)(tri_offset[clast] - base) + kMcTri.n[cells[clast].w & 255];
+    uint32_t(*mine)[5] = s_tri[wave];
     // corner i of ProcessVoxel (src/MarchingCubes.h:537-552); bit i of idx set = NOT in the model
     // x offsets of corners 0..7: 1 0 0 1 1 0 0 1; y: 0 0 1 1 0 0 1 1; z: 0 0 0 0 1 1 1 1
     constexpr unsigned kCx = 0x99u, kCy = 0xCCu, kCz = 0xF0u;
-    if (c < n) {
+    if (c < n) {  // ---- A
         const int4 cell = cells[c];
         const int idx = cell.w & 255;
-        int t = (int)(tri_offset[c] - base);
-        const int8_t *row = kMcTri.e[idx];
-        for (int k = 0; row[k] >= 0; k += 3, ++t) {
-            int vx[3], vy[3], vz[3];
+        const int t0 = (int)(tri_offset[c] - base), nt = kMcTri.n[idx];
+        const uint4 rw = *reinterpret_cast<const uint4 *>(kMcTri.e[idx]);  // 16 edge numbers
+        const unsigned long long elo = (unsigned long long)rw.x | ((unsigned long long)rw.y << 32),
+                                 ehi = (unsigned long long)rw.z | ((unsigned long long)rw.w << 32);
+        // (cell coordinates start at -1: stored + 1; grids are at most 16384 wide)
+        const uint32_t w0 = (uint32_t)(cell.x + 1) | ((uint32_t)(cell.y + 1) << 16);
+        for (int k = 0; k < nt; ++k) {
+            unsigned bits = 0;  // bit 3 v + axis: offset of vertex v along the axis
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
-                const int e = row[k + v];
+                const int j = 3 * k + v;
+                const int e = (int)(((j < 8 ? elo >> (8 * j) : ehi >> (8 * (j - 8)))) & 15ull);
                 const int a = e & 7, b = mc::kSecondCorner[e];  // e % 8 and its partner (:491)
                 const int cn = ((idx >> a) & 1) ? b : a;         // the corner that is in the model
-                vx[v] = cell.x + (int)((kCx >> cn) & 1u);
-                vy[v] = cell.y + (int)((kCy >> cn) & 1u);
-                vz[v] = cell.z + (int)((kCz >> cn) & 1u);
-                float *o = s_vert + 9 * t + 3 * v;
-                o[0] = (float)vx[v];
-                o[1] = (float)vy[v];
-                o[2] = (float)vz[v];
+                bits |= (((kCx >> cn) & 1u) | (((kCy >> cn) & 1u) << 1) | (((kCz >> cn) & 1u) << 2))
+                        << (3 * v);
             }
-            const float3 q0 = mc_voxel_rgb(p, vx[0], vy[0], vz[0]);
-            const float3 q1 = mc_voxel_rgb(p, vx[1], vy[1], vz[1]);  // col[2] = col[1], :506
-            s_rgb[3 * t] = mc_mean3(q0.x, q1.x, q1.x);
-            s_rgb[3 * t + 1] = mc_mean3(q0.y, q1.y, q1.y);
-            s_rgb[3 * t + 2] = mc_mean3(q0.z, q1.z, q1.z);
+            mine[t0 + k][0] = w0;
+            mine[t0 + k][1] = (uint32_t)(cell.z + 1) | (bits << 16);
         }
     }
-    __syncthreads();
-    const int ntri = (int)(tri_offset[clast] - base) + kMcTri.n[cells[clast].w & 255];
-    float *vo = verts + 9 * base;
-    for (int i = lane; i < 9 * ntri; i += 64) vo[i] = s_vert[i];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < ntri; t += 64) {  // ---- B
+        const uint32_t w0 = mine[t][0], w1 = mine[t][1];
+        const int x = (int)(w0 & 0xffffu) - 1, y = (int)(w0 >> 16) - 1, z = (int)(w1 & 0xffffu) - 1;
+        const unsigned bits = w1 >> 16;
+        const float3 q0 = mc_voxel_rgb(p, x + (int)(bits & 1u), y + (int)((bits >> 1) & 1u),
+                                       z + (int)((bits >> 2) & 1u));
+        const float3 q1 = mc_voxel_rgb(p, x + (int)((bits >> 3) & 1u), y + (int)((bits >> 4) & 1u),
+                                       z + (int)((bits >> 5) & 1u));  // col[2] = col[1], :506
+        mine[t][2] = mc_mean3(q0.x, q1.x, q1.x);
+        mine[t][3] = mc_mean3(q0.y, q1.y, q1.y);
+        mine[t][4] = mc_mean3(q0.z, q1.z, q1.z);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    float *vo = verts + 9 * base;  // ---- C
+    for (int i = lane; i < 9 * ntri; i += 64) {
+        const int t = i / 9, comp = i - 9 * t, axis = comp % 3;
+        const uint32_t w0 = mine[t][0], w1 = mine[t][1];
+        const int origin = axis == 0 ? (int)(w0 & 0xffffu) : axis == 1 ? (int)(w0 >> 16)
+                                                                        : (int)(w1 & 0xffffu);
+        vo[i] = (float)(origin - 1 + (int)((w1 >> (16 + comp)) & 1u));
+    }
     unsigned *fo = faces + 6 * base;
     for (int i = lane; i < 6 * ntri; i += 64) {
         const int t = i / 6, f = i - 6 * t;
-        fo[i] = f < 3 ? (unsigned)(3 * (base + t) + f) : s_rgb[3 * t + f - 3];
+        fo[i] = f < 3 ? (unsigned)(3 * (base + t) + f) : mine[t][f - 1];
     }
 }
 

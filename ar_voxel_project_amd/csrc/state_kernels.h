@@ -98,6 +98,10 @@ __device__ __forceinline__ uint32_t rec_state(const CarveParams &p, int x, int y
     const int r = (lz & 7) * 8 + (y & 7), b = x & 15;
     return ((rec[r] >> b) & 1u) | (((rec[64 + r] >> b) & 1u) << 1);
 }
+__device__ __forceinline__ bool rec_seen(const CarveParams &p, int x, int y, int lz) {
+    const uint16_t *rec = p.rec + rec_index(p, x >> 6, y >> 3, lz >> 3, (x >> 4) & 3) * kRecU16;
+    return (rec[64 + (lz & 7) * 8 + (y & 7)] >> (x & 15)) & 1u;
+}
 // one bit of a plane in the layout of bitplane_kernels.h (null plane: 0)
 __device__ __forceinline__ uint32_t plane_bit(const unsigned long long *__restrict__ bits, int X,
                                               int Y, int x, int y, int lz) {
@@ -291,20 +295,29 @@ __global__ __launch_bounds__(256) void export_fill_kernel(const CarveParams p, i
     }
 }
 
+// an uploaded colour list (3 floats per voxel) in the device's form (r, g, b, has = 1)
+__global__ __launch_bounds__(256) void rgb_to_rgba_kernel(const float *__restrict__ rgb, long long n,
+                                                          float4 *__restrict__ rgba) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) rgba[k] = make_float4(rgb[3 * k], rgb[3 * k + 1], rgb[3 * k + 2], 1.f);
+}
+
 __global__ __launch_bounds__(256) void export_scatter_kernel(
-    const int *__restrict__ index, const float *__restrict__ rgb, const uint8_t *__restrict__ has,
-    long long first, long long last, const CarveParams p, int zown,
+    const int *__restrict__ index, const float4 *__restrict__ rgba, long long first,
+    long long last, const CarveParams p, int zown,
     const unsigned long long *__restrict__ paint, size_t i0, float4 *__restrict__ out,
     int apply_unseen) {
     const long long e = first + (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= last || !has[e]) return;
+    if (e >= last) return;
+    const float4 c = rgba[e];
+    if (c.w == 0.f) return;  // no sample: the voxel keeps what the state says
     const size_t i = (size_t)index[e];
     const int x = (int)(i % p.X), y = (int)((i / p.X) % p.Y),
               lz = zown + (int)(i / ((size_t)p.X * p.Y));
     // handleUnseen runs after colouring
     if (plane_bit(paint, p.X, p.Y, x, y, lz) || (apply_unseen && !(rec_state(p, x, y, lz) & 2u)))
         return;
-    out[i - i0] = make_float4(rgb[3 * e], rgb[3 * e + 1], rgb[3 * e + 2], 1.f);
+    out[i - i0] = make_float4(c.x, c.y, c.z, 1.f);
 }
 
 }  // namespace arvx
