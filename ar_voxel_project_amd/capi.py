@@ -27,6 +27,8 @@ COLOR_AVERAGE = 1
 # every symbol include/arvx/arvx.h declares
 SYMBOLS = [
     "arvx_version", "arvx_last_error", "arvx_device_count", "arvx_projection_assoc",
+    "arvx_set_projection_assoc", "arvx_ctx_set_projection_assoc", "arvx_ctx_projection_assoc",
+    "arvx_selftest_project", "arvx_selftest_depth",
     "arvx_ctx_create", "arvx_ctx_create_slab", "arvx_ctx_create_striped", "arvx_ctx_destroy",
     "arvx_ctx_set_stream", "arvx_ctx_set_exchange_stream", "arvx_ctx_synchronize", "arvx_ctx_voxels",
     "arvx_compose_projection", "arvx_set_views", "arvx_set_views_device",
@@ -65,13 +67,12 @@ class Stats(C.Structure):
 
 
 _libs: dict = {}
-# the build with the other grouping of the M*world row sums (csrc/arvx_device.h, row_sum)
-ASSOC_LEFT_LIB_PATH = os.path.join(_HERE, "lib", "libarvx_assoc_left.so")
+ASSOC_RIGHT, ASSOC_LEFT = 0, 1  # grouping of the M*world row sums (include/arvx/arvx.h)
 
 
 def load_library(path: Optional[str] = None) -> C.CDLL:
     """Load libarvx.so (built in-tree by ar_voxel_project_amd.build), or another build
-    of it at `path` (tests of the ARVX_ASSOC_LEFT variant)."""
+    of it at `path` (A/B builds)."""
     path = path or LIB_PATH
     if path in _libs:
         return _libs[path]
@@ -205,10 +206,12 @@ class Context:
 
     def __init__(self, X: int, Y: int, Z: int, voxel_size: float, device: int = 0,
                  z_range: Optional[Sequence[int]] = None,
-                 stripes: Optional[Sequence[int]] = None, lib_path: Optional[str] = None):
+                 stripes: Optional[Sequence[int]] = None, lib_path: Optional[str] = None,
+                 assoc: Optional[int] = None):
         """z_range=(z0,z1): contiguous slab.  stripes=(world, rank): 8-plane groups
         rank, rank+world, ... (load-balanced multi-GPU split).  lib_path: another build of
-        the library (ASSOC_LEFT_LIB_PATH)."""
+        the library (A/B).  assoc: ASSOC_LEFT / ASSOC_RIGHT, the grouping of the M*world row
+        sums of this context (default: the library's, arvx_projection_assoc)."""
         self._lib = load_library(lib_path)
         self._h = C.c_void_p()
         self.X, self.Y, self.Z = int(X), int(Y), int(Z)
@@ -229,6 +232,43 @@ class Context:
         self.shape = (nz, Y, X)  # numpy view of the state plane: [z][y][x]
         self.nvox = nz * Y * X
         self._keep = []
+        if assoc is not None:
+            self.set_assoc(assoc)
+
+    def set_assoc(self, assoc: int) -> None:
+        self._lib.arvx_ctx_set_projection_assoc.argtypes = [C.c_void_p, C.c_int]
+        self._ck(self._lib.arvx_ctx_set_projection_assoc(self._h, int(assoc)))
+
+    @property
+    def assoc(self) -> int:
+        a = C.c_int()
+        self._lib.arvx_ctx_projection_assoc.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        self._ck(self._lib.arvx_ctx_projection_assoc(self._h, C.byref(a)))
+        return a.value
+
+    def selftest_project(self, M, voxel_size, xyz):
+        """(rows (n, 3), uv (n, 2)): the fp32 rows of M * toWord(x, y, z) and the quotients, as
+        the kernels compute them with this context's grouping."""
+        xyz = np.ascontiguousarray(xyz, np.int32).reshape(-1, 3)
+        n = len(xyz)
+        out = np.empty(5 * n, np.float32)
+        M = np.ascontiguousarray(M, np.float32).reshape(12)
+        self._lib.arvx_selftest_project.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_float,
+                                                    C.c_void_p, C.c_void_p]
+        self._ck(self._lib.arvx_selftest_project(self._h, n, M.ctypes.data, C.c_float(voxel_size),
+                                                 xyz.ctypes.data, out.ctypes.data))
+        return out[:3 * n].reshape(n, 3), out[3 * n:].reshape(n, 2)
+
+    def selftest_depth(self, campos, voxel_size, xyz):
+        xyz = np.ascontiguousarray(xyz, np.int32).reshape(-1, 3)
+        out = np.empty(len(xyz), np.float32)
+        c = np.ascontiguousarray(campos, np.float32).reshape(3)
+        self._lib.arvx_selftest_depth.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_float,
+                                                  C.c_void_p, C.c_void_p]
+        self._ck(self._lib.arvx_selftest_depth(self._h, len(xyz), c.ctypes.data,
+                                               C.c_float(voxel_size), xyz.ctypes.data,
+                                               out.ctypes.data))
+        return out
 
     def _ck(self, rc: int) -> None:
         _check(rc, self._lib)

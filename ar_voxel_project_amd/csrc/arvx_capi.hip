@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -33,6 +34,8 @@
 namespace {
 
 thread_local std::string g_last_error;
+// the grouping new contexts start with (arvx_set_projection_assoc)
+std::atomic<int> g_default_assoc{ARVX_ASSOC_LEFT};
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -170,18 +173,52 @@ static int bit_compact_write(Ctx *ctx, const unsigned long long *bits, size_t nw
     return ARVX_OK;
 }
 
+// xyz -> device, kernel, results back: the two projection self-tests share this frame
+template <class Launch>
+static int selftest_xyz(Ctx *ctx, int64_t n, const int32_t *xyz, size_t out_floats, float *out,
+                        Launch launch) {
+    if (n < 1 || !xyz || !out) return fail(ARVX_ERR_INVALID, "bad argument");
+    const size_t in_bytes = (size_t)n * 3 * sizeof(int32_t);
+    if (int rc = ensure_scratch(ctx, in_bytes + out_floats * sizeof(float) + 64)) return rc;
+    int *d_xyz = (int *)ctx->d_scratch;
+    float *d_out = (float *)((uint8_t *)ctx->d_scratch + ((in_bytes + 15) & ~(size_t)15));
+    ARVX_HIP(hipMemcpyAsync(d_xyz, xyz, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    launch(d_xyz, d_out);
+    ARVX_HIP(hipGetLastError());
+    ARVX_HIP(hipMemcpyAsync(out, d_out, out_floats * sizeof(float), hipMemcpyDeviceToHost,
+                            ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    return ARVX_OK;
+}
+
 extern "C" {
 
 int arvx_version(void) { return ARVX_VERSION; }
 
 const char *arvx_last_error(void) { return g_last_error.c_str(); }
 
-int arvx_projection_assoc(void) {
-#ifdef ARVX_ASSOC_LEFT
-    return 1;
-#else
-    return 0;
-#endif
+int arvx_projection_assoc(void) { return g_default_assoc.load(); }
+
+int arvx_set_projection_assoc(int assoc) {
+    if (assoc != ARVX_ASSOC_RIGHT && assoc != ARVX_ASSOC_LEFT)
+        return fail(ARVX_ERR_INVALID, "grouping %d (ARVX_ASSOC_RIGHT or ARVX_ASSOC_LEFT)", assoc);
+    g_default_assoc.store(assoc);
+    return ARVX_OK;
+}
+
+int arvx_ctx_set_projection_assoc(arvx_ctx *ctx, int assoc) {
+    if (!ctx) return fail(ARVX_ERR_INVALID, "null context");
+    if (assoc != ARVX_ASSOC_RIGHT && assoc != ARVX_ASSOC_LEFT)
+        return fail(ARVX_ERR_INVALID, "grouping %d (ARVX_ASSOC_RIGHT or ARVX_ASSOC_LEFT)", assoc);
+    if (ctx->assoc != assoc) ctx->color_ready = false;  // (colours were voted with the other one)
+    ctx->assoc = assoc;
+    return ARVX_OK;
+}
+
+int arvx_ctx_projection_assoc(const arvx_ctx *ctx, int *assoc) {
+    if (!ctx || !assoc) return fail(ARVX_ERR_INVALID, "null argument");
+    *assoc = ctx->assoc;
+    return ARVX_OK;
 }
 
 int arvx_device_count(int *count) {
@@ -228,6 +265,7 @@ int arvx_ctx_create_slab(arvx_ctx **out, int device, int X, int Y, int Z, float 
     c->z0 = z_begin;
     c->z1 = z_end;
     c->s = voxel_size;
+    c->assoc = g_default_assoc.load();
     c->ze0 = z_begin > 0 ? z_begin - 1 : 0;
     c->ze1 = z_end < Z ? z_end + 1 : Z;
     c->nvox = (size_t)X * Y * (size_t)(z_end - z_begin);
@@ -1078,11 +1116,19 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         ARVX_HIP(hipMemsetAsync(ctx->d_timeline, 0, (size_t)pgrid * 4 * 64, ctx->stream));
         p.timeline = (unsigned long long *)ctx->d_timeline;
 #endif
-        if (blocks)
-            hipLaunchKernelGGL(arvx::carve_exact_blocks_kernel, dim3(pgrid), dim3(256), 0,
+        const bool left = ctx->assoc == ARVX_ASSOC_LEFT;
+        if (blocks && left)
+            hipLaunchKernelGGL(arvx::carve_exact_blocks_kernel<true>, dim3(pgrid), dim3(256), 0,
+                               ctx->stream, p);
+        else if (blocks)
+            hipLaunchKernelGGL(arvx::carve_exact_blocks_kernel<false>, dim3(pgrid), dim3(256), 0,
+                               ctx->stream, p);
+        else if (left)
+            hipLaunchKernelGGL(arvx::carve_exact_kernel<true>, dim3(pgrid), dim3(256), 0,
                                ctx->stream, p);
         else
-            hipLaunchKernelGGL(arvx::carve_exact_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, p);
+            hipLaunchKernelGGL(arvx::carve_exact_kernel<false>, dim3(pgrid), dim3(256), 0,
+                               ctx->stream, p);
         ARVX_HIP(hipGetLastError());
         ctx->carve_layout = layout_when_done;
         ++ctx->carve_seq;
@@ -1097,7 +1143,10 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
     ARVX_HIP(hipMemsetAsync(ctx->d_timeline, 0, (size_t)grid * 32, ctx->stream));
     p.timeline = (unsigned long long *)ctx->d_timeline;
 #endif
-    hipLaunchKernelGGL(arvx::carve_fused_kernel, dim3(grid), dim3(256), 0, ctx->stream, p);
+    if (ctx->assoc == ARVX_ASSOC_LEFT)
+        hipLaunchKernelGGL(arvx::carve_fused_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, p);
+    else
+        hipLaunchKernelGGL(arvx::carve_fused_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, p);
     ARVX_HIP(hipGetLastError());
     return ARVX_OK;
 }
@@ -1240,8 +1289,12 @@ int arvx_color(arvx_ctx *ctx, int mode) {
         vp.rgba = ctx->d_surf_rgba;
         vp.depth = ctx->d_surf_depth;
         vp.has = ctx->d_surf_has;
-        hipLaunchKernelGGL(arvx::color_vote_kernel, dim3((unsigned)((total + 255) / 256)),
-                           dim3(256), 0, ctx->stream, vp);
+        if (ctx->assoc == ARVX_ASSOC_LEFT)
+            hipLaunchKernelGGL(arvx::color_vote_kernel<true>, dim3((unsigned)((total + 255) / 256)),
+                               dim3(256), 0, ctx->stream, vp);
+        else
+            hipLaunchKernelGGL(arvx::color_vote_kernel<false>, dim3((unsigned)((total + 255) / 256)),
+                               dim3(256), 0, ctx->stream, vp);
         ARVX_HIP(hipGetLastError());
         ctx->h_surf_index.resize((size_t)total);
         ctx->h_surf_has.resize((size_t)total);
@@ -1395,6 +1448,36 @@ int arvx_selftest_divide(arvx_ctx *ctx, int64_t n, const float *a0, const float 
     (void)hipFree(d);
     if (e != hipSuccess) return arvx::fail_hip(e, "selftest_divide", __FILE__, __LINE__);
     return ARVX_OK;
+}
+
+int arvx_selftest_project(arvx_ctx *ctx, int64_t n, const float M[12], float voxel_size,
+                          const int32_t *xyz, float *rows_uv) {
+    ARVX_CHECK_CTX(ctx);
+    if (!M) return fail(ARVX_ERR_INVALID, "null M");
+    arvx::SelftestMatrix m;
+    memcpy(m.m, M, sizeof m.m);
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    return selftest_xyz(ctx, n, xyz, (size_t)n * 5, rows_uv, [&](int *d_xyz, float *d_out) {
+        if (ctx->assoc == ARVX_ASSOC_LEFT)
+            hipLaunchKernelGGL(arvx::selftest_project_kernel<true>, dim3(grid), dim3(256), 0,
+                               ctx->stream, m, voxel_size, d_xyz, (long long)n, d_out, d_out + 3 * n);
+        else
+            hipLaunchKernelGGL(arvx::selftest_project_kernel<false>, dim3(grid), dim3(256), 0,
+                               ctx->stream, m, voxel_size, d_xyz, (long long)n, d_out, d_out + 3 * n);
+    });
+}
+
+int arvx_selftest_depth(arvx_ctx *ctx, int64_t n, const float campos[3], float voxel_size,
+                        const int32_t *xyz, float *depth) {
+    ARVX_CHECK_CTX(ctx);
+    if (!campos) return fail(ARVX_ERR_INVALID, "null campos");
+    arvx::SelftestMatrix m;
+    memset(&m, 0, sizeof m);
+    memcpy(m.m, campos, 3 * sizeof(float));
+    return selftest_xyz(ctx, n, xyz, (size_t)n, depth, [&](int *d_xyz, float *d_out) {
+        hipLaunchKernelGGL(arvx::selftest_depth_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256),
+                           0, ctx->stream, m, voxel_size, d_xyz, (long long)n, d_out);
+    });
 }
 
 int arvx_selftest_round(arvx_ctx *ctx, int64_t *mismatches) {

@@ -47,6 +47,7 @@ struct Ctx {
     int ze0 = 0, ze1 = 0;     // slab plus one halo plane each side (clipped to the grid)
     int stripe_world = 1, stripe_rank = 0;  // striped slabs (arvx_ctx_create_striped)
     float s = 0.f;
+    int assoc = 1;        // grouping of the M * world row sums (ARVX_ASSOC_*, arvx_device.h)
     size_t nvox = 0;      // owned voxels
     size_t nvox_ext = 0;  // voxels in the state buffer (owned + halo)
 

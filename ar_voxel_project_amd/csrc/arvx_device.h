@@ -4,10 +4,16 @@
 // reference src/VoxelCarving.cpp:18-21,41-54 and src/Model.h:134-140):
 //   w    = (float(y)*s, float(x)*s, float(-z)*s, 1)              fp32
 //   p_k  = double(M[r][k]) * double(w[k])                        exact in fp64
-//   a_r  = float(p0 + ((p1 + p2) + p3))                          cv::gemm generic path, 4-way
-//          unrolled `s0 += s1 + s2 + s3`; built with -DARVX_ASSOC_LEFT:
-//          float(((p0 + p1) + p2) + p3), the other plausible grouping (oracle:
-//          -DARVX_ORACLE_ASSOC_LEFT) -- tests/test_assoc_gpu.py tells the two apart
+//   a_r  = float(((p0 + p1) + p2) + p3)                          cv::gemm generic path: the
+//          A * Bt branch of GEMMSingleMul<float, double> (a matrix-vector product is
+//          turned into it), four accumulators, one product each, summed
+//          `(s0 + s1 + s2 + s3) * alpha` -- ARVX_ASSOC_LEFT, the default; or
+//          float(p0 + ((p1 + p2) + p3)) -- ARVX_ASSOC_RIGHT, what SURVEY 8c 3 recalls
+//          (`s0 += s1 + s2 + s3`).  Both are recollections of OpenCV's source (none in this
+//          image); the grouping is a RUNTIME property of a context (arvx_ctx_set_projection_
+//          assoc), every projecting kernel exists for both, and include/arvx/opencv_dropin.hpp
+//          settles it with one cv::gemm call where OpenCV exists.  tests/test_assoc_gpu.py
+//          tells the two apart on a known-answer voxel.
 //   u,v  = a_0 / a_2, a_1 / a_2                                  IEEE fp32 divide
 //   px   = (int)roundf(u), py = (int)roundf(v); inside iff 0<=px<W, 0<=py<H
 // The library is built with -ffp-contract=off so only explicit fma() fuses.
@@ -188,12 +194,10 @@ __device__ __forceinline__ bool pixel_of(float a0, float a1, float a2, int W, in
 
 // One row of M * world from its four exact fp64 products (p0: the y term, p1: the x term,
 // p2: the z term of Model::toWord's swapped coordinates, p3 = M[r][3]).
+template <bool LEFT>
 __device__ __forceinline__ float row_sum(double p0, double p1, double p2, double p3) {
-#ifdef ARVX_ASSOC_LEFT
-    return (float)(((p0 + p1) + p2) + p3);
-#else
+    if (LEFT) return (float)(((p0 + p1) + p2) + p3);
     return (float)(p0 + ((p1 + p2) + p3));
-#endif
 }
 
 }  // namespace arvx

@@ -416,6 +416,7 @@ __device__ __forceinline__ void subtile_store_done(uint16_t *__restrict__ rec, i
     reinterpret_cast<uint32_t *>(rec)[lane] = lane < 32 ? 0u : 0xffffffffu;
 }
 
+template <bool LEFT>
 __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p) {
 #ifdef ARVX_TIMELINE
     TimelineScope timeline_scope(p.timeline);
@@ -573,9 +574,9 @@ __global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p
                 bool in[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float a0 = row_sum(p0[0], p1[0][j], p20, p3[0]);
-                    const float a1 = row_sum(p0[1], p1[1][j], p21, p3[1]);
-                    const float a2 = row_sum(p0[2], p1[2][j], p22, p3[2]);
+                    const float a0 = row_sum<LEFT>(p0[0], p1[0][j], p20, p3[0]);
+                    const float a1 = row_sum<LEFT>(p0[1], p1[1][j], p21, p3[1]);
+                    const float a2 = row_sum<LEFT>(p0[2], p1[2][j], p22, p3[2]);
                     float u, v;
                     if (fast) {
                         divide2_shared_rcp(a0, a1, a2, u, v);
@@ -756,6 +757,7 @@ __global__ __launch_bounds__(256, 8) void carve_classify_kernel(const CarveParam
 
 // One view applied exactly to the 16 voxels of every lane.  Returns true when all
 // 1024 voxels of the sub-tile are carved and seen.
+template <bool LEFT>
 __device__ __forceinline__ bool exact_view(const CarveParams &p, const int view, const bool fast,
                                            const double dwy, const double (&dwx)[4],
                                            const double (&dwz)[4], uint32_t (&st)[4],
@@ -795,9 +797,9 @@ __device__ __forceinline__ bool exact_view(const CarveParams &p, const int view,
         bool in[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float a0 = row_sum(p0[0], p1[0][j], p20, p3[0]);
-            const float a1 = row_sum(p0[1], p1[1][j], p21, p3[1]);
-            const float a2 = row_sum(p0[2], p1[2][j], p22, p3[2]);
+            const float a0 = row_sum<LEFT>(p0[0], p1[0][j], p20, p3[0]);
+            const float a1 = row_sum<LEFT>(p0[1], p1[1][j], p21, p3[1]);
+            const float a2 = row_sum<LEFT>(p0[2], p1[2][j], p22, p3[2]);
             float u, v;
             if (fast) {
                 divide2_shared_rcp(a0, a1, a2, u, v);
@@ -948,6 +950,7 @@ __device__ __forceinline__ void for_each_work_item(const CarveParams &p, const i
     }
 }
 
+template <bool LEFT>
 __global__ __launch_bounds__(256, 4) void carve_exact_kernel(const CarveParams p) {
 #ifdef ARVX_TIMELINE
     WaveTimeline wave_timeline(p.timeline);
@@ -980,7 +983,7 @@ __global__ __launch_bounds__(256, 4) void carve_exact_kernel(const CarveParams p
                 while (mixed && !done) {
                     const int b = __ffsll((long long)mixed) - 1;
                     mixed &= mixed - 1;
-                    done = exact_view(p, p.v0 + 64 * c + b, (fastdiv >> b) & 1ull, dwy, dwx, dwz,
+                    done = exact_view<LEFT>(p, p.v0 + 64 * c + b, (fastdiv >> b) & 1ull, dwy, dwx, dwz,
                                       st, lane);
 #ifdef ARVX_TIMELINE
                     wave_timeline.view_done();
@@ -1033,6 +1036,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // but the per-view set-up is paid twice: 27 % more view evaluations, 4 % slower.)
 // need: bit 4 m + j set = block j of group m = 2 byi + bzi may be cut by this view's silhouette
 // (block_tests below); the other blocks are not projected.
+template <bool LEFT>
 __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const int view,
                                                   const bool fast, const float (&wy)[2],
                                                   const float (&wx)[4], const float (&wz)[2],
@@ -1082,7 +1086,7 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
         }
         pix[m][j] = pixel_tagged(u, v, p.W, wlim, hlim, zero_pix);
     };
-#ifndef ARVX_ASSOC_LEFT
+    if constexpr (!LEFT) {
     // a_r = p0[y] + ((p1[x] + p2[z]) + p3) (row_sum): the inner sum q depends on x and z
     // only, so it is formed once per (x, z) of the lane -- 4 x 2 values per row -- and a voxel
     // costs ONE fp64 add per row.  p1 is an exact product, so fma(m1, wx, p2) IS
@@ -1121,7 +1125,7 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
             }
         }
     }
-#else
+    } else {
     // a_r = ((p0[y] + p1[x]) + p2[z]) + p3: the inner sum depends on y and x
 #pragma unroll
     for (int byi = 0; byi < 2; ++byi) {
@@ -1155,7 +1159,7 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
             }
         }
     }
-#endif
+    }
     if (!did) return false;
     uint32_t word[4][4];
 #pragma unroll
@@ -1239,6 +1243,7 @@ __device__ __forceinline__ unsigned block_tests(const CarveParams &p, const SubT
     return needLanes;
 }
 
+template <bool LEFT>
 __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveParams p) {
 #ifdef ARVX_TIMELINE
     WaveTimeline wave_timeline(p.timeline);
@@ -1354,7 +1359,7 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
                                               : (unsigned)__builtin_amdgcn_readlane(needLanes, slot);
                     ++slot;
                     if (!need) continue;  // every block settled by its rectangle
-                    done = exact_view_blocks(p, __builtin_amdgcn_readfirstlane(p.v0 + 64 * c + b),
+                    done = exact_view_blocks<LEFT>(p, __builtin_amdgcn_readfirstlane(p.v0 + 64 * c + b),
                                              (fastdiv >> b) & 1ull, wy, wx, wz, st, need);
 #ifdef ARVX_TIMELINE
                     wave_timeline.view_done();

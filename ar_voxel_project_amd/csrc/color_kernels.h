@@ -61,6 +61,64 @@ struct VoteParams {
     uint8_t *has;  // n   (1 if >= 1 sample)
 };
 
+// (float)cv::norm(cameras[i] - word_coord), src/ColorReconstruction.h:59: fp32 differences of
+// the two Vec4f (the fourth is 1 - 1), then the square root of an fp64 sum of squares in the
+// order ((d0^2 + d1^2) + d2^2) + d3^2 (normL2Sqr<float, double>, one 4-way step)
+__device__ __forceinline__ float sample_depth(const float *__restrict__ c, float w0, float w1,
+                                              float w2) {
+    const double e0 = (double)(c[0] - w0), e1 = (double)(c[1] - w1), e2 = (double)(c[2] - w2);
+    const double e3 = (double)(1.f - 1.f);
+    const double acc = ((e0 * e0 + e1 * e1) + e2 * e2) + e3 * e3;
+    return (float)sqrt(acc);
+}
+
+// one row triple of M * world for voxel (x, y, z) (global z), reference src/Model.h:134-140 and
+// src/VoxelCarving.cpp:18-21
+template <bool LEFT>
+__device__ __forceinline__ void project_rows(const float *__restrict__ Mv, float s, int x, int y,
+                                             int z, float a[3]) {
+    const float w0 = (float)y * s, w1 = (float)x * s, w2 = (float)(-z) * s;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double p0 = (double)Mv[4 * r] * (double)w0;
+        const double p1 = (double)Mv[4 * r + 1] * (double)w1;
+        const double p2 = (double)Mv[4 * r + 2] * (double)w2;
+        const double p3 = (double)Mv[4 * r + 3];
+        a[r] = row_sum<LEFT>(p0, p1, p2, p3);
+    }
+}
+
+// self-test hooks (arvx_selftest_project / _depth): the raw values the kernels compute, for a
+// host that has OpenCV to compare with cv::gemm / cv::norm (include/arvx/opencv_dropin.hpp)
+struct SelftestMatrix {
+    float m[12];
+};
+template <bool LEFT>
+__global__ __launch_bounds__(256) void selftest_project_kernel(const SelftestMatrix M, float s,
+                                                               const int *__restrict__ xyz,
+                                                               long long n, float *__restrict__ rows,
+                                                               float *__restrict__ uv) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a[3];
+    project_rows<LEFT>(M.m, s, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], a);
+    rows[3 * i] = a[0];
+    rows[3 * i + 1] = a[1];
+    rows[3 * i + 2] = a[2];
+    uv[2 * i] = a[0] / a[2];
+    uv[2 * i + 1] = a[1] / a[2];
+}
+__global__ __launch_bounds__(256) void selftest_depth_kernel(const SelftestMatrix cam, float s,
+                                                             const int *__restrict__ xyz,
+                                                             long long n, float *__restrict__ depth) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float w0 = (float)xyz[3 * i + 1] * s, w1 = (float)xyz[3 * i] * s,
+                w2 = (float)(-xyz[3 * i + 2]) * s;
+    depth[i] = sample_depth(cam.m, w0, w1, w2);
+}
+
+template <bool LEFT>
 __global__ __launch_bounds__(256) void color_vote_kernel(const VoteParams p) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= p.n) return;
@@ -82,18 +140,13 @@ __global__ __launch_bounds__(256) void color_vote_kernel(const VoteParams p) {
             const double p1 = (double)Mv[4 * r + 1] * d1w;
             const double p2 = (double)Mv[4 * r + 2] * d2w;
             const double p3 = (double)Mv[4 * r + 3];
-            a[r] = row_sum(p0, p1, p2, p3);
+            a[r] = row_sum<LEFT>(p0, p1, p2, p3);
         }
         int pix;
         if (!pixel_of(a[0], a[1], a[2], p.W, p.H, pix)) continue;  // ColorReconstruction.h:54-57
         const uint8_t *q = p.images + ((size_t)v * p.W * p.H + pix) * 3;
         const unsigned b = q[0], g = q[1], r = q[2];  // Vec3b is BGR; colour = (R,G,B,1), :59
-        // cv::norm(cameras[i] - word_coord): fp32 differences, fp64 sum of squares, :59
-        const float *c = p.campos + 3 * v;
-        const double e0 = (double)(c[0] - w0), e1 = (double)(c[1] - w1), e2 = (double)(c[2] - w2);
-        const double e3 = (double)(1.f - 1.f);
-        const double acc = ((e0 * e0 + e1 * e1) + e2 * e2) + e3 * e3;
-        const float depth = (float)sqrt(acc);
+        const float depth = sample_depth(p.campos + 3 * v, w0, w1, w2);
         if (n == 0 || depth < best) {  // strict <: the first view wins ties, .cpp:33-40
             best = depth;
             br = (float)r;

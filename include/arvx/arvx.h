@@ -76,12 +76,20 @@ typedef struct arvx_stats {
 int arvx_version(void);
 const char *arvx_last_error(void);
 int arvx_device_count(int *count);
-/* How this build sums the four products of a row of M * world (the cv::gemm call behind
- * `intr * pose * world`, reference src/VoxelCarving.cpp:19): 0 = p0 + ((p1 + p2) + p3)
- * -- the default, OpenCV's 4-way unrolled `s0 += s1 + s2 + s3` --, 1 = ((p0 + p1) + p2) + p3
- * (built with -DARVX_ASSOC_LEFT as libarvx_assoc_left.so, for a host whose OpenCV sums that
- * way; the two differ by double rounding in about one voxel-view in 1e8). */
+/* How the four products of a row of M * world are summed -- the cv::gemm call behind
+ * `intr * pose * world`, reference src/VoxelCarving.cpp:19, which takes cv::gemm's generic path
+ * (GEMMSingleMul<float, double>: fp32 inputs, fp64 products and sums):
+ *   ARVX_ASSOC_LEFT   ((p0 + p1) + p2) + p3   four accumulators, `(s0 + s1 + s2 + s3) * alpha`
+ *   ARVX_ASSOC_RIGHT  p0 + ((p1 + p2) + p3)   `s0 += s1 + s2 + s3`
+ * The two differ by double rounding in about one voxel-view in 1e8.  Which one an OpenCV build
+ * uses cannot be checked in an image without OpenCV: the default (LEFT) follows the OpenCV 4.x
+ * source as recalled, it is a property of a context that can be changed at run time, and
+ * include/arvx/opencv_dropin.hpp settles it with one cv::gemm call at first use (see also
+ * tools/pin_with_opencv.py).  arvx_projection_assoc: what new contexts start with. */
+#define ARVX_ASSOC_RIGHT 0
+#define ARVX_ASSOC_LEFT 1
 int arvx_projection_assoc(void);
+int arvx_set_projection_assoc(int assoc);
 
 /* ---- context --------------------------------------------------------- */
 
@@ -110,6 +118,10 @@ int arvx_ctx_set_stream(arvx_ctx *ctx, void *hip_stream);
  * carve, and the next carve for the pack).  NULL: back on the context's stream. */
 int arvx_ctx_set_exchange_stream(arvx_ctx *ctx, void *hip_stream);
 int arvx_ctx_synchronize(arvx_ctx *ctx);
+/* The row-sum grouping of THIS context (see arvx_projection_assoc); takes effect with the next
+ * carve / colour pass. */
+int arvx_ctx_set_projection_assoc(arvx_ctx *ctx, int assoc);
+int arvx_ctx_projection_assoc(const arvx_ctx *ctx, int *assoc);
 /* Voxels held by this context (slab). */
 int arvx_ctx_voxels(const arvx_ctx *ctx, int64_t *count);
 
@@ -319,6 +331,18 @@ int arvx_get_stats(arvx_ctx *ctx, arvx_stats *out);
  * (a0/b fast, a1/b fast, a0/b IEEE, a1/b IEEE). */
 int arvx_selftest_divide(arvx_ctx *ctx, int64_t n, const float *a0, const float *a1,
                          const float *b, float *out);
+
+/* Self-test hooks for a host that has OpenCV (include/arvx/opencv_dropin.hpp runs them at first
+ * use): the raw values the kernels compute for n voxels xyz (3 ints each, global coordinates).
+ *   arvx_selftest_project: rows_uv = 3 n floats a0 a1 a2 -- the fp32 rows of M * toWord(x, y, z)
+ *     with the context's grouping, what `intr * pose * world` holds (src/VoxelCarving.cpp:19) --
+ *     followed by 2 n floats u = a0 / a2, v = a1 / a2 (:20).
+ *   arvx_selftest_depth: (float)cv::norm(cameras[i] - toWord(x, y, z)) for campos = the first
+ *     three components of cameras[i] (src/ColorReconstruction.h:59). */
+int arvx_selftest_project(arvx_ctx *ctx, int64_t n, const float M[12], float voxel_size,
+                          const int32_t *xyz, float *rows_uv);
+int arvx_selftest_depth(arvx_ctx *ctx, int64_t n, const float campos[3], float voxel_size,
+                        const int32_t *xyz, float *depth);
 
 /* Self-test hook: the kernels' one-instruction pixel rounding (v_cvt_rpi_i32_f32) against
  * std::round on every float in (-0.5, 2^24], i.e. every quotient that can fall inside an

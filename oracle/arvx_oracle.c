@@ -22,19 +22,24 @@
  *       last ulp, so the product's C-ABI takes M itself.
  *  (G2) `M * world` (3x4 * 4x1, CV_32F): len==4 matches neither d_size
  *       dimension, so the generic GEMMSingleMul<float,double> runs; with
- *       d_size.width==1 and B continuous it takes the A*Bt branch, 4-way
- *       unrolled: s0..s3 (double) each hold one exact product M[r][k]*w[k],
- *       the loop ends with `s0 += s1 + s2 + s3;` and the row result is
- *       float(s0*alpha), alpha = 1.0 -- i.e. p0 + ((p1 + p2) + p3) in double.
- *       This is the form SURVEY.md 8(c)(3) specifies and the default here and
- *       in the kernels.  No OpenCV source exists in this image to re-read the
- *       line, so the other plausible grouping, ((p0+p1)+p2)+p3, is kept behind
- *       ONE macro on both sides (here: -DARVX_ORACLE_ASSOC_LEFT, built as
- *       libarvx_oracle_assoc_left.so; kernels: -DARVX_ASSOC_LEFT, built as
- *       libarvx_assoc_left.so); tests/test_assoc_*.py hold a voxel on which the
- *       two groupings give different pixels and check kernel == oracle under
- *       each.  The two differ only through double rounding (about one
- *       voxel-view in 1e8 on ordinary scenes).
+ *       d_size.width==1 and B continuous gemm turns the product into the A*Bt
+ *       branch, 4-way unrolled: s0..s3 (double) each hold one exact product
+ *       M[r][k]*w[k], and the row result is float(s*alpha), alpha = 1.0, where
+ *       s is the sum of the four accumulators.  HOW they are summed is a
+ *       recollection of OpenCV's source (none in this image):
+ *         LEFT  (default)  `s0 = (s0+s1+s2+s3)*alpha`  = ((p0+p1)+p2)+p3
+ *         RIGHT            `s0 += s1 + s2 + s3`        = p0+((p1+p2)+p3)
+ *       SURVEY.md 8(c)(3) recalls the second form; the reviewer of round 2 and
+ *       a second reading of the 4.x source (matmul.simd.hpp, "A * Bt" branch)
+ *       recall the first, which is also what the loop gives when
+ *       CV_ENABLE_UNROLLED is off -- so LEFT is the default, here and in the
+ *       kernels, and the other one is a run-time switch on both sides
+ *       (arvx_oracle_set_assoc; kernels: arvx_ctx_set_projection_assoc).
+ *       tests/test_assoc_*.py hold a voxel on which the two groupings give
+ *       different pixels and check kernel == oracle under each; on a host with
+ *       OpenCV include/arvx/opencv_dropin.hpp / tools/pin_with_opencv.py settle
+ *       it with one cv::gemm call.  The two differ only through double
+ *       rounding (about one voxel-view in 1e8 on ordinary scenes).
  *  (N1) cv::norm(Vec4f) = sqrt(normL2Sqr<float,double>): one 4-way unrolled
  *       step, s += v0*v0 + v1*v1 + v2*v2 + v3*v3 in double, s starting at 0.
  *
@@ -78,6 +83,10 @@ static inline void to_word(float s, int x, int y, int z, float w[4]) {
     w[3] = 1.f;
 }
 
+/* grouping of (G2): 1 = ((p0+p1)+p2)+p3 (default), 0 = p0+((p1+p2)+p3).  Set between calls
+ * only (the worker threads of a call read it). */
+static int g_assoc_left = 1;
+
 /* (G2)  src/VoxelCarving.cpp:18-21 worldToCamera, the `* world` factor */
 static inline void mat_vec(const float M[12], const float w[4], float proj[3]) {
     for (int r = 0; r < 3; ++r) {
@@ -85,25 +94,16 @@ static inline void mat_vec(const float M[12], const float w[4], float proj[3]) {
         double p1 = (double)M[r * 4 + 1] * (double)w[1];
         double p2 = (double)M[r * 4 + 2] * (double)w[2];
         double p3 = (double)M[r * 4 + 3] * (double)w[3];
-#ifdef ARVX_ORACLE_ASSOC_LEFT
-        double s0 = ((p0 + p1) + p2) + p3;
-#else
-        double s0 = p0 + ((p1 + p2) + p3); /* s0 += s1 + s2 + s3; */
-#endif
+        double s0 = g_assoc_left ? ((p0 + p1) + p2) + p3   /* s0 = (s0+s1+s2+s3)*alpha */
+                                 : p0 + ((p1 + p2) + p3); /* s0 += s1 + s2 + s3 */
         s0 = s0 * 1.0; /* alpha */
         proj[r] = (float)s0;
     }
 }
 
-/* which grouping of (G2) this library was built with: 0 = p0+((p1+p2)+p3)
- * (default), 1 = ((p0+p1)+p2)+p3 (-DARVX_ORACLE_ASSOC_LEFT) */
-int arvx_oracle_assoc(void) {
-#ifdef ARVX_ORACLE_ASSOC_LEFT
-    return 1;
-#else
-    return 0;
-#endif
-}
+/* which grouping of (G2) is in force: 1 = ((p0+p1)+p2)+p3 (default), 0 = p0+((p1+p2)+p3) */
+int arvx_oracle_assoc(void) { return g_assoc_left; }
+void arvx_oracle_set_assoc(int left) { g_assoc_left = left ? 1 : 0; }
 
 void arvx_oracle_project_raw(const float M[12], float s, int x, int y, int z,
                              float out[5]) {

@@ -45,6 +45,7 @@ int arvx_oracle_project(const float M[12], float s, int x, int y, int z,
 
 /* 0: M*world summed as p0+((p1+p2)+p3) (default); 1: ((p0+p1)+p2)+p3. */
 int arvx_oracle_assoc(void);
+void arvx_oracle_set_assoc(int left);
 
 /* Raw projection, no rounding: out[0..2] = proj (f32), out[3]=u, out[4]=v. */
 void arvx_oracle_project_raw(const float M[12], float s, int x, int y, int z,

@@ -12,38 +12,35 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libarvx_oracle.so")
 OCC, SEEN = 1, 2
-_libs: dict = {}
-_variant = ""  # "" = default build; "assoc_left" = the other grouping of the M*world sums
-
-
-def _path(variant: str) -> str:
-    return os.path.join(_HERE, f"libarvx_oracle{'_' + variant if variant else ''}.so")
+_lib = None
+ASSOC_RIGHT, ASSOC_LEFT = 0, 1  # grouping of the M*world row sums (arvx_oracle.c, G2)
 
 
 def lib() -> C.CDLL:
-    L = _libs.get(_variant)
-    if L is None:
-        path = _path(_variant)
-        if not os.path.exists(path):
-            raise FileNotFoundError(f"{path} missing: run `make -C oracle`")
-        L = C.CDLL(path)
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} missing: run `make -C oracle`")
+        L = C.CDLL(LIB_PATH)
         L.arvx_oracle_project.restype = C.c_int
         L.arvx_oracle_depth.restype = C.c_float
         L.arvx_oracle_assoc.restype = C.c_int
-        _libs[_variant] = L
-    return L
+        _lib = L
+    return _lib
 
 
 @contextlib.contextmanager
 def variant(name: str):
-    """Run the enclosed calls on another build of the oracle (oracle/Makefile):
-    "assoc_left" sums the M*world rows as ((p0+p1)+p2)+p3."""
-    global _variant
-    old, _variant = _variant, name
+    """Run the enclosed calls with another grouping of the M*world row sums:
+    "assoc_right" = p0+((p1+p2)+p3), "assoc_left" = ((p0+p1)+p2)+p3 (the default), "" = as is."""
+    L = lib()
+    old = int(L.arvx_oracle_assoc())
+    if name:
+        L.arvx_oracle_set_assoc({"assoc_left": 1, "assoc_right": 0}[name])
     try:
-        yield lib()
+        yield L
     finally:
-        _variant = old
+        L.arvx_oracle_set_assoc(old)
 
 
 def assoc() -> int:

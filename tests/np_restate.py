@@ -15,9 +15,9 @@ def to_word(s, x, y, z):
     return wx, wy, wz
 
 
-def project_raw(M, s, x, y, z, assoc_left=False):
+def project_raw(M, s, x, y, z, assoc_left=True):
     """proj = M * world via the cv::gemm generic path: exact f64 products, summed
-    p0+((p1+p2)+p3) (`s0 += s1 + s2 + s3`; assoc_left: ((p0+p1)+p2)+p3),
+    ((p0+p1)+p2)+p3 (`(s0+s1+s2+s3)*alpha`: the default; assoc_left=False: p0+((p1+p2)+p3)),
     rounded to f32; then the two f32 divides."""
     M = np.asarray(M, F32).reshape(3, 4).astype(F64)
     w0, w1, w2 = (a.astype(F64) for a in to_word(s, x, y, z))

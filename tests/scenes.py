@@ -50,13 +50,13 @@ def assoc_kat(N=2):
     """One view on which the two groupings of the M*world row sum put voxel
     (1,1,1) on different pixels.  With s = 1 the voxel's world vector is (1, 1, -1, 1), so the
     four products of row 0 are M00, M01, -M02, M03 = 1, 2^-24, 2^-54, 2^-53:
-      p0 + ((p1 + p2) + p3) = 1 + 2^-24 + 3*2^-54 -> fp64 1 + 2^-24 + 2^-52 -> fp32 1 + 2^-23
-      ((p0 + p1) + p2) + p3 : both small terms vanish in fp64 (quarter ulp, then a tie to even)
-                              -> 1 + 2^-24 -> fp32 tie to even -> 1.0
+      RIGHT p0 + ((p1 + p2) + p3) = 1 + 2^-24 + 3*2^-54 -> fp64 1 + 2^-24 + 2^-52 -> fp32 1 + 2^-23
+      LEFT  ((p0 + p1) + p2) + p3 : both small terms vanish in fp64 (quarter ulp, then a tie to
+                              even) -> 1 + 2^-24 -> fp32 tie to even -> 1.0
     and with a_2 = fl32(1/3.5) the quotients are 3.5000002 -> pixel 4 and 3.4999998 -> pixel 3.
     Rows 1 and 2 are constant (v = 1).  The mask is a checkerboard: pixel (3,1) is background,
     (4,1) foreground.  Returns (X, Y, Z, s, M[1,3,4], masks[1,H,W], target xyz, state of the
-    target under the default grouping, under the left one)."""
+    target under the RIGHT grouping (seen, kept: 3), under the LEFT one (carved: 2))."""
     a2 = np.float32(1.0 / 3.5)
     M = np.zeros((1, 3, 4), np.float32)
     M[0, 0] = [1.0, 2.0 ** -24, -(2.0 ** -54), 2.0 ** -53]

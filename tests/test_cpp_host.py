@@ -47,6 +47,19 @@ def test_opencv_dropin_header_type_checks():
     assert r.returncode == 0, r.stderr
 
 
+@pytest.mark.gpu
+def test_opencv_dropin_self_pinning_runs():
+    """dropin::run_self_pin (include/arvx/opencv_dropin.hpp) against the stand-ins of
+    tests/cpp/mock_opencv: a cv::gemm for either row-sum grouping switches the library to that
+    grouping; an unknown gemm, a different cv::norm or cv::undistort are reported
+    (tests/cpp/test_selfpin.cpp).  Checks the self-pinning's logic, not OpenCV's arithmetic."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_selfpin")
+    if not os.path.exists(exe):
+        pytest.fail("tests/cpp/test_selfpin missing: run __graft_entry__.build()")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "selfpin ok" in r.stdout, r.stdout + r.stderr
+
+
 def write_scene(path, X, Y, Z, s, K, Rt, masks, images, st0):
     m4 = masks if masks.ndim == 4 else masks[..., None]
     V, H, W, C = m4.shape

@@ -275,26 +275,28 @@ def test_mc_cells_oracle_threshold_and_colours(oracle):
 
 
 def test_assoc_kat_tells_the_groupings_apart(oracle):
-    """proj[r] = float(p0 + ((p1 + p2) + p3)).  The KAT voxel lands on
-    pixel 4 (foreground: seen, kept) under that grouping and on pixel 3 (background: carved)
-    under ((p0+p1)+p2)+p3; C oracle (both builds) and the numpy twin agree on which is which."""
+    """proj[r] = float(((p0 + p1) + p2) + p3) by default (LEFT), float(p0 + ((p1 + p2) + p3))
+    under "assoc_right" (what SURVEY 8(c)(3) recalls).  The KAT voxel lands on pixel 3
+    (background: carved) under LEFT and on pixel 4 (foreground: seen, kept) under RIGHT; C
+    oracle (both settings) and the numpy twin agree on which is which."""
     from tests import np_restate as npr, scenes
-    X, Y, Z, s, M, masks, (tx, ty, tz), st_default, st_left = scenes.assoc_kat()
-    assert oracle.assoc() == 0
+    X, Y, Z, s, M, masks, (tx, ty, tz), st_right, st_left = scenes.assoc_kat()
+    assert oracle.assoc() == 1
     raw = oracle.project_raw(M[0], s, tx, ty, tz)
-    assert raw[0] == np.float32(1.0) + np.float32(2.0 ** -23) and raw[3] > 3.5
-    assert oracle.project(M[0], s, tx, ty, tz, 8, 4) == (4, 1)
-    want = oracle.carve(X, Y, Z, s, M, masks, threads=1)
-    assert want[tz, ty, tx] == st_default
-    assert np.array_equal(want, npr.carve(X, Y, Z, s, M, masks))
-    with oracle.variant("assoc_left"):
-        assert oracle.assoc() == 1
-        raw = oracle.project_raw(M[0], s, tx, ty, tz)
-        assert raw[0] == np.float32(1.0) and raw[3] < 3.5
-        assert oracle.project(M[0], s, tx, ty, tz, 8, 4) == (3, 1)
-        left = oracle.carve(X, Y, Z, s, M, masks, threads=1)
+    assert raw[0] == np.float32(1.0) and raw[3] < 3.5
+    assert oracle.project(M[0], s, tx, ty, tz, 8, 4) == (3, 1)
+    left = oracle.carve(X, Y, Z, s, M, masks, threads=1)
     assert left[tz, ty, tx] == st_left
-    diff = np.argwhere(left != want)
+    assert np.array_equal(left, npr.carve(X, Y, Z, s, M, masks))
+    with oracle.variant("assoc_right"):
+        assert oracle.assoc() == 0
+        raw = oracle.project_raw(M[0], s, tx, ty, tz)
+        assert raw[0] == np.float32(1.0) + np.float32(2.0 ** -23) and raw[3] > 3.5
+        assert oracle.project(M[0], s, tx, ty, tz, 8, 4) == (4, 1)
+        right = oracle.carve(X, Y, Z, s, M, masks, threads=1)
+    assert oracle.assoc() == 1
+    assert right[tz, ty, tx] == st_right
+    diff = np.argwhere(left != right)
     assert diff.tolist() == [[tz, ty, tx]]  # the only voxel the grouping decides
-    a, _, _ = npr.project_raw(M[0], s, np.array(tx), np.array(ty), np.array(tz), assoc_left=True)
-    assert a[0] == np.float32(1.0)
+    a, _, _ = npr.project_raw(M[0], s, np.array(tx), np.array(ty), np.array(tz), assoc_left=False)
+    assert a[0] == np.float32(1.0) + np.float32(2.0 ** -23)
