@@ -81,12 +81,24 @@ struct ExchangeStreamScope {
 // --hip-trace of tools/cpp/arvx_bench6: more than the whole carve of its largest model), and a
 // drop-in caller makes a context per Model (src/main.cpp:306-440 builds eight in a row): the
 // streams of destroyed contexts are kept per device and handed to the next context.
+// A/B switches of the launch path.  The shipped library reads NO environment variable: its
+// behaviour never depends on the caller's environment.  An experiment build
+// (make EXTRA=-DARVX_EXPERIMENTS, e.g. into ab_libs/ for tools/carve_ab.py) turns the same
+// names into environment switches again.
+#ifdef ARVX_EXPERIMENTS
+static bool experiment_flag(const char *name) { return getenv(name) != nullptr; }
+static int experiment_int(const char *name) { return getenv(name) ? atoi(getenv(name)) : 0; }
+#else
+static constexpr bool experiment_flag(const char *) { return false; }
+static constexpr int experiment_int(const char *) { return 0; }
+#endif
+
 namespace {
 std::mutex g_stream_mutex;
 std::vector<std::pair<int, hipStream_t>> g_idle_streams;  // (device, stream), idle and drained
 
 hipError_t acquire_stream(int device, hipStream_t *out) {
-    static const bool no_reuse = getenv("ARVX_NO_STREAM_REUSE") != nullptr;  // A/B
+    static const bool no_reuse = experiment_flag("ARVX_NO_STREAM_REUSE");
     if (!no_reuse) {
         std::lock_guard<std::mutex> lock(g_stream_mutex);
         for (size_t i = 0; i < g_idle_streams.size(); ++i)
@@ -100,7 +112,7 @@ hipError_t acquire_stream(int device, hipStream_t *out) {
 }
 
 void release_stream(int device, hipStream_t s) {  // s: synchronised by the caller
-    static const bool no_reuse = getenv("ARVX_NO_STREAM_REUSE") != nullptr;
+    static const bool no_reuse = experiment_flag("ARVX_NO_STREAM_REUSE");
     std::lock_guard<std::mutex> lock(g_stream_mutex);
     if (!no_reuse && g_idle_streams.size() < 64) {
         g_idle_streams.emplace_back(device, s);
@@ -1014,7 +1026,7 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
     const unsigned grid = (unsigned)(rows8 * p.tilesX);
     const bool cull = !(flags & ARVX_CARVE_NO_CULL);
     const bool split = cull && !(flags & ARVX_CARVE_FUSED) && p.nchunks <= arvx::kMaxChunks;
-    static const bool two_launches = getenv("ARVX_COARSE_SPLIT") != nullptr;  // A/B
+    static const bool two_launches = experiment_flag("ARVX_COARSE_SPLIT");
     const size_t ncoarse = (size_t)p.coarseX * p.coarseY * p.coarseZ;
     if (ctx->ncu <= 0) {
         ctx->ncu = 256;
@@ -1083,13 +1095,20 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         }
     }
     // the statistics counters live in the row-mapped variant
-    static const bool row_map = getenv("ARVX_EXACT_ROWS") != nullptr;
+    static const bool row_map = experiment_flag("ARVX_EXACT_ROWS");
     const bool blocks = split && !row_map && !(flags & ARVX_CARVE_STATS);
     // few sub-tiles per wave (small grids, slabs): the exact kernel may hand an item's views
     // to several waves (decided in the kernel from the length of the work lists)
-    static const bool no_item_split = getenv("ARVX_NO_ITEM_SPLIT") != nullptr;
-    if (blocks && !no_item_split && (size_t)p.X * p.Y * p.Z <= ((size_t)1 << 26)) p.flags |= 8u;
-    static const bool no_block_tests = getenv("ARVX_NO_BLOCK_TESTS") != nullptr;  // A/B
+    static const bool no_item_split = experiment_flag("ARVX_NO_ITEM_SPLIT");
+    // (up to 2^26 voxels: above that there are more items than half the waves and the kernel
+    // never splits; ARVX_ITEM_SPLIT_LOG2 in an experiment build moves the limit)
+    static const int split_log2 = experiment_int("ARVX_ITEM_SPLIT_LOG2");
+    if (blocks && !no_item_split &&
+        (size_t)p.X * p.Y * p.Z <= ((size_t)1 << (split_log2 > 0 ? split_log2 : 26)))
+        p.flags |= 8u;
+    static const bool force_split = experiment_flag("ARVX_FORCE_SPLIT2");  // every item in 2 parts
+    if (blocks && force_split) p.flags |= 8u | 64u;
+    static const bool no_block_tests = experiment_flag("ARVX_NO_BLOCK_TESTS");
     if (no_block_tests) p.flags |= 32u;
     if (split) {
         // coarse tiles: classified, and the decided ones written as constant records, one
@@ -1102,7 +1121,7 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
                                0, ctx->stream, p);
         ARVX_HIP(hipGetLastError());
         // the others: a fixed grid walks the list (8 waves per SIMD)
-        static const int cgrid_env = getenv("ARVX_CLASSIFY_WGS") ? atoi(getenv("ARVX_CLASSIFY_WGS")) : 0;
+        static const int cgrid_env = experiment_int("ARVX_CLASSIFY_WGS");
         const unsigned cgrid = cgrid_env > 0 ? (unsigned)cgrid_env : (unsigned)ncu * 8u;
         hipLaunchKernelGGL(arvx::carve_classify_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, p);
         ARVX_HIP(hipGetLastError());

@@ -64,7 +64,9 @@ struct CarveParams {
     int satW;               // entries per row of a view's table (>= W + 1, padded to whole lines)
     int v0, v1;             // view range [v0, v1)
     unsigned flags;         // bit0 no cull, bit1 stats, bit2 state is fresh (skip the load),
-                            // bit3 the exact kernel may split items between waves
+                            // bit3 the exact kernel may split items between waves, bit4 fill
+                            // as a fresh model, bit5 no block tests, bit6 always two parts
+                            // (5, 6: experiment builds)
     int tilesX, tilesY, tilesZ;
     // coarse pre-pass results
     int coarseX, coarseY, coarseZ, nchunks;
@@ -146,14 +148,36 @@ __device__ __forceinline__ uint32_t pixel_tagged(float u, float v, int W, float 
     return in ? ((uint32_t)at | 0x80000000u) : (uint32_t)outside_pix;
 }
 
-// a0/a2 and a1/a2, correctly rounded, with ONE reciprocal: the unscaled core of
-// the gfx9 fp32 division expansion (rcp, one Newton step, quotient, two residual
-// corrections).  Bit-identical to the IEEE quotient whenever the hardware's
-// v_div_scale would not rescale; callers use it only where |a2| is known to lie in
-// [2^-60, 2^60] and |a0|,|a1| <= 2^60 (sub-tile bounds from the rectangle test).
-// Then the remaining rescale cases are numerators below 2^-103 (|quotient| < 2^-43,
-// pixel 0 either way) and ratios above 2^95 (outside the image either way).
-// Checked against `/` on random and adversarial operands in tests/test_carve_gpu.py.
+// a0/a2 and a1/a2, correctly rounded, with ONE reciprocal.
+//
+// Why this equals the IEEE quotient.  The compiler expands an fp32 `/` on gfx9 into
+//     bs = v_div_scale(b, b, a)        as = v_div_scale(a, b, a)
+//     r0 = v_rcp(bs)
+//     e  = fma(-bs, r0, 1)             r  = fma(e, r0, r0)
+//     q0 = as * r
+//     t0 = fma(-bs, q0, as)            q1 = fma(t0, r, q0)
+//     t1 = fma(-bs, q1, as)
+//     q  = v_div_fmas(t1, r, q1)       = fma(t1, r, q1), times 2^+-32 when something was scaled
+//     result = v_div_fixup(q, b, a)    replaces q only for zero / infinite / NaN operands and
+//                                      for quotients that overflow or are subnormal
+// and that sequence IS the correctly rounded quotient (it is how the hardware divides).  The
+// function below is the same instruction sequence with bs = b, as = a: whenever v_div_scale
+// returns its operands unchanged and v_div_fixup passes q through, both compute the same bits,
+// and two quotients with one denominator can share r.  v_div_scale rescales exactly when
+//   (i)   b is subnormal or |b| >= 2^126 (its reciprocal would be subnormal),
+//   (ii)  the biased exponent of a is <= 23, i.e. 0 < |a| < 2^-103 (the residuals t would lose
+//         bits to the subnormal range),
+//   (iii) exponent(a) - exponent(b) >= 96 (the quotient may overflow), or
+//   (iv)  the quotient is subnormal, exponent(a) - exponent(b) <= -126.
+// Callers use the function only where the rectangle test has shown 2^-60 <= |a2| <= 2^60 and
+// |a0|, |a1| <= 2^60 for every voxel of the box (kFastDiv, classify_box): (i) cannot happen;
+// under (ii) and (iv) both the IEEE quotient and this one are smaller than 2^-43 in magnitude,
+// which is pixel 0 and "inside" either way (pixel_from_quotients: u > -0.5, round = 0); under
+// (iii) both exceed 2^95, outside any image either way.  a = 0 gives a zero of some sign from
+// both (the sign does not matter to the pixel).  tests/test_carve_gpu.py::
+// test_shared_reciprocal_division_is_ieee asserts bit equality with `/` on every operand triple
+// outside (ii)-(iv) -- random, whole exponent range, engineered rounding ties -- and the harmless
+// outcome inside them.
 __device__ __forceinline__ void divide2_shared_rcp(float a0, float a1, float b, float &u,
                                                    float &v) {
     // both quotients go through the same five steps: two-wide (v_pk_mul_f32 / v_pk_fma_f32 do

@@ -641,7 +641,8 @@ __device__ __forceinline__ void subtile_store_const(const CarveParams &p, uint16
 
 // Sub-tile classification of the coarse tiles carve_fill_kernel could not settle, taken
 // from the list the pre-pass wrote: a fixed grid of workgroups, one tile (four sub-tiles,
-// one per wave) per turn.  46 VGPRs -> 8 waves per SIMD: the work is a chain of dependent
+// one per wave) per turn.  64 VGPRs (the cap of 8 waves per SIMD; two loop-invariant pointers
+// are spilled in the prologue and reloaded once per sub-tile): the work is a chain of dependent
 // reads per sub-tile (coarse masks + matrix -> summed-area entries -> store).
 // (Round 1 launched one workgroup per tile of the whole grid and filled the decided tiles
 // from here, 16 bytes per thread into the byte plane: two million workgroups at 1024^3,
@@ -874,7 +875,9 @@ __device__ __forceinline__ void for_each_work_item(const CarveParams &p, const i
         // 0.035 ms, 128^3 0.103 / 0.065 / 0.047 / 0.048, 192^3 0.093 / 0.068 / 0.058 / 0.115,
         // 256^3 0.094 / 0.076 / 0.114, 320^3 0.097 / 0.118: from there on there are more
         // items than half the waves.)
-        if (16 * items <= p.nwaves)
+        if (p.flags & 64u)  // experiment builds: two parts whatever the list length
+            shift = 1;
+        else if (16 * items <= p.nwaves)
             shift = 3;
         else if (4 * items <= p.nwaves)
             shift = 2;
