@@ -471,11 +471,14 @@ class Context:
         self._ck(self._lib.arvx_colors_upload(self._h, len(index),
                                             index.ctypes.data_as(C.POINTER(C.c_int64)), _fp(rgb)))
 
-    def closure(self, kernel_size: int = 3, apply_unseen: bool = True):
-        """applyClosure; returns (flat indices of the filled voxels, their RGBA)."""
+    def closure(self, kernel_size: int = 3, apply_unseen: bool = True, download: bool = True):
+        """applyClosure; returns (flat indices of the filled voxels, their RGBA) -- or, with
+        download=False, only their number (the list stays on the device)."""
         self._ck(self._lib.arvx_closure(self._h, kernel_size, int(apply_unseen)))
         n = C.c_int64()
         self._ck(self._lib.arvx_closure_count(self._h, C.byref(n)))
+        if not download:
+            return int(n.value)
         idx = np.empty(n.value, np.int64)
         rgba = np.empty((n.value, 4), np.float32)
         if n.value:
@@ -519,6 +522,13 @@ class Context:
             assert np.array_equal(v2, verts) and np.array_equal(faces[:, 3:], rgb)
             assert np.array_equal(faces[:, :3], t3[:, None] + np.arange(3, dtype=np.uint32))
         return verts, rgb
+
+    def mc_mesh_count(self, apply_unseen: bool = False) -> int:
+        """arvx_mc_mesh without the download: the triangles stay on the device."""
+        n = C.c_int64()
+        self._lib.arvx_mc_mesh.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+        self._ck(self._lib.arvx_mc_mesh(self._h, int(apply_unseen), C.byref(n)))
+        return int(n.value)
 
     def export_model(self, apply_unseen: bool = False) -> np.ndarray:
         out = np.empty((self.nvox, 4), np.float32)

@@ -98,3 +98,52 @@ class MultiGpu:
         a, b = C.c_float(), C.c_float()
         self._ck(self._lib.arvx_mgpu_last_times(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+
+def bench_main(argv=None) -> int:
+    """`python -m ar_voxel_project_amd.mgpu --devices N [--grid 512 --views 36 --steps 20]`:
+    the carve over N GPUs from ONE process (ncclCommInitAll, one stream per device), timed per
+    merge.  Prints one JSON line.  bench.py runs it as a child process beside its
+    one-process-per-GPU measurement."""
+    import argparse
+    import json
+    import time
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--devices", type=int, required=True)
+    ap.add_argument("--grid", type=int, default=512)
+    ap.add_argument("--views", type=int, default=36)
+    ap.add_argument("--steps", type=int, default=20)
+    a = ap.parse_args(argv)
+    from . import sharding, synthetic
+    n = a.devices
+    X, Y, Z = sharding.grid_for(n, a.grid)
+    sc = synthetic.sphere_scene(max(X, Y, Z), a.views)
+    out = {"devices": n, "grid": [X, Y, Z], "views": a.views, "steps": a.steps,
+           "driver": "one process, ncclCommInitAll, one stream per device (libarvx_mgpu.so)"}
+    with MultiGpu(list(range(n)), X, Y, Z, sc.voxel_size) as m:
+        m.set_views(sc.M, sc.masks)
+        for name, merge in (("allreduce", MERGE_ALLREDUCE), ("compressed", MERGE_COMPRESSED)):
+            for _ in range(3):  # warm-up (the compressed packets are sized by the first calls)
+                m.reset()
+                m.carve(merge)
+            fell_back = False
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                m.reset()
+                fell_back = m.carve(merge) or fell_back
+            dt = (time.perf_counter() - t0) / a.steps
+            carve_ms, merge_ms = m.times()
+            words = m.occupancy()
+            occ, _ = m.planes()
+            merged_bits = int(np.bitwise_count(words).sum())
+            out[name] = {"ms_per_step": dt * 1e3, "value": X * Y * Z * a.views / dt / 1e6,
+                         "unit": "Mvoxel-views/s", "carve_ms_slowest_device": carve_ms,
+                         "merge_ms": merge_ms, "fell_back_to_allreduce": bool(fell_back),
+                         "merge_ok": merged_bits == int(np.bitwise_count(occ).sum())}
+    print(json.dumps(out))
+    return 0
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(bench_main())

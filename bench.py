@@ -100,6 +100,118 @@ def cpu_baseline(sc, X, Y, Z, budget_s=12.0):
     return out, plane  # plane: the oracle's state of planes z = 0..mt_planes-1
 
 
+def block_noise_masks(V, H, W, block, seed=0):
+    """Masks of random block x block pixel squares, half of them background: every pixel
+    rectangle larger than a square is "mixed", so the rectangle tests settle next to nothing --
+    the worst case for the culling."""
+    rng = np.random.default_rng(seed)
+    hb, wb = (H + block - 1) // block, (W + block - 1) // block
+    coarse = rng.random((V, hb, wb)) >= 0.5
+    m = np.repeat(np.repeat(coarse, block, axis=1), block, axis=2)[:, :H, :W]
+    return (m * 255).astype(np.uint8)
+
+
+def run_workloads(capi, synthetic, dev, check):
+    """The other configurations behind the headline, each in a few launches: the BASELINE.json
+    configurations that fit one GPU, a worst case for the culling, and the north-star target
+    with its planes checked.  Per entry: carve_kernel_ms (HIP events around arvx_carve, best of
+    5), the fraction of (sub-tile, view) pairs the rectangle tests could NOT settle
+    (ARVX_CARVE_STATS, an untimed extra launch) and -- `check`: the CPU oracle as checker --
+    parity of the state with the oracle, every voxel of the planes named."""
+    from tests import golden_io  # the reference's own silhouettes / photographs (fixtures)
+    stream = torch.cuda.current_stream()
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    out = []
+
+    def carve_entry(name, N, M, masks, s, planes=None, post=None):
+        V = masks.shape[0]
+        e = {"workload": name, "grid": [N, N, N], "views": V}
+        with capi.Context(N, N, N, s, device=dev.index) as ctx:
+            ctx.set_stream(stream.cuda_stream)
+            ctx.set_views(M, masks, campos=post["campos"] if post else None)
+            best = 1e9
+            for _ in range(5):
+                ctx.reset()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                ctx.carve(0)
+                b.record(stream)
+                torch.cuda.synchronize()
+                best = min(best, a.elapsed_time(b))
+            e["carve_kernel_ms"] = best
+            e["value"] = N ** 3 * V / best / 1e3
+            e["unit"] = "Mvoxel-views/s"
+            st = ctx.download_state() if (check or post) else None
+            if st is not None:
+                e["occupied_fraction"] = float((st & 1).mean())
+            if post:  # carve -> colour vote -> handleUnseen -> closure -> mesh, src/main.cpp:262-303
+                ctx.set_images(post["images"])
+                stages = {}
+                for stage, call in (("colour_avg", lambda: ctx.color(capi.COLOR_AVERAGE)),
+                                    ("handle_unseen", ctx.handle_unseen),
+                                    ("closure_3", lambda: ctx.closure(3, True, download=False)),
+                                    ("mc_mesh", lambda: ctx.mc_mesh_count(True))):
+                    ctx.synchronize()
+                    t0 = time.perf_counter()
+                    r = call()
+                    ctx.synchronize()
+                    stages[stage] = (time.perf_counter() - t0) * 1e3
+                    if stage == "mc_mesh":
+                        e["triangles"] = int(r)
+                e["stage_ms"] = stages
+                e["stage_ms_note"] = ("wall time of the C-ABI call with inputs resident, incl. its "
+                                      "own synchronisations; no result copied to the host")
+            ctx.reset()
+            ctx.carve(capi.CARVE_STATS)
+            stt = ctx.stats()
+            # pairs that needed per-voxel work, of those the sub-tile stage looked at (the rest was
+            # settled per coarse tile before) and of all (sub-tile, view) pairs of the grid
+            e["mixed_pair_fraction"] = stt["subtile_views_mixed"] / max(1, stt["subtile_views_total"])
+            all_pairs = ((N + 15) // 16) * ((N + 7) // 8) ** 2 * V
+            e["mixed_pairs_of_all"] = stt["subtile_views_mixed"] / all_pairs
+            e["subtiles_carved_by_a_rectangle"] = stt["subtiles_carved"] / max(1, stt["subtiles"])
+        if check:
+            from oracle import pyoracle
+            if planes is None:
+                want = pyoracle.carve(N, N, N, s, M, masks, threads=ncores)
+                got = st
+                e["parity_planes"] = f"all {N}"
+            else:
+                want = pyoracle.carve_planes(N, N, s, M, masks, planes, threads=ncores)
+                got = st[planes]
+                e["parity_planes"] = f"z={planes[0]}..{planes[-1]}"
+            e["parity_vs_oracle"] = bool(np.array_equal(got, want))
+        return e
+
+    def guarded(fn):
+        try:
+            out.append(fn())
+        except Exception as ex:  # noqa: BLE001 -- a workload that cannot run must not cost the line
+            out.append({"error": f"{type(ex).__name__}: {ex}"})
+
+    sc = synthetic.sphere_scene(128, 8)
+    guarded(lambda: carve_entry("C1 Data/box_dataset silhouettes (8 views, PIL-decoded, ring cameras), 128^3",
+                                128, sc.M, golden_io.dataset_masks("box"), sc.voxel_size))
+    sc = synthetic.sphere_scene(256, 24)
+    human = golden_io.dataset_masks("human", recentre=True)
+    guarded(lambda: carve_entry("C2 Data/human_dataset silhouettes (24 views, re-centred, ring cameras), 256^3",
+                                256, sc.M, human, sc.voxel_size))
+    sc5 = synthetic.sphere_scene(512, 24)
+    guarded(lambda: carve_entry("C5 Data/human_dataset 512^3 x 24: carve + colour vote + handleUnseen + "
+                                "closure + marching-cubes mesh", 512, sc5.M, human, sc5.voxel_size,
+                                post={"campos": sc5.campos, "images": golden_io.dataset_images("human")}))
+    sc = synthetic.sphere_scene(512, 36)
+    guarded(lambda: carve_entry("ragged silhouettes: 512^3 x 36 views of 8x8-pixel block noise",
+                                512, sc.M, block_noise_masks(36, sc.H, sc.W, 8), sc.voxel_size))
+    guarded(lambda: carve_entry("worst case for the culling: 512^3 x 36 views of 2x2-pixel block noise "
+                                "(no pixel rectangle of a 4x4x4 block is uniform)",
+                                512, sc.M, block_noise_masks(36, sc.H, sc.W, 2), sc.voxel_size))
+    sc = synthetic.sphere_scene(1024, 36)
+    guarded(lambda: carve_entry("north-star target: sphere, 1024^3 x 36 views", 1024, sc.M, sc.masks,
+                                sc.voxel_size, planes=np.arange(384, 640)))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +232,11 @@ def main():
                     help="skip the NO_CULL ablation leg (keeps a profile to one kernel variant)")
     ap.add_argument("--extra-grid", type=int, default=1024,
                     help="also time this grid at N=1 (0 = skip); reported under 'extra'")
+    ap.add_argument("--no-mgpu", action="store_true",
+                    help="N > 1: skip the one-process-all-GPUs leg (libarvx_mgpu.so)")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="skip the `workloads` array (the other BASELINE configurations, a worst "
+                         "case for the culling and the 1024^3 target with parity)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -335,7 +452,7 @@ def main():
     alg_bytes = nv_rank * r["V"] + r["V"] * r["sc"].W * r["sc"].H
     achieved = alg_bytes / (r["kern_ms"] * 1e-3) / 1e9
     traffic = traffic_step = None
-    valu = None
+    valu = valu_all = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and world == 1:
         try:
@@ -347,6 +464,7 @@ def main():
             # what the dominant kernel is actually bound by: vector-instruction issue.  Peak:
             # 256 CUs x 4 SIMD-32, one wave64 instruction per 2 cycles at 2.4 GHz (the guide's
             # FP32 vector peak counted in instructions; fp64 adds / converts issue slower)
+            valu_all = ent.get("valu_wave_instructions") or None
             ins = ent.get("valu_wave_instructions", {}).get("exact")
             t_ns = ent.get("kernel_avg_ns_rocprofv3", {}).get("exact")
             if ins and t_ns:
@@ -359,33 +477,45 @@ def main():
             traffic = None
     phys = (traffic / (r["kern_ms"] * 1e-3) / 1e9) if traffic else None
     step_kernel_ms = r["kern_ms"] + r["views_ms"]
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "frac_is": "effective (algorithmic bytes of the per-view streaming formulation / "
-                           "time); see physical_frac for what the chip moves",
-                "physical_GBps": phys,
-                "physical_frac": (phys / HBM_PEAK_GBS) if phys else None,
+    # What bounds the carve is vector-instruction issue (the exact kernel) and dependent-read
+    # latency (the classification), not HBM: the roofline is stated against the issue peak --
+    # 256 CUs x 4 SIMDs, one wave64 instruction per 2 cycles at 2.4 GHz (the guide's FP32 vector
+    # peak counted in instructions; fp64 adds / converts issue at half that).  Work = the VALU
+    # wave-instructions of the launch's three kernels (SQ_INSTS_VALU, a PMC pass of the same
+    # command: profiles/traffic.json -- deterministic for a fixed scene), time = this run's.
+    VALU_PEAK = 256 * 4 * 2.4e9 / 2 / 1e9  # G wave-instructions / s
+    ins_all = sum(valu_all.values()) if valu_all else None
+    roofline = {"bound": "valu-issue",
+                "achieved": (ins_all / (r["kern_ms"] * 1e-3) / 1e9) if ins_all else None,
+                "peak": VALU_PEAK, "unit": "G wave-instructions/s",
+                "frac": (ins_all / (r["kern_ms"] * 1e-3) / 1e9 / VALU_PEAK) if ins_all else None,
+                "traffic": traffic,
                 "kernel": "carve_coarse_fill_kernel + carve_classify_kernel + "
                           "carve_exact_blocks_kernel (one arvx_carve call)",
                 "kernel_ms": r["kern_ms"],
-                "algorithmic_bytes": alg_bytes,
-                "valu": valu,
+                "valu_wave_instructions": valu_all,
+                "dominant_kernel": valu,
+                "measured_here": "kernel_ms (HIP events on the launch stream)",
+                "from_profiles": "valu_wave_instructions, traffic, dominant_kernel: "
+                                 "profiles/traffic.json (rocprofv3 --pmc passes of this command)",
+                "hbm_effective": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
+                                  "note": "SURVEY 8d's per-view streaming formulation (N*V + V*W*H "
+                                          "read bytes) / kernel time: an EFFECTIVE rate -- the "
+                                          "kernels keep 2 bits per voxel, write them once and settle "
+                                          "~99 % of the (sub-tile, view) pairs from pixel "
+                                          "rectangles, so it exceeds the physical peak"},
+                "hbm_physical": {"traffic_bytes": traffic, "GBps": phys,
+                                 "frac": (phys / HBM_PEAK_GBS) if phys else None,
+                                 "note": "2 x FETCH_SIZE + WRITE_SIZE per the guide's gfx950 "
+                                         "correction"},
                 "step": {"kernels": "views_bits + views_tile_sums + views_table "
                                     "(arvx_set_views_device) + the three carve kernels",
                          "kernel_ms": step_kernel_ms,
-                         "effective_frac": alg_bytes / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "hbm_effective_frac": alg_bytes / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic_step,
-                         "physical_frac": (traffic_step / (step_kernel_ms * 1e-3) / 1e9 /
-                                           HBM_PEAK_GBS) if traffic_step else None},
-                "note": "algorithmic = N*V + V*W*H read bytes of the per-view streaming "
-                        "formulation (SURVEY 8d); the kernels keep the state at 2 bits per voxel, "
-                        "write it once and decide most 16x8x8 sub-tiles (and 4x4x4 blocks) from "
-                        "pixel-rectangle tests, so `frac` is an EFFECTIVE rate and exceeds the "
-                        "physical peak; `traffic` is the rocprofv3 PMC byte count per launch "
-                        "(2 x FETCH_SIZE + WRITE_SIZE per the guide's gfx950 correction, "
-                        "profiles/traffic.json) and `physical_frac` = traffic / kernel time / "
-                        "peak: the path is bound by vector-instruction issue in the exact kernel "
-                        "(`valu`) and by dependent-read latency in the classification, not by HBM"}
+                         "hbm_physical_frac": (traffic_step / (step_kernel_ms * 1e-3) / 1e9 /
+                                               HBM_PEAK_GBS) if traffic_step else None}}
 
     out = {
         "metric": "Mvoxel-views/s (voxels x views / s) + carve wall-time, 512^3 grid x 36 views",
@@ -411,6 +541,33 @@ def main():
         "roofline": roofline,
     }
 
+    if world > 1:
+        # One scaling run answers every collective question: the headline above is the default
+        # (compressed all-gather over striped slabs); the north star's all-reduce and the plain
+        # all-gather follow with a few steps each -- the same job, the same timing frame, not
+        # part of `value`.
+        def coll_entry(c, k):
+            xb = c["exchange_bytes_per_rank"]
+            return {"ms_per_step": c["dt"] / k * 1e3, "value": c["nvox"] * c["V"] / (c["dt"] / k) / 1e6,
+                    "unit": "Mvoxel-views/s", "steps": k, "layout": c["layout"],
+                    "exchange_bytes_per_rank": xb, "merge_ok": c["merge_ok"],
+                    "carve_kernel_ms": c["kern_ms"], "views_kernel_ms": c["views_ms"]}
+        coll = {args.collective: coll_entry(r, args.steps)}
+        kc = max(5, args.steps // 10)
+        for mode in ("compressed", "allreduce", "allgather"):
+            if mode in coll:
+                continue
+            try:
+                coll[mode] = coll_entry(run_config(args.grid, args.views, kc, 2, mode), kc)
+            except Exception as ex:  # noqa: BLE001
+                coll[mode] = {"error": f"{type(ex).__name__}: {ex}"}
+        if rank == 0:
+            out["collectives"] = coll
+            out["collective_backend"] = {
+                "backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                "library": ("gloo (one-GPU rehearsal)" if rehearsal else
+                            "RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version()))}
+
     if world == 8 and (args.grid, args.views) == (512, 36):
         # BASELINE config 4 as it is written: 1024^3 x 72 views over the 8 GPUs
         try:
@@ -425,6 +582,27 @@ def main():
         except Exception as ex:  # noqa: BLE001
             if rank == 0:
                 out["c4_1024x72"] = {"error": str(ex)}
+
+    if world > 1 and not rehearsal and not args.no_mgpu:
+        # The same job driven by ONE process over all GPUs (libarvx_mgpu.so: ncclCommInitAll, one
+        # stream per device) -- the form a drop-in caller of the reference's carve() uses
+        # (include/arvx/multi_gpu.hpp).  Run as a child process of rank 0 while the ranks of this
+        # job wait on the host (a gloo barrier: their GPUs are idle), with a time limit: a
+        # failure there must not cost the line.
+        host = dist.new_group(backend="gloo")
+        if rank == 0:
+            import subprocess
+            try:
+                cp = subprocess.run([sys.executable, "-m", "ar_voxel_project_amd.mgpu", "--devices",
+                                     str(world), "--grid", str(args.grid), "--views", str(args.views),
+                                     "--steps", str(max(5, args.steps // 10))],
+                                    cwd=ROOT, capture_output=True, text=True, timeout=240)
+                line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+                out["arvx_mgpu"] = (json.loads(line[-1]) if cp.returncode == 0 and line else
+                                    {"error": f"rc {cp.returncode}: {cp.stderr[-400:]}"})
+            except Exception as ex:  # noqa: BLE001 (incl. TimeoutExpired)
+                out["arvx_mgpu"] = {"error": f"{type(ex).__name__}: {ex}"}
+        dist.barrier(group=host)
 
     if rank == 0 and world == 1 and args.extra_grid and args.extra_grid != args.grid:
         try:
@@ -473,6 +651,12 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
         out["parity_vs_oracle"] = None
+
+    if rank == 0 and world == 1 and not args.no_workloads:
+        try:
+            out["workloads"] = run_workloads(capi, synthetic, dev, check=not args.no_cpu)
+        except Exception as ex:  # noqa: BLE001
+            out["workloads"] = [{"error": f"{type(ex).__name__}: {ex}"}]
 
     if rank == 0:
         print(json.dumps(out))

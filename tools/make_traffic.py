@@ -24,7 +24,8 @@ VIEWS = ("views_bits", "views_tile_sums", "views_table", "views_rows", "views_co
 def main():
     name = sys.argv[1]
     summ = json.load(open(os.path.join(ROOT, "profiles", name, "summary.json")))
-    out = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    out = json.load(open(tpath)) if os.path.exists(tpath) else {}  # entries of other runs stay
     for arg in sys.argv[2:]:
         tag, key = arg.split(":")
         ks = summ[tag]
@@ -49,9 +50,9 @@ def main():
                                        if k in ks and "SQ_INSTS_VALU" in ks[k]},
             "source": f"profiles/{name}/summary.json tag {tag} (rocprofv3 --pmc FETCH_SIZE / "
                       "WRITE_SIZE / SQ_* in separate passes over `bench.py --steps 10 --warmup 2 "
-                      "--no-cpu --no-ablation --extra-grid 0`, tools/profile.sh; bytes = 2 x FETCH "
+                      "--no-cpu --no-ablation --no-workloads --extra-grid 0`, tools/profile.sh; bytes = 2 x FETCH "
                       "+ WRITE per the guide's gfx950 correction, raw counters beside it)"}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    json.dump(out, open(tpath, "w"), indent=1)
     for k, v in out.items():
         print(k, {a: (round(b) if isinstance(b, float) else b) for a, b in v.items()
                   if a in ("bytes_per_launch", "bytes_per_step", "carve_kernels_ns", "views_kernels_ns")})
