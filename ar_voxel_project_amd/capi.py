@@ -27,6 +27,7 @@ COLOR_AVERAGE = 1
 # every symbol include/arvx/arvx.h declares
 SYMBOLS = [
     "arvx_version", "arvx_last_error", "arvx_device_count", "arvx_projection_assoc",
+    "arvx_ctx_create_slab_halo",
     "arvx_set_projection_assoc", "arvx_ctx_set_projection_assoc", "arvx_ctx_projection_assoc",
     "arvx_selftest_project", "arvx_selftest_depth",
     "arvx_ctx_create", "arvx_ctx_create_slab", "arvx_ctx_create_striped", "arvx_ctx_destroy",
@@ -207,11 +208,12 @@ class Context:
     def __init__(self, X: int, Y: int, Z: int, voxel_size: float, device: int = 0,
                  z_range: Optional[Sequence[int]] = None,
                  stripes: Optional[Sequence[int]] = None, lib_path: Optional[str] = None,
-                 assoc: Optional[int] = None):
+                 assoc: Optional[int] = None, halo: int = 1):
         """z_range=(z0,z1): contiguous slab.  stripes=(world, rank): 8-plane groups
         rank, rank+world, ... (load-balanced multi-GPU split).  lib_path: another build of
         the library (A/B).  assoc: ASSOC_LEFT / ASSOC_RIGHT, the grouping of the M*world row
-        sums of this context (default: the library's, arvx_projection_assoc)."""
+        sums of this context (default: the library's, arvx_projection_assoc).  halo: planes a
+        slab keeps (and recomputes) beyond its own on each inner side: arvx_ctx_create_slab_halo."""
         self._lib = load_library(lib_path)
         self._h = C.c_void_p()
         self.X, self.Y, self.Z = int(X), int(Y), int(Z)
@@ -225,8 +227,11 @@ class Context:
         else:
             z0, z1 = (0, Z) if z_range is None else (int(z_range[0]), int(z_range[1]))
             self.z_range = (z0, z1)
-            self._ck(self._lib.arvx_ctx_create_slab(C.byref(self._h), device, X, Y, Z,
-                                                  C.c_float(voxel_size), z0, z1))
+            self._lib.arvx_ctx_create_slab_halo.argtypes = [
+                C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                C.c_int, C.c_int]
+            self._ck(self._lib.arvx_ctx_create_slab_halo(C.byref(self._h), device, X, Y, Z,
+                                                       C.c_float(voxel_size), z0, z1, int(halo)))
             self.planes = np.arange(z0, z1)
         nz = len(self.planes)  # global z of every local plane
         self.shape = (nz, Y, X)  # numpy view of the state plane: [z][y][x]

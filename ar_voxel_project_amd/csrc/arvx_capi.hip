@@ -255,7 +255,13 @@ int arvx_compose_projection(const float K[9], const float Rt[12], float M[12]) {
 
 int arvx_ctx_create_slab(arvx_ctx **out, int device, int X, int Y, int Z, float voxel_size,
                          int z_begin, int z_end) {
+    return arvx_ctx_create_slab_halo(out, device, X, Y, Z, voxel_size, z_begin, z_end, 1);
+}
+
+int arvx_ctx_create_slab_halo(arvx_ctx **out, int device, int X, int Y, int Z, float voxel_size,
+                              int z_begin, int z_end, int halo) {
     if (!out) return fail(ARVX_ERR_INVALID, "null out");
+    if (halo < 1 || halo > 16) return fail(ARVX_ERR_INVALID, "halo %d (1..16 planes)", halo);
     *out = nullptr;
     if (X < 1 || Y < 1 || Z < 1) return fail(ARVX_ERR_INVALID, "grid dims must be >= 1");
     if ((int64_t)X * Y * Z > (int64_t)INT32_MAX)
@@ -278,8 +284,9 @@ int arvx_ctx_create_slab(arvx_ctx **out, int device, int X, int Y, int Z, float 
     c->z1 = z_end;
     c->s = voxel_size;
     c->assoc = g_default_assoc.load();
-    c->ze0 = z_begin > 0 ? z_begin - 1 : 0;
-    c->ze1 = z_end < Z ? z_end + 1 : Z;
+    c->halo = halo;
+    c->ze0 = z_begin - halo > 0 ? z_begin - halo : 0;
+    c->ze1 = z_end + halo < Z ? z_end + halo : Z;
     c->nvox = (size_t)X * Y * (size_t)(z_end - z_begin);
     c->nvox_ext = (size_t)X * Y * (size_t)(c->ze1 - c->ze0);
     hipError_t e = acquire_stream(device, &c->own_stream);
@@ -727,10 +734,10 @@ int arvx_state_upload_halo(arvx_ctx *ctx, const uint8_t *plane_below, const uint
     if (ctx->stripe_world > 1) return fail(ARVX_ERR_STATE, "striped slabs keep no halo planes");
     if (!ctx->d_state) ARVX_HIP(hipMalloc(&ctx->d_state, ctx->nvox_ext));
     state_changes(ctx, true);
-    if (plane_below && ctx->ze0 < ctx->z0) {
-        ARVX_HIP(hipMemcpyAsync(ctx->d_state, plane_below, plane, hipMemcpyHostToDevice,
+    if (plane_below && ctx->ze0 < ctx->z0) {  // plane z0 - 1
+        ARVX_HIP(hipMemcpyAsync(ctx->owned() - plane, plane_below, plane, hipMemcpyHostToDevice,
                                 ctx->stream));
-        if (int rc = bytes_into_records(ctx, 0, 1)) return rc;
+        if (int rc = bytes_into_records(ctx, ctx->z0 - ctx->ze0 - 1, 1)) return rc;
     }
     if (plane_above && ctx->ze1 > ctx->z1) {
         ARVX_HIP(hipMemcpyAsync(ctx->owned() + ctx->nvox, plane_above, plane,
@@ -1214,6 +1221,29 @@ int arvx_get_stats(arvx_ctx *ctx, arvx_stats *out) {
     return ARVX_OK;
 }
 
+// Which planes (global z, [lo, hi)) a context's stages work on.  Colours: every plane whose two
+// neighbour planes the records hold (a voxel is on the surface or not by its six neighbours).
+// Closure with radius r: every plane whose 2 r neighbour planes have colours.  A whole-grid
+// context and the sides of a slab that touch the grid's faces lose nothing.
+static void stage_ranges(const Ctx *ctx, int radius, int &c_lo, int &c_hi, int &f_lo, int &f_hi) {
+    c_lo = ctx->ze0 > 0 ? ctx->ze0 + 1 : 0;
+    c_hi = ctx->ze1 < ctx->Z ? ctx->ze1 - 1 : ctx->Z;
+    f_lo = c_lo > 0 ? c_lo + radius : 0;
+    f_hi = c_hi < ctx->Z ? c_hi - radius : ctx->Z;
+}
+// the entries [lo, hi) of an ascending index list over the context's planes that lie in the
+// owned planes; base = what to subtract to number them over the owned planes
+static void owned_part(const Ctx *ctx, const std::vector<int> &idx, size_t &lo, size_t &hi,
+                       long long &base) {
+    const long long plane = (long long)ctx->X * ctx->Y;
+    base = plane * (ctx->z0 - ctx->ze0);
+    const long long end = plane * (ctx->z1 - ctx->ze0);
+    lo = (size_t)(std::lower_bound(idx.begin(), idx.end(), base,
+                                   [](int a, long long b) { return (long long)a < b; }) - idx.begin());
+    hi = (size_t)(std::lower_bound(idx.begin(), idx.end(), end,
+                                   [](int a, long long b) { return (long long)a < b; }) - idx.begin());
+}
+
 // ---- colour pass -----------------------------------------------------------------
 
 int arvx_set_images(arvx_ctx *ctx, const uint8_t *const *images, size_t stride) {
@@ -1253,31 +1283,37 @@ int arvx_color(arvx_ctx *ctx, int mode) {
     if (ctx->stripe_world > 1)
         return fail(ARVX_ERR_STATE, "the colour pass needs contiguous slabs (neighbour planes)");
     ctx->free_surface();
-    // surface = occupied and not inner, on bit planes; the halo planes of a slab take
-    // part as neighbours only
+    // surface = occupied and not inner, on bit planes over the context's planes; colours are
+    // voted for the planes [c_lo, c_hi) (stage_ranges): the owned ones and the halo planes
+    // whose own neighbours the records hold
     const int XW = (ctx->X + 63) / 64;
-    const int Zown = ctx->z1 - ctx->z0, Zext = ctx->ze1 - ctx->ze0;
-    const arvx::BitGrid gext{ctx->X, ctx->Y, Zext, XW}, gown{ctx->X, ctx->Y, Zown, XW};
-    const size_t nw_ext = (size_t)XW * ctx->Y * Zext, nw_own = (size_t)XW * ctx->Y * Zown;
-    const int nblk = (int)((nw_own + arvx::kBitChunk - 1) / arvx::kBitChunk);
+    const int Zext = ctx->ze1 - ctx->ze0;
+    int c_lo, c_hi, f_lo, f_hi;
+    stage_ranges(ctx, 0, c_lo, c_hi, f_lo, f_hi);
+    const arvx::BitGrid gext{ctx->X, ctx->Y, Zext, XW};
+    const size_t row_words = (size_t)XW * ctx->Y;
+    const size_t nw_ext = row_words * Zext, nw_col = row_words * (size_t)(c_hi - c_lo);
+    const int nblk = (int)((nw_ext + arvx::kBitChunk - 1) / arvx::kBitChunk);
     if (int rc = ensure_scratch(ctx, nw_ext * sizeof(unsigned long long) +
                                          (size_t)(nblk + 1) * sizeof(long long) +
                                          (size_t)nblk * sizeof(int) + 64))
         return rc;
     // the surface plane stays with the context: with its ranks it is the index of the colour
     // list (closure and mesh look colours up through it)
-    ARVX_HIP(ctx->pool_col_bits.reserve(nw_own * sizeof(unsigned long long)));
-    ARVX_HIP(ctx->pool_col_rank.reserve(nw_own * sizeof(arvx::SparseWord)));
+    ARVX_HIP(ctx->pool_col_bits.reserve(nw_ext * sizeof(unsigned long long)));
+    ARVX_HIP(ctx->pool_col_rank.reserve(nw_ext * sizeof(arvx::SparseWord)));
     unsigned long long *d_occ = (unsigned long long *)ctx->d_scratch;
     unsigned long long *d_surf = (unsigned long long *)ctx->pool_col_bits.p;
     long long *d_off = (long long *)(d_occ + nw_ext);
     int *d_cnt = (int *)(d_off + nblk + 1);
     if (int rc = launch_bit_pack(ctx, gext, 0, 0, d_occ, nullptr)) return rc;
-    hipLaunchKernelGGL(arvx::bit_surface_kernel, dim3((unsigned)((nw_own + 255) / 256)), dim3(256),
-                       0, ctx->stream, d_occ, gext, ctx->z0 - ctx->ze0, Zown, d_surf);
+    if (nw_col != nw_ext) ARVX_HIP(hipMemsetAsync(d_surf, 0, nw_ext * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(arvx::bit_surface_kernel, dim3((unsigned)((nw_col + 255) / 256)), dim3(256),
+                       0, ctx->stream, d_occ, gext, c_lo - ctx->ze0, c_hi - c_lo,
+                       d_surf + row_words * (size_t)(c_lo - ctx->ze0));
     ARVX_HIP(hipGetLastError());
     long long total = 0;
-    if (int rc = bit_compact_count(ctx, d_surf, nw_own, d_cnt, d_off, &total)) return rc;
+    if (int rc = bit_compact_count(ctx, d_surf, nw_ext, d_cnt, d_off, &total)) return rc;
     ctx->surf_count = total;
     if (total > 0) {
         ARVX_HIP(ctx->pool_surf_index.reserve((size_t)total * sizeof(int)));
@@ -1288,7 +1324,7 @@ int arvx_color(arvx_ctx *ctx, int mode) {
         ctx->d_surf_depth = (float *)ctx->pool_surf_depth.p;
         ARVX_HIP(ctx->pool_surf_has.reserve((size_t)total));
         ctx->d_surf_has = (uint8_t *)ctx->pool_surf_has.p;
-        if (int rc = bit_compact_write(ctx, d_surf, nw_own, gown, d_off, ctx->d_surf_index,
+        if (int rc = bit_compact_write(ctx, d_surf, nw_ext, gext, d_off, ctx->d_surf_index,
                                        (arvx::SparseWord *)ctx->pool_col_rank.p))
             return rc;
         arvx::VoteParams vp;
@@ -1296,7 +1332,7 @@ int arvx_color(arvx_ctx *ctx, int mode) {
         vp.n = total;
         vp.X = ctx->X;
         vp.Y = ctx->Y;
-        vp.zglob0 = ctx->z0;
+        vp.zglob0 = ctx->ze0;  // (list indices run over the context's planes)
         vp.s = ctx->s;
         vp.V = ctx->V;
         vp.W = ctx->W;
@@ -1323,7 +1359,10 @@ int arvx_color(arvx_ctx *ctx, int mode) {
                                 hipMemcpyDeviceToHost, ctx->stream));
         ARVX_HIP(hipStreamSynchronize(ctx->stream));
     }
-    unsigned long long sv = (unsigned long long)total;
+    size_t own_lo, own_hi;
+    long long own_base;
+    owned_part(ctx, ctx->h_surf_index, own_lo, own_hi, own_base);
+    unsigned long long sv = (unsigned long long)(own_hi - own_lo);  // surface voxels of the owned planes
     ARVX_HIP(hipMemcpyAsync(ctx->d_stats + 4, &sv, sizeof sv, hipMemcpyHostToDevice, ctx->stream));
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
     ctx->color_ready = true;
@@ -1333,8 +1372,11 @@ int arvx_color(arvx_ctx *ctx, int mode) {
 int arvx_surface_count(arvx_ctx *ctx, int64_t *count) {
     if (!ctx || !count) return fail(ARVX_ERR_INVALID, "null argument");
     if (!ctx->color_ready) return fail(ARVX_ERR_STATE, "no colour result (call arvx_color)");
+    size_t lo, hi;
+    long long base;
+    owned_part(ctx, ctx->h_surf_index, lo, hi, base);
     int64_t n = 0;
-    for (uint8_t h : ctx->h_surf_has) n += h;
+    for (size_t e = lo; e < hi; ++e) n += ctx->h_surf_has[e];
     *count = n;
     return ARVX_OK;
 }
@@ -1359,10 +1401,13 @@ int arvx_surface_download(arvx_ctx *ctx, int64_t *index, float *rgb) {
     std::vector<float> hrgb, hdepth;
     int rc = surface_fetch(ctx, hrgb, hdepth);
     if (rc) return rc;
+    size_t lo, hi;
+    long long base;
+    owned_part(ctx, ctx->h_surf_index, lo, hi, base);
     size_t k = 0;
-    for (size_t e = 0; e < ctx->h_surf_has.size(); ++e) {
+    for (size_t e = lo; e < hi; ++e) {
         if (!ctx->h_surf_has[e]) continue;
-        index[k] = ctx->h_surf_index[e];
+        index[k] = ctx->h_surf_index[e] - base;
         rgb[3 * k] = hrgb[4 * e];
         rgb[3 * k + 1] = hrgb[4 * e + 1];
         rgb[3 * k + 2] = hrgb[4 * e + 2];
@@ -1378,8 +1423,11 @@ int arvx_surface_depth_download(arvx_ctx *ctx, float *depth) {
     std::vector<float> hrgb, hdepth;
     int rc = surface_fetch(ctx, hrgb, hdepth);
     if (rc) return rc;
+    size_t lo, hi;
+    long long base;
+    owned_part(ctx, ctx->h_surf_index, lo, hi, base);
     size_t k = 0;
-    for (size_t e = 0; e < ctx->h_surf_has.size(); ++e)
+    for (size_t e = lo; e < hi; ++e)
         if (ctx->h_surf_has[e]) depth[k++] = hdepth[e];
     return ARVX_OK;
 }
@@ -1406,14 +1454,18 @@ int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen) {
         const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 16384);
         hipLaunchKernelGGL(arvx::export_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, g,
                            zown, i0, n, paint_plane(ctx), d_out, apply_unseen);
+        // entries of an ascending list (numbered over the context's planes) in owned voxels
+        // [i0, i0 + n)
+        const long long own_base = (long long)ctx->X * ctx->Y * zown;
+        auto list_range = [&](const std::vector<int> &idx, long long &first, long long &last) {
+            auto below = [](int a, long long b) { return (long long)a < b; };
+            first = std::lower_bound(idx.begin(), idx.end(), own_base + (long long)i0, below) - idx.begin();
+            last = std::lower_bound(idx.begin(), idx.end(), own_base + (long long)(i0 + n), below) -
+                   idx.begin();
+        };
         if (ctx->color_ready && ctx->surf_count > 0) {
-            const auto &idx = ctx->h_surf_index;
-            const long long first =
-                std::lower_bound(idx.begin(), idx.end(), (int)i0) - idx.begin();
-            const long long last = (i0 + n > (size_t)INT32_MAX)
-                                       ? (long long)idx.size()
-                                       : std::lower_bound(idx.begin(), idx.end(), (int)(i0 + n)) -
-                                             idx.begin();
+            long long first, last;
+            list_range(ctx->h_surf_index, first, last);
             if (last > first)
                 hipLaunchKernelGGL(arvx::export_scatter_kernel,
                                    dim3((unsigned)((last - first + 255) / 256)), dim3(256), 0,
@@ -1421,18 +1473,13 @@ int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen) {
                                    g, zown, paint_plane(ctx), i0, d_out, apply_unseen);
         }
         if (ctx->closure_ready && ctx->clo_count > 0) {
-            const auto &idx = ctx->h_clo_index;
-            const long long first =
-                std::lower_bound(idx.begin(), idx.end(), (int)i0) - idx.begin();
-            const long long last = (i0 + n > (size_t)INT32_MAX)
-                                       ? (long long)idx.size()
-                                       : std::lower_bound(idx.begin(), idx.end(), (int)(i0 + n)) -
-                                             idx.begin();
+            long long first, last;
+            list_range(ctx->h_clo_index, first, last);
             if (last > first)
                 hipLaunchKernelGGL(arvx::export_overlay_kernel,
                                    dim3((unsigned)((last - first + 255) / 256)), dim3(256), 0,
                                    ctx->stream, ctx->d_clo_index, (const float4 *)ctx->d_clo_rgba,
-                                   first, last, i0, d_out);
+                                   first, last, (size_t)own_base, i0, d_out);
         }
         hipError_t e = hipGetLastError();
         if (e == hipSuccess)
@@ -1542,10 +1589,11 @@ int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const flo
     if (n < 0 || (n > 0 && (!index || !rgb))) return fail(ARVX_ERR_INVALID, "bad colour list");
     ctx->free_surface();
     std::vector<int> idx((size_t)n);
+    const long long own_base = (long long)ctx->X * ctx->Y * (ctx->z0 - ctx->ze0);
     for (int64_t k = 0; k < n; ++k) {
         if (index[k] < 0 || (size_t)index[k] >= ctx->nvox || (k && index[k] <= index[k - 1]))
             return fail(ARVX_ERR_INVALID, "colour indices must be ascending and inside the grid");
-        idx[(size_t)k] = (int)index[k];
+        idx[(size_t)k] = (int)(index[k] + own_base);  // numbered over the context's planes
     }
     ctx->surf_count = n;
     ctx->h_surf_index = idx;
@@ -1574,7 +1622,7 @@ int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const flo
         ARVX_HIP(hipMemsetAsync(ctx->d_surf_has, 1, (size_t)n, ctx->stream));
         // the list's plane + ranks (what arvx_color leaves behind)
         const int XW = (ctx->X + 63) / 64;
-        const arvx::BitGrid gown{ctx->X, ctx->Y, ctx->z1 - ctx->z0, XW};
+        const arvx::BitGrid gown{ctx->X, ctx->Y, ctx->ze1 - ctx->ze0, XW};  // the context's planes
         const size_t nw = (size_t)XW * gown.Y * gown.Z;
         const int nblk = (int)((nw + arvx::kBitChunk - 1) / arvx::kBitChunk);
         ARVX_HIP(ctx->pool_col_bits.reserve(nw * sizeof(unsigned long long)));
@@ -1614,18 +1662,29 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     ARVX_CHECK_CTX(ctx);
     if (kernel_size < 1 || kernel_size % 2 != 1 || kernel_size > 9)
         return fail(ARVX_ERR_INVALID, "kernel size %d (odd, 1..9)", kernel_size);
-    if (ctx->z0 != 0 || ctx->z1 != ctx->Z || ctx->stripe_world > 1)
-        return fail(ARVX_ERR_STATE, "arvx_closure needs the whole grid in one context");
+    if (ctx->stripe_world > 1)
+        return fail(ARVX_ERR_STATE, "arvx_closure needs contiguous slabs (neighbour planes)");
     if (ctx->closure_ready)
         return fail(ARVX_ERR_STATE, "closure already applied to this model state");
+    const int radius = (kernel_size - 1) / 2;
+    // the planes that get filled here: all owned ones, plus the halo planes whose box lies
+    // inside the planes that carry colours (stage_ranges)
+    int c_lo, c_hi, f_lo, f_hi;
+    stage_ranges(ctx, radius, c_lo, c_hi, f_lo, f_hi);
+    if (f_lo > ctx->z0 || f_hi < ctx->z1)
+        return fail(ARVX_ERR_STATE,
+                    "a slab needs %d halo planes for a closure of size %d (it has %d): "
+                    "arvx_ctx_create_slab_halo", radius + 1, kernel_size, ctx->halo);
     if (int mrc = need_rec(ctx)) return mrc;
     ctx->free_closure();
-    // filled = dilate(occupied, box of radius r) and not occupied, on bit planes
+    // filled = dilate(occupied, box of radius r) and not occupied, on bit planes over the
+    // context's planes
     const int XW = (ctx->X + 63) / 64;
-    const arvx::BitGrid g{ctx->X, ctx->Y, ctx->Z, XW};
-    const size_t nwords = (size_t)XW * g.Y * g.Z;
+    const int Zext = ctx->ze1 - ctx->ze0;
+    const arvx::BitGrid g{ctx->X, ctx->Y, Zext, XW};
+    const size_t row_words = (size_t)XW * g.Y;
+    const size_t nwords = row_words * g.Z;
     const int nblk = (int)((nwords + arvx::kBitChunk - 1) / arvx::kBitChunk);
-    const int radius = (kernel_size - 1) / 2;
     const bool paints = apply_unseen || ctx->paint_valid;  // somebody is UNSEEN_COLOR
     if (int rc = ensure_scratch(ctx, 4 * nwords * sizeof(unsigned long long) +
                                          (size_t)(nblk + 1) * sizeof(long long) +
@@ -1648,6 +1707,13 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     hipLaunchKernelGGL(arvx::bit_dilate_yz_kernel, dim3(gw), dim3(256), 0, ctx->stream, d_b, g,
                        radius, 2, (const unsigned long long *)d_occ, d_fill);
     ARVX_HIP(hipGetLastError());
+    // (halo planes outside [f_lo, f_hi): their boxes reach planes this context knows nothing
+    // about -- not filled here, their owners do it)
+    if (f_lo > ctx->ze0)
+        ARVX_HIP(hipMemsetAsync(d_fill, 0, row_words * (size_t)(f_lo - ctx->ze0) * 8, ctx->stream));
+    if (f_hi < ctx->ze1)
+        ARVX_HIP(hipMemsetAsync(d_fill + row_words * (size_t)(f_hi - ctx->ze0), 0,
+                                row_words * (size_t)(ctx->ze1 - f_hi) * 8, ctx->stream));
     long long total = 0;
     if (int rc = bit_compact_count(ctx, d_fill, nwords, d_cnt, d_off, &total)) return rc;
     ctx->clo_count = total;
@@ -1689,13 +1755,17 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     }
     ctx->closure_ready = true;
     ctx->closure_unseen = apply_unseen ? 1 : 0;
+    ctx->closure_radius = radius;
     return ARVX_OK;
 }
 
 int arvx_closure_count(arvx_ctx *ctx, int64_t *count) {
     if (!ctx || !count) return fail(ARVX_ERR_INVALID, "null argument");
     if (!ctx->closure_ready) return fail(ARVX_ERR_STATE, "no closure result (call arvx_closure)");
-    *count = ctx->clo_count;
+    size_t lo, hi;
+    long long base;
+    owned_part(ctx, ctx->h_clo_index, lo, hi, base);
+    *count = (int64_t)(hi - lo);  // (the filled voxels of the owned planes)
     return ARVX_OK;
 }
 
@@ -1703,10 +1773,13 @@ int arvx_closure_download(arvx_ctx *ctx, int64_t *index, float *rgba) {
     ARVX_CHECK_CTX(ctx);
     if (!index || !rgba) return fail(ARVX_ERR_INVALID, "null argument");
     if (!ctx->closure_ready) return fail(ARVX_ERR_STATE, "no closure result (call arvx_closure)");
-    for (size_t k = 0; k < ctx->h_clo_index.size(); ++k) index[k] = ctx->h_clo_index[k];
-    if (ctx->clo_count) {
-        ARVX_HIP(hipMemcpyAsync(rgba, ctx->d_clo_rgba, (size_t)ctx->clo_count * sizeof(float4),
-                                hipMemcpyDeviceToHost, ctx->stream));
+    size_t lo, hi;
+    long long base;
+    owned_part(ctx, ctx->h_clo_index, lo, hi, base);
+    for (size_t k = lo; k < hi; ++k) index[k - lo] = ctx->h_clo_index[k] - base;
+    if (hi > lo) {
+        ARVX_HIP(hipMemcpyAsync(rgba, (const float4 *)ctx->d_clo_rgba + lo,
+                                (hi - lo) * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
         ARVX_HIP(hipStreamSynchronize(ctx->stream));
     }
     return ARVX_OK;
@@ -1798,11 +1871,27 @@ int arvx_mc_cells_download(arvx_ctx *ctx, int32_t *cells) {
 int arvx_mc_mesh(arvx_ctx *ctx, int apply_unseen, int64_t *triangles) {
     ARVX_CHECK_CTX(ctx);
     if (!triangles) return fail(ARVX_ERR_INVALID, "null argument");
-    if (ctx->z0 != 0 || ctx->z1 != ctx->Z || ctx->stripe_world > 1)
-        return fail(ARVX_ERR_STATE, "arvx_mc_mesh needs the whole grid in one context");
+    if (ctx->stripe_world > 1)
+        return fail(ARVX_ERR_STATE, "arvx_mc_mesh needs contiguous slabs (neighbour planes)");
     if (ctx->closure_ready && (apply_unseen != 0) != (ctx->closure_unseen != 0))
         return fail(ARVX_ERR_STATE, "arvx_closure was computed with apply_unseen=%d",
                     ctx->closure_unseen);
+    {
+        // a slab lists the cells whose upper plane it owns: their corners lie in planes
+        // z0 - 1 .. z1 - 1, and plane z0 - 1 (a halo plane) must carry whatever the owned
+        // planes carry -- colours, the closure's fills -- or the cells at the slab's lower
+        // face would be coloured differently from the whole-grid result
+        int c_lo, c_hi, f_lo, f_hi;
+        stage_ranges(ctx, ctx->closure_radius, c_lo, c_hi, f_lo, f_hi);
+        const int low = ctx->z0 > 0 ? ctx->z0 - 1 : 0;
+        if (ctx->color_ready && ctx->surf_count > 0 && c_lo > low)
+            return fail(ARVX_ERR_STATE, "a slab's mesh needs 2 halo planes once colours exist "
+                                        "(it has %d): arvx_ctx_create_slab_halo", ctx->halo);
+        if (ctx->closure_ready && f_lo > low)
+            return fail(ARVX_ERR_STATE, "a slab's mesh needs %d halo planes after a closure of "
+                                        "radius %d (it has %d): arvx_ctx_create_slab_halo",
+                        ctx->closure_radius + 2, ctx->closure_radius, ctx->halo);
+    }
     int64_t ncells = 0;
     if (int rc = arvx_mc_cells(ctx, &ncells)) return rc;
     ctx->mesh_tris = 0;
@@ -1883,10 +1972,14 @@ int arvx_closure_download32(arvx_ctx *ctx, int32_t *index, float *rgba) {
     ARVX_CHECK_CTX(ctx);
     if (!index || !rgba) return fail(ARVX_ERR_INVALID, "null argument");
     if (!ctx->closure_ready) return fail(ARVX_ERR_STATE, "no closure result (call arvx_closure)");
-    if (ctx->clo_count) {
-        memcpy(index, ctx->h_clo_index.data(), (size_t)ctx->clo_count * sizeof(int32_t));
-        ARVX_HIP(hipMemcpyAsync(rgba, ctx->d_clo_rgba, (size_t)ctx->clo_count * sizeof(float4),
-                                hipMemcpyDeviceToHost, ctx->stream));
+    size_t lo, hi;
+    long long base;
+    owned_part(ctx, ctx->h_clo_index, lo, hi, base);
+    if (hi > lo) {
+        if (base == 0) memcpy(index, ctx->h_clo_index.data() + lo, (hi - lo) * sizeof(int32_t));
+        else for (size_t k = lo; k < hi; ++k) index[k - lo] = (int32_t)(ctx->h_clo_index[k] - base);
+        ARVX_HIP(hipMemcpyAsync(rgba, (const float4 *)ctx->d_clo_rgba + lo,
+                                (hi - lo) * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
         ARVX_HIP(hipStreamSynchronize(ctx->stream));
     }
     return ARVX_OK;

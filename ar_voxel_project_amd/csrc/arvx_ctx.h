@@ -44,7 +44,8 @@ struct Ctx {
     int device = 0;
     int X = 0, Y = 0, Z = 0;  // full grid
     int z0 = 0, z1 = 0;       // slab owned here
-    int ze0 = 0, ze1 = 0;     // slab plus one halo plane each side (clipped to the grid)
+    int ze0 = 0, ze1 = 0;     // slab plus `halo` planes each side (clipped to the grid)
+    int halo = 1;             // halo planes per inner side (arvx_ctx_create_slab_halo)
     int stripe_world = 1, stripe_rank = 0;  // striped slabs (arvx_ctx_create_striped)
     float s = 0.f;
     int assoc = 1;        // grouping of the M * world row sums (ARVX_ASSOC_*, arvx_device.h)
@@ -107,7 +108,12 @@ struct Ctx {
     float4 *d_surf_rgba = nullptr;    // r, g, b, has-sample flag per surface voxel
     float *d_surf_depth = nullptr;    // minimum sample depth per surface voxel
     uint8_t *d_surf_has = nullptr;    // 1 if the voxel received >= 1 sample
-    int64_t surf_count = 0;           // occupied non-inner voxels found
+    int64_t surf_count = 0;           // occupied non-inner voxels found (planes c_lo .. c_hi)
+    // Index lists (d_surf_index, d_clo_index) hold flat indices over the context's planes
+    // ze0 .. ze1 - 1 (x + X * (y + Y * (z - ze0))): a slab with a halo wider than one plane
+    // colours / closes some halo planes too, because its OWNED cells and voxels need their
+    // neighbours' results (stage_ranges in arvx_capi.hip).  What the download calls return is
+    // the owned part, relative to the owned planes.
     std::vector<int> h_surf_index;    // host copy (ascending)
     std::vector<uint8_t> h_surf_has;
     bool color_ready = false;
@@ -120,6 +126,7 @@ struct Ctx {
     int64_t clo_count = 0;
     bool closure_ready = false;
     int closure_unseen = 0;
+    int closure_radius = 0;
     std::vector<int> h_clo_index;
     DevPool pool_clo_bits, pool_clo_rank;  // the filled voxels' plane and index (SparseWord)
 

@@ -23,7 +23,7 @@
 namespace arvx {
 
 struct ClosureParams {
-    BitGrid g;                         // the whole grid
+    BitGrid g;                         // the context's planes (the whole grid, or slab + halo)
     const unsigned long long *occ;     // what the closure calls occupied
     const unsigned long long *unseen;  // voxels whose colour is UNSEEN_COLOR (null: none)
     int radius;                        // (kernelSize - 1) / 2
@@ -154,12 +154,14 @@ __global__ __launch_bounds__(256) void closure_fill_kernel(const ClosureParams p
     rgba[e] = make_float4(sum.x / fc, sum.y / fc, sum.z / fc, sum.w / fc);
 }
 
+// (base: flat index of the first owned voxel in the list's numbering over the context's planes)
 __global__ __launch_bounds__(256) void export_overlay_kernel(const int *__restrict__ index,
                                                              const float4 *__restrict__ rgba,
                                                              long long first, long long last,
-                                                             size_t i0, float4 *__restrict__ out) {
+                                                             size_t base, size_t i0,
+                                                             float4 *__restrict__ out) {
     const long long e = first + (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e < last) out[(size_t)index[e] - i0] = rgba[e];
+    if (e < last) out[(size_t)index[e] - base - i0] = rgba[e];
 }
 
 }  // namespace arvx

@@ -44,7 +44,7 @@ constexpr McTriTable make_mc_tri_table() {
 __constant__ McTriTable kMcTri = make_mc_tri_table();
 
 struct McMeshParams {
-    CarveParams g;         // the state records (whole grid)
+    CarveParams g;         // the state records (whole grid, or slab + halo)
     const unsigned long long *paint;  // voxels painted UNSEEN_COLOR by the host (null: none)
     int apply_unseen;      // never-seen voxels are painted UNSEEN_COLOR
     SparseList col;        // colour pass: index, (r, g, b, has-sample flag)
@@ -53,9 +53,11 @@ struct McMeshParams {
     const float4 *clo_rgba;
 };
 
-// rgb of an occupied voxel
-__device__ inline float3 mc_voxel_rgb(const McMeshParams &p, int x, int y, int z) {
+// rgb of an occupied voxel (z: global plane; records, paint plane and lists are indexed by the
+// context's local planes)
+__device__ inline float3 mc_voxel_rgb(const McMeshParams &p, int x, int y, int zg) {
     const int X = p.g.X, Y = p.g.Y, XW = (X + 63) >> 6;
+    const int z = zg - p.g.zoff;
     if (plane_bit(p.paint, X, Y, x, y, z) || (p.apply_unseen && !rec_seen(p.g, x, y, z)))
         return make_float3(204.f, 0.f, 0.f);
     const size_t row = (size_t)z * Y + y;

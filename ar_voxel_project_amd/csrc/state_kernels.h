@@ -311,9 +311,10 @@ __global__ __launch_bounds__(256) void export_scatter_kernel(
     if (e >= last) return;
     const float4 c = rgba[e];
     if (c.w == 0.f) return;  // no sample: the voxel keeps what the state says
-    const size_t i = (size_t)index[e];
-    const int x = (int)(i % p.X), y = (int)((i / p.X) % p.Y),
-              lz = zown + (int)(i / ((size_t)p.X * p.Y));
+    // (list indices run over the context's planes; `out` over the owned ones)
+    const size_t j = (size_t)index[e];
+    const int x = (int)(j % p.X), y = (int)((j / p.X) % p.Y), lz = (int)(j / ((size_t)p.X * p.Y));
+    const size_t i = j - (size_t)zown * p.X * p.Y;
     // handleUnseen runs after colouring
     if (plane_bit(paint, p.X, p.Y, x, y, lz) || (apply_unseen && !(rec_state(p, x, y, lz) & 2u)))
         return;

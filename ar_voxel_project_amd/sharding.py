@@ -80,6 +80,58 @@ def merge_mc_cells(per_rank):
     return cells[order]
 
 
+def merge_closure(per_rank, X: int, Y: int, slabs):
+    """The filled voxels of the slab contexts (Context.closure: (index, rgba) per rank, indices
+    numbered over the rank's OWN planes) -> the whole grid's list, ascending flat index: slabs
+    are ordered by z, so this is a concatenation with the index moved to the grid's numbering.
+    slabs: (z0, z1) per rank."""
+    import numpy as np
+    idx = [np.asarray(i, np.int64) + X * Y * z0 for (i, _), (z0, _z1) in zip(per_rank, slabs)]
+    rgba = [np.asarray(c, np.float32).reshape(-1, 4) for _, c in per_rank]
+    return np.concatenate(idx), np.concatenate(rgba)
+
+
+def merge_surface(per_rank, X: int, Y: int, slabs):
+    """The coloured voxels of the slab contexts (Context.surface: (index, rgb)) -> the whole
+    grid's list, as merge_closure."""
+    import numpy as np
+    idx = [np.asarray(i, np.int64) + X * Y * z0 for (i, _), (z0, _z1) in zip(per_rank, slabs)]
+    rgb = [np.asarray(c, np.float32).reshape(-1, 3) for _, c in per_rank]
+    return np.concatenate(idx), np.concatenate(rgb)
+
+
+def triangles_per_cube_index():
+    """Triangles Bourke's table emits per cube index (include/arvx/mc_triangles.inc: three hex
+    digits per triangle)."""
+    import os
+    import re
+    import numpy as np
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include",
+                       "arvx", "mc_triangles.inc")
+    rows = re.findall(r'"([0-9a-f]*)"', open(inc).read().split("*/", 1)[1])
+    assert len(rows) == 256
+    return np.array([len(r) // 3 for r in rows], np.int64)
+
+
+def merge_mesh(per_rank):
+    """The meshes of the slab contexts -- per rank (cells (n,4), verts (3T,3), face_rgb (T,3)):
+    Context.mc_cells and Context.mc_mesh of the same state -- -> the mesh marchingCubes() builds
+    of the whole grid: cells in the reference's visiting order (x outermost, then y, then z;
+    slabs own disjoint z ranges), every cell's triangles kept together and in their order."""
+    import numpy as np
+    ntri = triangles_per_cube_index()
+    cells = np.concatenate([np.asarray(c, np.int32).reshape(-1, 4) for c, _, _ in per_rank])
+    verts = np.concatenate([np.asarray(v, np.float32).reshape(-1, 9) for _, v, _ in per_rank])
+    rgb = np.concatenate([np.asarray(r, np.uint32).reshape(-1, 3) for _, _, r in per_rank])
+    count = ntri[cells[:, 3] & 255]
+    start = np.concatenate([[0], np.cumsum(count)[:-1]])  # first triangle of a cell, slab order
+    assert int(count.sum()) == len(verts) == len(rgb)
+    order = np.lexsort((cells[:, 2], cells[:, 1], cells[:, 0]))
+    take = np.concatenate([np.arange(start[c], start[c] + count[c]) for c in order]) \
+        if len(order) else np.zeros(0, np.int64)
+    return cells[order], verts[take].reshape(-1, 3), rgb[take]
+
+
 def words_of(nvox: int) -> int:
     return (nvox + 31) // 32
 

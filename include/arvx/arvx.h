@@ -101,6 +101,18 @@ int arvx_ctx_create(arvx_ctx **out, int device, int X, int Y, int Z,
  * (one Z slab of a multi-GPU split). State buffers cover the slab only. */
 int arvx_ctx_create_slab(arvx_ctx **out, int device, int X, int Y, int Z,
                          float voxel_size, int z_begin, int z_end);
+/* The same with `halo` planes kept (and recomputed by the carve: carving is a pure function of
+ * the voxel position) on each side that lies inside the grid; arvx_ctx_create_slab keeps 1.
+ * The stages after the carve look further: a voxel is on the surface by its six neighbours
+ * (colour pass: 1 plane), the closure's box has radius r = (kernel_size - 1) / 2 and averages
+ * its neighbours' COLOURS (r + 1 planes), and the mesh of a slab's cells needs the colours and
+ * fills of plane z_begin - 1 (2 planes with colours, r + 2 after a closure: 3 for the
+ * reference's kernel size 3).  With enough halo every slab computes its part of
+ * carve -> colour -> handleUnseen -> closure -> mesh without any exchange, and the parts put
+ * together are the whole-grid result (ar_voxel_project_amd/sharding.py: merge_closure,
+ * merge_mesh; tests/test_sharded_stages_gpu.py).  A call that lacks halo planes says so. */
+int arvx_ctx_create_slab_halo(arvx_ctx **out, int device, int X, int Y, int Z,
+                              float voxel_size, int z_begin, int z_end, int halo);
 /* Same grid, striped over `world` GPUs for load balance: with the planes cut
  * into groups of 8, this context holds groups rank, rank+world, rank+2*world, ...
  * back to back (Z must be a multiple of 8).  Carve, state up/download and
@@ -281,7 +293,9 @@ int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const flo
  * neighbours.  apply_unseen != 0: the model is taken as it is after
  * handleUnseen().  State bytes may carry bit2 (voxel painted UNSEEN_COLOR by
  * a host Model; kept beside the records as a bit plane until the next carve, plane upload or
- * reset).  Whole-grid contexts only.  The filled voxels become occupied;
+ * reset).  Whole-grid contexts and slabs with at least r + 1 halo planes
+ * (arvx_ctx_create_slab_halo): a slab fills -- and reports -- the voxels of its own planes.
+ * The filled voxels become occupied;
  * arvx_export_model(ctx, ., same apply_unseen) then returns the closed model. */
 int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen);
 int arvx_closure_count(arvx_ctx *ctx, int64_t *count);
@@ -311,8 +325,10 @@ int arvx_mc_cells_download(arvx_ctx *ctx, int32_t *cells);
  * `verts` gets 9 floats per triangle, voxel units -- and the face colour face_rgb[3t..3t+2]
  * (rounded mean with the reference's `i + 1` quirk, :506).  Voxel colours: UNSEEN_COLOR where
  * handleUnseen painted (apply_unseen != 0: every never-seen voxel; bit2 of uploaded bytes),
- * else the closure's colour, else the colour pass's, else MODEL_COLOR.  Whole-grid contexts.
- * Runs arvx_mc_cells itself; the order is the reference's. */
+ * else the closure's colour, else the colour pass's, else MODEL_COLOR.  Whole-grid contexts and
+ * slabs with enough halo planes (arvx_ctx_create_slab_halo): a slab builds the triangles of the
+ * cells arvx_mc_cells lists for it (global z).  Runs arvx_mc_cells itself; the order is the
+ * reference's. */
 int arvx_mc_mesh(arvx_ctx *ctx, int apply_unseen, int64_t *triangles);
 int arvx_mc_mesh_download(arvx_ctx *ctx, float *verts, uint32_t *face_rgb);
 /* The same triangles with whole face records, 6 uints per triangle: the vertex numbers 3t,
