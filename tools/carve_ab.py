@@ -41,6 +41,24 @@ def child(grids):
                 ms.append(a.elapsed_time(b))
             ctx.close()
             out.append(f"{'LEFT' if assoc else 'RIGHT'} median {np.median(ms[5:]):.4f} min {np.min(ms):.4f} ms")
+        # the bench's step: derive the views from the resident masks, then carve
+        import time
+        ctx = capi.Context(N, N, N, sc.voxel_size)
+        ctx.set_stream(stream.cuda_stream)
+        d_masks = torch.from_numpy(sc.masks).to(dev)
+        steps = []
+        for rep in range(4):
+            K = 100
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                ctx.reset()
+                ctx.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1)
+                ctx.carve(0)
+            torch.cuda.synchronize()
+            steps.append((time.perf_counter() - t0) / K * 1e3)
+        ctx.close()
+        out.append(f"step (views + carve) {min(steps[1:]):.4f} ms")
         print(f"  N={N}: " + " | ".join(out), flush=True)
 
 
