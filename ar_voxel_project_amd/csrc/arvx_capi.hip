@@ -134,7 +134,7 @@ static int ensure_scratch(Ctx *ctx, size_t need) {
     return ARVX_OK;
 }
 
-static int need_rec(Ctx *ctx);
+static int need_rec(Ctx *ctx, bool lazy_ok = false);
 static void carve_geometry(const Ctx *ctx, arvx::CarveParams &p);
 
 // the paint plane where it takes part (null: nobody is painted)
@@ -147,7 +147,7 @@ static const unsigned long long *paint_plane(const Ctx *ctx) {
 // voxels whose colour is UNSEEN_COLOR.
 static int launch_bit_pack(Ctx *ctx, const arvx::BitGrid &g, int closure_occupied, int apply_unseen,
                            unsigned long long *occ, unsigned long long *unseen) {
-    if (int rc = need_rec(ctx)) return rc;
+    if (int rc = need_rec(ctx, true)) return rc;  // (bitgrid_from_rec_kernel reads lazy tiles)
     const size_t nwords = (size_t)g.XW * g.Y * g.Z;
     arvx::CarveParams p;
     carve_geometry(ctx, p);
@@ -624,6 +624,7 @@ static void carve_geometry(const Ctx *ctx, arvx::CarveParams &p) {
     p.coarseX = (p.X + arvx::kCoarseX - 1) / arvx::kCoarseX;
     p.coarseY = (p.Y + (8 << p.cyShift) - 1) / (8 << p.cyShift);
     p.coarseZ = (p.Z + (8 << p.czShift) - 1) / (8 << p.czShift);
+    p.ccode = ctx->lazy ? (const uint8_t *)ctx->pool_ccode.p : nullptr;
 }
 
 // a record buffer for this context's grid, every record "finished" when it is new
@@ -643,13 +644,30 @@ static int ensure_records(Ctx *ctx, void **buf, size_t *cap) {
     return ARVX_OK;
 }
 
-// The state as records: what every stage works on.
-static int need_rec(Ctx *ctx) {
+// The state as records: what every stage works on.  lazy_ok: the caller's kernels read the
+// coarse tiles a fresh carve settled as a whole from their codes (CarveParams::ccode); everybody
+// else gets those tiles written out first -- the fill the carve itself skipped.
+static int need_rec(Ctx *ctx, bool lazy_ok) {
     void *buf = ctx->d_rec;
     if (int rc = ensure_records(ctx, &buf, &ctx->rec_bytes)) return rc;
     ctx->d_rec = (uint16_t *)buf;
-    if (ctx->rec_valid) return ARVX_OK;
     arvx::CarveParams g;
+    if (ctx->rec_valid) {
+        if (ctx->lazy && !lazy_ok) {
+            carve_geometry(ctx, g);
+            g.rec = ctx->d_rec;
+            g.ccode = nullptr;
+            g.coarseCarved = (uint8_t *)ctx->pool_ccode.p;
+            g.flags = 4u;  // codes 2 and 3 are those of a fresh model: written as such
+            hipLaunchKernelGGL(arvx::carve_fill_kernel,
+                               dim3((unsigned)((size_t)g.coarseX * g.coarseY * g.coarseZ)), dim3(256),
+                               0, ctx->stream, g);
+            ARVX_HIP(hipGetLastError());
+            ctx->lazy = false;
+        }
+        return ARVX_OK;
+    }
+    ctx->lazy = false;
     carve_geometry(ctx, g);
     g.rec = ctx->d_rec;
     g.flags = 4u | 16u;  // a fresh model: all occupied, none seen
@@ -697,7 +715,7 @@ static int bytes_into_records(Ctx *ctx, int zl0, int nz) {
 
 // the byte staging buffer holds the current state of local planes [zl0, zl0 + nz)
 static int records_into_bytes(Ctx *ctx, int zl0, int nz) {
-    if (int rc = need_rec(ctx)) return rc;
+    if (int rc = need_rec(ctx, true)) return rc;  // (rec_to_bytes_kernel reads lazy tiles)
     if (!ctx->d_state) ARVX_HIP(hipMalloc(&ctx->d_state, ctx->nvox_ext));
     arvx::CarveParams g;
     carve_geometry(ctx, g);
@@ -714,6 +732,7 @@ int arvx_state_reset(arvx_ctx *ctx) {
     state_changes(ctx, false);
     ctx->fresh_pending = true;  // materialised by need_rec, or never (a carve of a fresh model
     ctx->rec_valid = false;     // writes every record)
+    ctx->lazy = false;
     return ARVX_OK;
 }
 
@@ -780,7 +799,7 @@ int arvx_state_upload_planes(arvx_ctx *ctx, const uint32_t *occ, const uint32_t 
 int arvx_state_download_planes(arvx_ctx *ctx, uint32_t *occ, uint32_t *seen) {
     ARVX_CHECK_CTX(ctx);
     if (!occ || !seen) return fail(ARVX_ERR_INVALID, "null plane");
-    if (int mrc = need_rec(ctx)) return mrc;
+    if (int mrc = need_rec(ctx, true)) return mrc;  // (planes_from_rec_kernel reads lazy tiles)
     const int nz = ctx->z1 - ctx->z0;
     const size_t nwords = (size_t)((ctx->X + 31) / 32) * ctx->Y * nz;
     if (int rc = ensure_scratch(ctx, 2 * nwords * sizeof(uint32_t) + 64)) return rc;
@@ -837,7 +856,7 @@ int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
     if (!dev_words) return fail(ARVX_ERR_INVALID, "null dev_words");
     if (ctx->X % 32 == 0 && (uintptr_t)dev_words % 4 == 0) {
         // straight from the records: 2 bits per voxel in, 1 out
-        if (int mrc = need_rec(ctx)) return mrc;
+        if (int mrc = need_rec(ctx, true)) return mrc;
         arvx::CarveParams g;
         carve_geometry(ctx, g);
         g.rec = ctx->d_rec;
@@ -850,7 +869,7 @@ int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
         return ARVX_OK;
     }
     if (ctx->X % 8 == 0 && ((size_t)ctx->X * ctx->Y) % 32 == 0 && (uintptr_t)dev_words % 4 == 0) {
-        if (int mrc = need_rec(ctx)) return mrc;
+        if (int mrc = need_rec(ctx, true)) return mrc;
         arvx::CarveParams g;
         carve_geometry(ctx, g);
         g.rec = ctx->d_rec;
@@ -889,7 +908,7 @@ int arvx_pack_occupancy_global(arvx_ctx *ctx, void *dev_global_words) {
     const size_t plane = (size_t)ctx->X * ctx->Y;
     if (plane % 64) return fail(ARVX_ERR_INVALID, "X*Y must be a multiple of 64");
     if (ctx->X % 32 == 0) {
-        if (int mrc = need_rec(ctx)) return mrc;
+        if (int mrc = need_rec(ctx, true)) return mrc;
         arvx::CarveParams g;
         carve_geometry(ctx, g);
         g.rec = ctx->d_rec;
@@ -902,7 +921,7 @@ int arvx_pack_occupancy_global(arvx_ctx *ctx, void *dev_global_words) {
         return ARVX_OK;
     }
     if (ctx->X % 8 == 0) {  // (X * Y % 64 == 0 above)
-        if (int mrc = need_rec(ctx)) return mrc;
+        if (int mrc = need_rec(ctx, true)) return mrc;
         arvx::CarveParams g;
         carve_geometry(ctx, g);
         g.rec = ctx->d_rec;
@@ -1026,6 +1045,7 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
     p.v0 = first;
     p.v1 = first + count;
     p.flags = (flags & 3u) | (fresh ? 4u : 0u);
+    p.ccode = nullptr;  // (the carve reads records only where it has written them)
     p.nchunks = (count + 63) / 64;
     if (flags & ARVX_CARVE_STATS) ARVX_HIP(hipMemsetAsync(ctx->d_stats, 0, 64, ctx->stream));
     // rows of tiles (along x) are dealt to the XCDs cyclically: see carve_fused_kernel
@@ -1042,6 +1062,8 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
     }
     const int ncu = ctx->ncu;
     size_t layout_when_done = 0;
+    bool lazy = false;
+    if (rec == ctx->d_rec) ctx->lazy = false;  // (set again below once the launches are out)
     if (cull) {
         const size_t words = ncoarse * p.nchunks;
         // coarse masks | coarse codes | undecided list | two list counters
@@ -1070,6 +1092,18 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         p.coarseMixed = (unsigned long long *)ctx->d_coarse;
         p.coarseFg = p.coarseMixed + words;
         p.coarseCarved = (uint8_t *)(p.coarseFg + words);
+        // Lazy state: a fresh model carved by the split launch into the context's own records
+        // does not write the coarse tiles it settles as a whole -- their code, kept in the
+        // context, is their state (arvx_device.h; need_rec writes them out for the stages that
+        // want records).
+#ifndef ARVX_NO_LAZY  // (A/B builds: always write the decided tiles)
+        lazy = fresh && split && rec == ctx->d_rec;
+#endif
+        if (lazy) {
+            ARVX_HIP(ctx->pool_ccode.reserve(ncoarse + 64));
+            p.coarseCarved = (uint8_t *)ctx->pool_ccode.p;
+            p.flags |= 128u;
+        }
         if (split) {
             int *lst = (int *)((uint8_t *)ctx->d_coarse + off_list);
             // two counters, 64 ints apart, used alternately (carve_coarse_kernel): both zero
@@ -1095,7 +1129,9 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
             p.itemMasks = p.itemInfo + nitems;
             // (carve_coarse_kernel zeroes the `ints` counters at base)
         }
-        if (!split || two_launches) {
+        if (!split || two_launches || lazy) {
+            // (lazy: one WAVE per coarse tile classifies it and lists it if it is undecided;
+            // no workgroup per tile is needed when nothing is filled)
             hipLaunchKernelGGL(arvx::carve_coarse_kernel, dim3((unsigned)((ncoarse + 3) / 4)),
                                dim3(256), 0, ctx->stream, p);
             ARVX_HIP(hipGetLastError());
@@ -1120,7 +1156,9 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
     if (split) {
         // coarse tiles: classified, and the decided ones written as constant records, one
         // workgroup each
-        if (two_launches)
+        if (lazy) {
+            // (carve_coarse_kernel above did everything)
+        } else if (two_launches)
             hipLaunchKernelGGL(arvx::carve_fill_kernel, dim3((unsigned)ncoarse), dim3(256), 0,
                                ctx->stream, p);
         else
@@ -1158,6 +1196,7 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         ARVX_HIP(hipGetLastError());
         ctx->carve_layout = layout_when_done;
         ++ctx->carve_seq;
+        if (lazy) ctx->lazy = true;
         return ARVX_OK;
     }
 #ifdef ARVX_TIMELINE
@@ -2100,6 +2139,7 @@ int arvx_fast_carve(arvx_ctx *ctx) {
     ARVX_HIP(hipGetLastError());
     ctx->fresh_pending = false;  // the records now hold every voxel's state
     ctx->rec_valid = true;
+    ctx->lazy = false;
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
     return ARVX_OK;
 }

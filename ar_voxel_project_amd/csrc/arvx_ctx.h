@@ -64,6 +64,10 @@ struct Ctx {
     uint16_t *d_rec = nullptr;   // records of planes ze0..ze1-1 (+ padding to whole coarse tiles)
     size_t rec_bytes = 0;
     bool rec_valid = false;      // d_rec holds the current state (else: fresh_pending)
+    // lazy state (arvx_device.h): after the carve of a fresh model the coarse tiles it settled
+    // as a whole exist only as their code in `ccode`; their records are not written
+    DevPool pool_ccode;
+    bool lazy = false;
     uint8_t *d_state = nullptr;  // byte staging, planes ze0..ze1-1 (lazy)
     uint8_t *owned() const { return d_state + (size_t)(z0 - ze0) * X * Y; }
     DevPool pool_paint;          // bit plane (bitplane_kernels.h layout) over planes ze0..ze1-1
@@ -151,6 +155,7 @@ struct Ctx {
         pool_mesh_rgb.release();
         pool_xscratch.release();
         pool_paint.release();
+        pool_ccode.release();
         pool_col_bits.release();
         pool_col_rank.release();
         pool_clo_bits.release();

@@ -49,6 +49,9 @@ constexpr int kRecU16 = 128;  // uint16 per record
 
 struct CarveParams {
     uint16_t *rec;          // slab state records (see above)
+    const uint8_t *ccode;   // readers: per coarse tile 0 = its records hold the state, 1..3 = the
+                            // tile is a constant and its records are NOT written (lazy state,
+                            // below); null: every record holds the state
     const float *M;         // V x 12
     const uint32_t *bg;     // V x bgWords, bit = 1 where the mask pixel is background
     const int *sat;         // V x satStride, summed-area table of foreground pixels
@@ -66,7 +69,9 @@ struct CarveParams {
     unsigned flags;         // bit0 no cull, bit1 stats, bit2 state is fresh (skip the load),
                             // bit3 the exact kernel may split items between waves, bit4 fill
                             // as a fresh model, bit5 no block tests, bit6 always two parts
-                            // (5, 6: experiment builds)
+                            // (5, 6: experiment builds), bit7 the decided coarse tiles are
+                            // not written: their code (coarseCarved -> the context's ccode) is
+                            // their state
     int tilesX, tilesY, tilesZ;
     // coarse pre-pass results
     int coarseX, coarseY, coarseZ, nchunks;
@@ -101,6 +106,39 @@ __host__ __device__ __forceinline__ size_t rec_index(const CarveParams &p, int t
 __host__ __device__ __forceinline__ size_t rec_count(const CarveParams &p) {
     return ((size_t)p.coarseX * p.coarseY * p.coarseZ) << (p.cyShift + p.czShift + 2);
 }
+// Lazy state.  A carve of a fresh model settles most coarse tiles (64 x 32 x 32 voxels, 16 KB of
+// records) as a whole: everything carved and seen (code 1), untouched and seen (2), untouched and
+// not even seen (3).  Writing those constants is N / 4 bytes of HBM traffic per carve (the
+// largest single share of the carve at 1024^3) that no later stage needs: the per-coarse-tile
+// code IS the state of such a tile.  The readers that follow a carve directly -- downloads,
+// occupancy packing, the bit planes of the colour pass and the closure -- take the code array
+// and synthesise the constants; every other stage first materialises them (arvx_capi.hip,
+// need_rec).
+__device__ __forceinline__ int coarse_of(const CarveParams &p, int tx, int ty, int tz) {
+    return tx + p.coarseX * ((ty >> p.cyShift) + p.coarseY * (tz >> p.czShift));
+}
+__device__ __forceinline__ int lazy_code(const CarveParams &p, int tx, int ty, int tz) {
+    return p.ccode ? (int)p.ccode[coarse_of(p, tx, ty, tz)] : 0;
+}
+// in-grid voxels of entry r of sub-tile `wave` of tile (tx, ty, tz)
+__device__ __forceinline__ uint32_t row_inmask(const CarveParams &p, int tx, int ty, int tz,
+                                               int wave, int r) {
+    const int x0 = tx * kTileX + wave * kSubX;
+    const int y = ty * kTileY + (r & 7), z = tz * kTileZ + (r >> 3);
+    if (y >= p.Y || z >= p.Z || x0 >= p.X) return 0u;
+    const int nx = min(kSubX, p.X - x0);
+    return 0xffffu >> (kSubX - nx);
+}
+// entry r of a sub-tile of a coarse tile with code 1..3 (voxels outside the grid: occ 0, seen 1)
+__device__ __forceinline__ uint32_t lazy_occ(const CarveParams &p, int code, int tx, int ty, int tz,
+                                             int wave, int r) {
+    return code == 1 ? 0u : row_inmask(p, tx, ty, tz, wave, r);
+}
+__device__ __forceinline__ uint32_t lazy_seen(const CarveParams &p, int code, int tx, int ty,
+                                              int tz, int wave, int r) {
+    return code == 3 ? (~row_inmask(p, tx, ty, tz, wave, r) & 0xffffu) : 0xffffu;
+}
+
 // 4 bits -> bit 0 of 4 bytes, and back
 __device__ __forceinline__ uint32_t nibble_to_bytes(uint32_t nib) {
     return (nib * 0x00204081u) & 0x01010101u;

@@ -192,17 +192,13 @@ __global__ __launch_bounds__(256) void carve_coarse_kernel(const CarveParams p) 
     const int lane = threadIdx.x & 63;
     if (ct >= p.coarseX * p.coarseY * p.coarseZ) return;
     const int code = coarse_classify(p, ct, lane);
-    if (lane == 0) p.coarseCarved[ct] = (uint8_t)code;
-}
-
-// in-grid voxels of entry r of sub-tile `wave` of tile (tx, ty, tz)
-__device__ __forceinline__ uint32_t row_inmask(const CarveParams &p, int tx, int ty, int tz,
-                                               int wave, int r) {
-    const int x0 = tx * kTileX + wave * kSubX;
-    const int y = ty * kTileY + (r & 7), z = tz * kTileZ + (r >> 3);
-    if (y >= p.Y || z >= p.Z || x0 >= p.X) return 0u;
-    const int nx = min(kSubX, p.X - x0);
-    return 0xffffu >> (kSubX - nx);
+    if (lane == 0) {
+        p.coarseCarved[ct] = (uint8_t)code;
+        // lazy state (flags bit7): nothing else happens to a decided tile -- no fill launch
+        // follows --, so the undecided ones go on the classify kernel's list from here
+        if ((p.flags & 128u) && p.undecidedList && !(code == 1 || (code >= 2 && (p.flags & 4u))))
+            p.undecidedList[atomicAdd(p.undecidedCount, 1)] = ct;
+    }
 }
 
 // Coarse tiles that the pre-pass decided are constant: carved + seen (code 1), or, for a
@@ -218,6 +214,7 @@ __device__ __forceinline__ void coarse_fill(const CarveParams &p, const int ct, 
             p.undecidedList[atomicAdd(p.undecidedCount, 1)] = ct;
         return;
     }
+    if (p.flags & 128u) return;  // lazy state: the tile's code says it all (arvx_device.h)
     const int cx = ct % p.coarseX, cy = (ct / p.coarseX) % p.coarseY, cz = ct / (p.coarseX * p.coarseY);
     const int tshift = p.cyShift + p.czShift;
     uint4 *dst = reinterpret_cast<uint4 *>(p.rec + (((size_t)ct << (tshift + 2)) * kRecU16));

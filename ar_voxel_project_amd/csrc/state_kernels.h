@@ -72,7 +72,9 @@ __global__ __launch_bounds__(256) void rec_to_bytes_kernel(const CarveParams p,
     const int x0 = tx * kTileX + wave * kSubX, y = ty * kTileY + (r & 7), z = tz * kTileZ + (r >> 3);
     if (x0 >= p.X || y >= p.Y || z >= p.Z || z < zl0 || z >= zl0 + nz) return;
     const uint16_t *rec = p.rec + rec_index(p, tx, ty, tz, wave) * kRecU16;
-    const uint32_t occ = rec[r], seen = rec[64 + r];
+    const int code = lazy_code(p, tx, ty, tz);
+    const uint32_t occ = code ? lazy_occ(p, code, tx, ty, tz, wave, r) : rec[r];
+    const uint32_t seen = code ? lazy_seen(p, code, tx, ty, tz, wave, r) : rec[64 + r];
     uint32_t pnt = 0;
     if (paint) {
         const int XW = (p.X + 63) >> 6;
@@ -124,7 +126,10 @@ __global__ __launch_bounds__(256) void pack_occupancy_rec_kernel(const CarvePara
     const int z = zl0 + zi;
     const int r = (z & 7) * 8 + (y & 7);
     const uint16_t *rec = p.rec + rec_index(p, k >> 1, y >> 3, z >> 3, (k & 1) * 2) * kRecU16;
-    const uint32_t w = (uint32_t)rec[r] | ((uint32_t)rec[kRecU16 + r] << 16);
+    const int code = lazy_code(p, k >> 1, y >> 3, z >> 3);
+    const uint32_t w = code ? (lazy_occ(p, code, k >> 1, y >> 3, z >> 3, (k & 1) * 2, r) |
+                               (lazy_occ(p, code, k >> 1, y >> 3, z >> 3, (k & 1) * 2 + 1, r) << 16))
+                            : ((uint32_t)rec[r] | ((uint32_t)rec[kRecU16 + r] << 16));
     const size_t zo = global ? (size_t)global_z(p, z) : (size_t)zi;
     out[(zo * p.Y + y) * wpr + k] = w;
 }
@@ -152,7 +157,10 @@ __global__ __launch_bounds__(256) void pack_occupancy_rec8_kernel(const CarvePar
         const int z = zl0 + zi;
         const uint16_t *rec =
             p.rec + rec_index(p, x0 >> 6, y >> 3, z >> 3, (x0 >> 4) & 3) * kRecU16;
-        const uint32_t e = rec[(z & 7) * 8 + (y & 7)];
+        const int code = lazy_code(p, x0 >> 6, y >> 3, z >> 3);
+        const uint32_t e = code ? lazy_occ(p, code, x0 >> 6, y >> 3, z >> 3, (x0 >> 4) & 3,
+                                           (z & 7) * 8 + (y & 7))
+                                : rec[(z & 7) * 8 + (y & 7)];
         word |= ((e >> (x0 & 15)) & 0xffu) << (8 * k);
         if (k == 0) dst = global ? ((size_t)global_z(p, z) * plane_bytes + in_plane) : b;
     }
@@ -180,12 +188,16 @@ __global__ __launch_bounds__(256) void bitgrid_from_rec_kernel(
     const int xw = (int)(i % XW), y = (int)((i / XW) % p.Y), zi = (int)(i / ((size_t)XW * p.Y));
     const int z = zl0 + zi, r = (z & 7) * 8 + (y & 7);
     const uint16_t *rec = p.rec + rec_index(p, xw, y >> 3, z >> 3, 0) * kRecU16;
+    const int code = lazy_code(p, xw, y >> 3, z >> 3);
     unsigned long long o = 0, u = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {  // the tile's four sub-tiles: 16 voxels each
         if (64 * xw + 16 * k >= p.X) break;
-        o |= (unsigned long long)rec[k * kRecU16 + r] << (16 * k);
-        if (apply_unseen) u |= (unsigned long long)(uint16_t)~rec[k * kRecU16 + 64 + r] << (16 * k);
+        const uint32_t eo = code ? lazy_occ(p, code, xw, y >> 3, z >> 3, k, r) : rec[k * kRecU16 + r];
+        const uint32_t es = code ? lazy_seen(p, code, xw, y >> 3, z >> 3, k, r)
+                                 : rec[k * kRecU16 + 64 + r];
+        o |= (unsigned long long)eo << (16 * k);
+        if (apply_unseen) u |= (unsigned long long)(uint16_t)~es << (16 * k);
     }
     if (paint) u |= paint[((size_t)z * p.Y + y) * XW + xw];
     if (closure_occupied) o |= u;
@@ -240,10 +252,14 @@ __global__ __launch_bounds__(256) void planes_from_rec_kernel(const CarveParams 
     const int k = (int)(i % wpr), y = (int)((i / wpr) % p.Y), zi = (int)(i / ((size_t)wpr * p.Y));
     const int z = zl0 + zi, r = (z & 7) * 8 + (y & 7);
     const uint16_t *rec = p.rec + rec_index(p, k >> 1, y >> 3, z >> 3, (k & 1) * 2) * kRecU16;
-    uint32_t o = rec[r], sn = rec[64 + r];
+    const int code = lazy_code(p, k >> 1, y >> 3, z >> 3);
+    const int w0 = (k & 1) * 2;
+    uint32_t o = code ? lazy_occ(p, code, k >> 1, y >> 3, z >> 3, w0, r) : rec[r];
+    uint32_t sn = code ? lazy_seen(p, code, k >> 1, y >> 3, z >> 3, w0, r) : rec[64 + r];
     if (32 * k + 16 < p.X) {  // the word's upper half lies in the next sub-tile
-        o |= (uint32_t)rec[kRecU16 + r] << 16;
-        sn |= (uint32_t)rec[kRecU16 + 64 + r] << 16;
+        o |= (code ? lazy_occ(p, code, k >> 1, y >> 3, z >> 3, w0 + 1, r) : (uint32_t)rec[kRecU16 + r]) << 16;
+        sn |= (code ? lazy_seen(p, code, k >> 1, y >> 3, z >> 3, w0 + 1, r)
+                    : (uint32_t)rec[kRecU16 + 64 + r]) << 16;
     }
     // voxels behind the end of the row: records hold (occ 0, seen 1) there, the planes zeros
     const int nx = p.X - 32 * k;
