@@ -1168,7 +1168,19 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         // the others: a fixed grid walks the list (8 waves per SIMD)
         static const int cgrid_env = experiment_int("ARVX_CLASSIFY_WGS");
         const unsigned cgrid = cgrid_env > 0 ? (unsigned)cgrid_env : (unsigned)ncu * 8u;
-        hipLaunchKernelGGL(arvx::carve_classify_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, p);
+#ifndef ARVX_CLASSIFY_SPARSE  // (A/B builds: the wave-per-sub-tile kernel everywhere)
+        // (the statistics counters live in the other kernel; below 2^26 voxels there are too few
+        // listed coarse tiles for a workgroup each: 256^3 +2.5 % with the dense kernel, 512^3
+        // -1.5 %, 768^3 -5 %, 1024^3 -11 %)
+        const bool dense = !(flags & ARVX_CARVE_STATS) && (size_t)p.X * p.Y * p.Z >= ((size_t)1 << 26);
+#else
+        const bool dense = false;
+#endif
+        if (dense)  // one workgroup per listed coarse tile and turn
+            hipLaunchKernelGGL(arvx::carve_classify_dense_kernel, dim3((unsigned)ncu * 4u), dim3(256),
+                               0, ctx->stream, p);
+        else
+            hipLaunchKernelGGL(arvx::carve_classify_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, p);
         ARVX_HIP(hipGetLastError());
         const unsigned pgrid = (unsigned)(p.nwaves / 4);
 #ifdef ARVX_TIMELINE

@@ -344,6 +344,12 @@ struct WaveTimeline {
 };
 #endif
 
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 struct SubTile {
     int sx0, sy0, sz0, sx1, sy1, sz1;  // voxel box (slab-local z)
     int x, y, zb;                      // this lane's 4 x-voxels, its y, its first z
@@ -753,6 +759,150 @@ __global__ __launch_bounds__(256, 8) void carve_classify_kernel(const CarveParam
     }
 }
 
+// The same job with the lanes packed densely.  In carve_classify_kernel a wave owns ONE sub-tile
+// and its lanes are the views: at most V of 64 lanes exist (36 in the data sets), and of those
+// only the views that are still "mixed" for the coarse tile -- typically a quarter -- run the
+// rectangle test, while the wave pays for all of it.  Here a workgroup owns a listed coarse tile
+// (64 sub-tiles; 32 on striped slabs) -- or, when there are fewer listed tiles than workgroups,
+// a QUARTER of one -- and a lane is a (sub-tile, view slot) pair: a wave takes the coarse tile's
+// mixed views one (or four) at a time, every fourth group, so the rectangle test runs with all
+// lanes busy and a lane's box is formed once per unit.  The lanes OR their answers into LDS;
+// then every wave settles or queues a quarter of the unit's sub-tiles exactly as the kernel
+// above does (one record store per sub-tile).
+__global__ __launch_bounds__(256, 4) void carve_classify_dense_kernel(const CarveParams p) {
+    __shared__ unsigned long long s_mixed[kMaxChunks][64], s_fast[kMaxChunks][64];
+    __shared__ unsigned s_flag[64];  // bit0: some view carves the sub-tile, bit1: some view sees all of it
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tshift = p.cyShift + p.czShift;
+    const int nlisted = __builtin_amdgcn_readfirstlane(*p.undecidedCount);
+    // whole coarse tiles while they fill the grid (1024^3: -10 % on the carve against quarters,
+    // which in turn are what keeps small grids from waiting for a few long workgroups)
+    const int split = nlisted >= (int)gridDim.x ? 0 : 2;  // log2 units per coarse tile
+    const int ushift = tshift + 2 - split;                 // log2 sub-tiles of a unit
+    const int U = 1 << ushift, VS = 64 >> ushift;          // ... and view slots of a wave
+    const int sub = lane & (U - 1), vslot = lane >> ushift;
+    const int nunits = nlisted << split;
+    for (int ui = blockIdx.x; ui < nunits; ui += gridDim.x) {
+        const int ct = __builtin_amdgcn_readfirstlane(p.undecidedList[ui >> split]);
+        const int cx = ct % p.coarseX;
+        const int cty = ((ct / p.coarseX) % p.coarseY) << p.cyShift;
+        const int ctz = (ct / (p.coarseX * p.coarseY)) << p.czShift;
+        const int s0 = (ui & ((1 << split) - 1)) * U;  // the unit's first sub-tile (of the coarse tile's)
+        if (threadIdx.x < 64) {
+#pragma unroll
+            for (int c = 0; c < kMaxChunks; ++c) s_mixed[c][threadIdx.x] = s_fast[c][threadIdx.x] = 0;
+            s_flag[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        // ---- phase 1: lane = (sub-tile, view slot)
+        {
+            const int sidx = s0 + sub, tl = sidx >> 2, sw = sidx & 3;
+            const int ty = cty + (tl & ((1 << p.cyShift) - 1)), tz = ctz + (tl >> p.cyShift);
+            const int sx0 = cx * kTileX + sw * kSubX, sy0 = ty * kTileY, sz0 = tz * kTileZ;
+            const bool in_grid = ty < p.tilesY && tz < p.tilesZ && sx0 < p.X;
+            BoxW box = make_box(p.s, 0, 0, 0, 0, 0, 0);
+            if (in_grid)
+                box = make_box(p.s, sx0, min(sx0 + kSubX - 1, p.X - 1), sy0,
+                               min(sy0 + kTileY - 1, p.Y - 1), global_z(p, sz0),
+                               global_z(p, min(sz0 + kTileZ - 1, p.Z - 1)));
+            unsigned flag = 0;
+            int k = 0;  // running number of the coarse tile's mixed views
+#pragma unroll
+            for (int chunk = 0; chunk < kMaxChunks; ++chunk) {
+                const int vc = p.v0 + 64 * chunk;
+                if (vc >= p.v1) continue;
+                unsigned long long cm = uniform64(p.coarseMixed[(size_t)ct * p.nchunks + chunk]);
+                const unsigned long long cf = uniform64(p.coarseFg[(size_t)ct * p.nchunks + chunk]);
+                if (cf) flag |= 2u;  // inherited: the coarse rectangle contains every sub-tile's
+                unsigned long long mixed = 0, fast = 0;
+                int myb = -1;  // this lane's view of the group being collected
+                while (cm) {
+                    const int b = __ffsll((long long)cm) - 1;
+                    cm &= cm - 1;
+                    const int g = k >> (6 - ushift), slot = k & (VS - 1);
+                    ++k;
+                    const bool ours = (g & 3) == wave;  // wave-uniform
+                    if (ours && slot == vslot) myb = b;
+                    if (!ours || !(slot == VS - 1 || cm == 0)) continue;
+                    // a group is complete (or the chunk ends): one rectangle test for 64 lanes
+                    int cls = kClsOut;
+                    if (myb >= 0 && in_grid) {
+                        const int view = vc + myb;
+                        cls = classify_box(p.M + 12 * view, box, p.W, p.H,
+                                           p.sat + (size_t)view * p.satStride, p.satW);
+                    }
+                    if (myb >= 0) {
+                        if (cls & kFastDiv) fast |= 1ull << myb;
+                        cls &= 3;
+                        if (cls == kClsMixed) mixed |= 1ull << myb;
+                        if (cls == kClsCarved) flag |= 1u;
+                        if (cls == kClsFg) flag |= 2u;
+                    }
+                    myb = -1;
+                }
+                if (mixed) atomicOr(&s_mixed[chunk][sub], mixed);
+                if (fast) atomicOr(&s_fast[chunk][sub], fast);
+            }
+            if (flag) atomicOr(&s_flag[sub], flag);
+        }
+        __syncthreads();
+        // ---- phase 2: a wave per sub-tile, a quarter of the unit's each: settle or queue
+        for (int sl = wave; sl < U; sl += 4) {
+            const int sidx = s0 + sl, tl = sidx >> 2, sw = sidx & 3;
+            const int tx = cx;
+            const int ty = cty + (tl & ((1 << p.cyShift) - 1)), tz = ctz + (tl >> p.cyShift);
+            // (tiles and sub-tiles of an edge coarse tile that lie outside the grid keep the
+            // "finished" records they were allocated with)
+            if (ty >= p.tilesY || tz >= p.tilesZ || tx * kTileX + sw * kSubX >= p.X) continue;
+            unsigned long long mixed_c[kMaxChunks], fast_c[kMaxChunks];
+            bool any_mixed = false;
+#pragma unroll
+            for (int c = 0; c < kMaxChunks; ++c) {
+                mixed_c[c] = fast_c[c] = 0;
+                if (c >= p.nchunks) continue;
+                mixed_c[c] = uniform64(s_mixed[c][sl]);
+                fast_c[c] = uniform64(s_fast[c][sl]);
+                any_mixed = any_mixed || mixed_c[c] != 0;
+            }
+            const unsigned flag = __builtin_amdgcn_readfirstlane(s_flag[sl]);
+            const bool any_carved = flag & 1u, any_fg = flag & 2u;
+            uint16_t *const rec = p.rec + rec_index(p, tx, ty, tz, sw) * kRecU16;
+            const bool fresh = p.flags & 4u;
+            if (any_carved) {  // carved implies seen (src/VoxelCarving.cpp:50-54): no load needed
+                subtile_store_done(rec, lane);
+            } else if (!any_mixed) {
+                if (fresh)
+                    subtile_store_const(p, rec, lane, tx, ty, tz, sw, true, any_fg);
+                else if (any_fg && lane >= 32)
+                    reinterpret_cast<uint32_t *>(rec)[lane] = 0xffffffffu;  // the seen half
+            } else if ((p.flags & 12u) == 12u) {
+                subtile_store_const(p, rec, lane, tx, ty, tz, sw, true, false);
+            }
+            if (!any_carved && any_mixed && lane == 0) {  // hand it to the exact kernel (see above)
+                int nmixed = 0;
+#pragma unroll
+                for (int c = 0; c < kMaxChunks; ++c)
+                    if (c < p.nchunks) nmixed += __popcll(mixed_c[c]);
+                const int wclass = 7 - min(7, nmixed * 8 / (p.v1 - p.v0 + 1));
+                const int cls =
+                    wclass * 8 + (((((tz * p.tilesY + ty) * p.tilesX + tx) << 2) + sw) & 7);
+                const int pos = atomicAdd(&p.workCount[cls * kCounterStride], 1);
+                const size_t it = (size_t)cls * p.workCap + pos;
+                p.itemInfo[it] = (unsigned long long)tx | ((unsigned long long)ty << 16) |
+                                 ((unsigned long long)tz << 32) | ((unsigned long long)sw << 48) |
+                                 ((unsigned long long)(any_fg ? 1 : 0) << 50);
+#pragma unroll
+                for (int c = 0; c < kMaxChunks; ++c)
+                    if (c < p.nchunks) {
+                        p.itemMasks[(it * p.nchunks + c) * 2] = mixed_c[c];
+                        p.itemMasks[(it * p.nchunks + c) * 2 + 1] = fast_c[c];
+                    }
+            }
+        }
+        __syncthreads();  // (the next unit reuses the LDS arrays)
+    }
+}
+
 // One view applied exactly to the 16 voxels of every lane.  Returns true when all
 // 1024 voxels of the sub-tile are carved and seen.
 template <bool LEFT>
@@ -1015,12 +1165,6 @@ __device__ __forceinline__ uint32_t spread4(uint32_t t) {
 }
 __device__ __forceinline__ uint32_t gather4(uint32_t b) {
     return (b & 1u) | ((b >> 4) & 0x10u) | ((b >> 8) & 0x100u) | ((b >> 12) & 0x1000u);
-}
-
-__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
 }
 
 __device__ __forceinline__ void wave_lds_sync() {
