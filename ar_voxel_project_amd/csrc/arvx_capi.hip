@@ -1132,8 +1132,11 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         if (!split || two_launches || lazy) {
             // (lazy: one WAVE per coarse tile classifies it and lists it if it is undecided;
             // no workgroup per tile is needed when nothing is filled)
-            hipLaunchKernelGGL(arvx::carve_coarse_kernel, dim3((unsigned)((ncoarse + 3) / 4)),
-                               dim3(256), 0, ctx->stream, p);
+            // (16 tiles per workgroup where that still leaves a workgroup per compute unit:
+            // fewer appends to the list's counter; 4 on small grids)
+            const int cw = ncoarse >= (size_t)16 * ncu ? arvx::kCoarseWaves : 4;
+            hipLaunchKernelGGL(arvx::carve_coarse_kernel, dim3((unsigned)((ncoarse + cw - 1) / cw)),
+                               dim3(64 * cw), 0, ctx->stream, p);
             ARVX_HIP(hipGetLastError());
         }
     }

@@ -142,7 +142,7 @@ __device__ __forceinline__ void coarse_reset_counters(const CarveParams &p) {
     // the work-list and pool counters of the kernels that follow start at zero (this
     // saves a memset launch in front of every carve)
     if (blockIdx.x == 0 && p.workCount)
-        for (int i = threadIdx.x; i < (kWorkLists + kPoolCounters) * kCounterStride; i += 256)
+        for (int i = threadIdx.x; i < (kWorkLists + kPoolCounters) * kCounterStride; i += blockDim.x)
             p.workCount[i] = 0;  // poolNext follows workCount in the same allocation
     // the length of the undecided list alternates between two counters: this launch appends
     // to one (zeroed by the launch before) and zeroes the other for the next carve
@@ -186,18 +186,35 @@ __device__ __forceinline__ int coarse_classify(const CarveParams &p, const int c
     return any_carved ? 1 : (any_mixed ? 0 : (any_fg ? 2 : 3));
 }
 
-__global__ __launch_bounds__(256) void carve_coarse_kernel(const CarveParams p) {
+// Up to kCoarseWaves coarse tiles per workgroup (blockDim.x / 64), one wave each.  Lazy state (flags bit7): nothing
+// else happens to a decided tile -- no fill launch follows --, so the undecided ones go on the
+// classify kernels' list from here: collected in LDS, ONE append per workgroup (an append per
+// tile, ~450 at 512^3 on one counter, was 5 of this kernel's 11 us).
+constexpr int kCoarseWaves = 16;
+__global__ __launch_bounds__(64 * kCoarseWaves) void carve_coarse_kernel(const CarveParams p) {
+    __shared__ int s_ct[kCoarseWaves];
+    __shared__ int s_n, s_base;
     coarse_reset_counters(p);
-    const int ct = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ct = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (ct >= p.coarseX * p.coarseY * p.coarseZ) return;
-    const int code = coarse_classify(p, ct, lane);
-    if (lane == 0) {
-        p.coarseCarved[ct] = (uint8_t)code;
-        // lazy state (flags bit7): nothing else happens to a decided tile -- no fill launch
-        // follows --, so the undecided ones go on the classify kernel's list from here
-        if ((p.flags & 128u) && p.undecidedList && !(code == 1 || (code >= 2 && (p.flags & 4u))))
-            p.undecidedList[atomicAdd(p.undecidedCount, 1)] = ct;
+    const bool listing = (p.flags & 128u) && p.undecidedList;  // workgroup-uniform
+    if (listing) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+    }
+    if (ct < p.coarseX * p.coarseY * p.coarseZ) {
+        const int code = coarse_classify(p, ct, lane);
+        if (lane == 0) {
+            p.coarseCarved[ct] = (uint8_t)code;
+            if (listing && !(code == 1 || (code >= 2 && (p.flags & 4u))))
+                s_ct[atomicAdd(&s_n, 1)] = ct;
+        }
+    }
+    if (listing) {
+        __syncthreads();
+        if (threadIdx.x == 0 && s_n) s_base = atomicAdd(p.undecidedCount, s_n);
+        __syncthreads();
+        if ((int)threadIdx.x < s_n) p.undecidedList[s_base + threadIdx.x] = s_ct[threadIdx.x];
     }
 }
 
