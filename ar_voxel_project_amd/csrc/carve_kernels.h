@@ -863,7 +863,8 @@ __global__ __launch_bounds__(256, 4) void carve_classify_dense_kernel(const Carv
             if (flag) atomicOr(&s_flag[sub], flag);
         }
         __syncthreads();
-        // ---- phase 2: a wave per sub-tile, a quarter of the unit's each: settle or queue
+        // ---- phase 2: a wave per sub-tile, a quarter of the unit's each: settle (one record
+        // store, nothing to wait for) ...
         for (int sl = wave; sl < U; sl += 4) {
             const int sidx = s0 + sl, tl = sidx >> 2, sw = sidx & 3;
             const int tx = cx;
@@ -871,16 +872,10 @@ __global__ __launch_bounds__(256, 4) void carve_classify_dense_kernel(const Carv
             // (tiles and sub-tiles of an edge coarse tile that lie outside the grid keep the
             // "finished" records they were allocated with)
             if (ty >= p.tilesY || tz >= p.tilesZ || tx * kTileX + sw * kSubX >= p.X) continue;
-            unsigned long long mixed_c[kMaxChunks], fast_c[kMaxChunks];
             bool any_mixed = false;
 #pragma unroll
-            for (int c = 0; c < kMaxChunks; ++c) {
-                mixed_c[c] = fast_c[c] = 0;
-                if (c >= p.nchunks) continue;
-                mixed_c[c] = uniform64(s_mixed[c][sl]);
-                fast_c[c] = uniform64(s_fast[c][sl]);
-                any_mixed = any_mixed || mixed_c[c] != 0;
-            }
+            for (int c = 0; c < kMaxChunks; ++c)
+                if (c < p.nchunks) any_mixed = any_mixed || uniform64(s_mixed[c][sl]) != 0;
             const unsigned flag = __builtin_amdgcn_readfirstlane(s_flag[sl]);
             const bool any_carved = flag & 1u, any_fg = flag & 2u;
             uint16_t *const rec = p.rec + rec_index(p, tx, ty, tz, sw) * kRecU16;
@@ -895,11 +890,27 @@ __global__ __launch_bounds__(256, 4) void carve_classify_dense_kernel(const Carv
             } else if ((p.flags & 12u) == 12u) {
                 subtile_store_const(p, rec, lane, tx, ty, tz, sw, true, false);
             }
-            if (!any_carved && any_mixed && lane == 0) {  // hand it to the exact kernel (see above)
-                int nmixed = 0;
+        }
+        // ... and queue: lane = sub-tile, so that the unit's appends to the work lists (an atomic
+        // whose answer the item's place depends on) are in flight together instead of one
+        // round trip per sub-tile
+        if (wave == 0 && lane < U) {
+            const int sl = lane, sidx = s0 + sl, tl = sidx >> 2, sw = sidx & 3;
+            const int tx = cx;
+            const int ty = cty + (tl & ((1 << p.cyShift) - 1)), tz = ctz + (tl >> p.cyShift);
+            const unsigned flag = s_flag[sl];
+            unsigned long long mixed_c[kMaxChunks], fast_c[kMaxChunks];
+            int nmixed = 0;
 #pragma unroll
-                for (int c = 0; c < kMaxChunks; ++c)
-                    if (c < p.nchunks) nmixed += __popcll(mixed_c[c]);
+            for (int c = 0; c < kMaxChunks; ++c) {
+                mixed_c[c] = fast_c[c] = 0;
+                if (c >= p.nchunks) continue;
+                mixed_c[c] = s_mixed[c][sl];
+                fast_c[c] = s_fast[c][sl];
+                nmixed += __popcll(mixed_c[c]);
+            }
+            const bool in_grid = ty < p.tilesY && tz < p.tilesZ && tx * kTileX + sw * kSubX < p.X;
+            if (in_grid && !(flag & 1u) && nmixed) {  // hand it to the exact kernel (see above)
                 const int wclass = 7 - min(7, nmixed * 8 / (p.v1 - p.v0 + 1));
                 const int cls =
                     wclass * 8 + (((((tz * p.tilesY + ty) * p.tilesX + tx) << 2) + sw) & 7);
@@ -907,7 +918,7 @@ __global__ __launch_bounds__(256, 4) void carve_classify_dense_kernel(const Carv
                 const size_t it = (size_t)cls * p.workCap + pos;
                 p.itemInfo[it] = (unsigned long long)tx | ((unsigned long long)ty << 16) |
                                  ((unsigned long long)tz << 32) | ((unsigned long long)sw << 48) |
-                                 ((unsigned long long)(any_fg ? 1 : 0) << 50);
+                                 ((unsigned long long)((flag & 2u) ? 1 : 0) << 50);
 #pragma unroll
                 for (int c = 0; c < kMaxChunks; ++c)
                     if (c < p.nchunks) {

@@ -120,6 +120,10 @@ int arvx_ctx_create_slab_halo(arvx_ctx **out, int device, int X, int Y, int Z,
  * arvx_fast_carve need neighbouring planes and take contiguous slabs only. */
 int arvx_ctx_create_striped(arvx_ctx **out, int device, int X, int Y, int Z,
                             float voxel_size, int world, int rank);
+/* (The HIP stream a destroyed context owned is kept in a per-device pool and handed to the next
+ * context: creating and destroying a stream costs milliseconds on this stack.  A caller that
+ * resets the device (hipDeviceReset) between contexts must not have any context alive across
+ * the reset -- the pooled streams die with the device and the library does not notice.) */
 int arvx_ctx_destroy(arvx_ctx *ctx);
 /* Launch on a caller-owned hipStream_t (borrowed); NULL = context's own. */
 int arvx_ctx_set_stream(arvx_ctx *ctx, void *hip_stream);
