@@ -415,14 +415,14 @@ static int views_common(Ctx *ctx, int V, const float *M, const float *campos, in
     ctx->bgWords = (int)(((size_t)W * H + 31) / 32) + 1;
     // summed-area table (views_kernels.h): (H + 1) rows of W + 1 entries, the rows padded to
     // whole 128-byte lines so that the table kernel's stores are line-aligned
-    ctx->satW = (W + 1 + 31) / 32 * 32;
+    ctx->satW = (W + 1 + 63) / 64 * 64;  // (two-byte entries: 64 per 128-byte line)
     ctx->satH = H + 1;
     ctx->satStride = ctx->satW * ctx->satH;
     if (!same) {
         hipError_t e = hipMalloc(&ctx->d_M, (size_t)V * 12 * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(&ctx->d_campos, (size_t)V * 3 * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(&ctx->d_bg, (size_t)V * ctx->bgWords * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(&ctx->d_sat, (size_t)V * ctx->satStride * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc(&ctx->d_sat, (size_t)V * ctx->satStride * sizeof(uint16_t));
         if (e != hipSuccess) {
             ctx->free_views();  // whatever was allocated before the failure
             return arvx::fail_hip(e, "hipMalloc(views)", __FILE__, __LINE__);

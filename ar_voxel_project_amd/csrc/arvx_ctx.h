@@ -102,7 +102,7 @@ struct Ctx {
     float *d_M = nullptr;
     float *d_campos = nullptr;
     uint32_t *d_bg = nullptr;
-    int *d_sat = nullptr;
+    uint16_t *d_sat = nullptr;
     std::vector<float> h_M, h_campos;
 
     // colour pass

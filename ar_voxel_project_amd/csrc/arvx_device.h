@@ -54,7 +54,7 @@ struct CarveParams {
                             // below); null: every record holds the state
     const float *M;         // V x 12
     const uint32_t *bg;     // V x bgWords, bit = 1 where the mask pixel is background
-    const int *sat;         // V x satStride, summed-area table of foreground pixels
+    const uint16_t *sat;    // V x satStride, summed-area table of foreground pixels (mod 2^16)
     unsigned long long *stats;
     unsigned long long *timeline;  // diagnostic builds only (ARVX_TIMELINE), else null
     int X, Y, Z;            // slab extent in voxels (Z = planes held)

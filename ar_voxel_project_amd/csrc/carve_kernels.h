@@ -66,9 +66,14 @@ __device__ __forceinline__ BoxW make_box(float s, int x0, int x1, int y0, int y1
 // and of the bound arithmetic below (<2u|u|): 2^-20|u| = 16u|u| and an absolute
 // 2^-12 cover them.  roundf(t) lies in [t-0.5, t+0.5].
 // sat: the view's summed-area table of foreground pixels, satW entries per row
-// (views_kernels.h): entry (Y, X) = foreground pixels in rows < Y, columns < X.
+// (views_kernels.h): entry (Y, X) = foreground pixels in rows < Y, columns < X -- MODULO 2^16:
+// the count of a rectangle comes out of the four corners exactly whenever the rectangle has
+// fewer than 2^16 pixels, which is every rectangle that matters (a sub-tile's is a few hundred
+// pixels); a larger one is called "mixed" without looking (conservative: the next level of
+// tests, on smaller boxes, decides).  Half the bytes to derive per step and to keep in the caches.
+typedef uint16_t sat_t;
 __device__ inline int classify_box(const float *__restrict__ M, const BoxW b, int W, int H,
-                                   const int *__restrict__ sat, int satW) {
+                                   const sat_t *__restrict__ sat, int satW) {
     const float dy = b.wy1 - b.wy0, dx = b.wx1 - b.wx0, dz = b.wz1 - b.wz0;
     const float ay = fmaxf(fabsf(b.wy0), fabsf(b.wy1));
     const float ax = fmaxf(fabsf(b.wx0), fabsf(b.wx1));
@@ -126,10 +131,12 @@ __device__ inline int classify_box(const float *__restrict__ M, const BoxW b, in
     if (pxlo < 0 || pxhi >= W || pylo < 0 || pyhi >= H) return kClsMixed | fast;
     const int X0 = pxlo, X1 = pxhi + 1;
     const int Y0 = pylo, Y1 = pyhi + 1;
-    const int cnt = sat[Y1 * satW + X1] - sat[Y0 * satW + X1] - sat[Y1 * satW + X0] +
-                    sat[Y0 * satW + X0];
+    const int area = (X1 - X0) * (Y1 - Y0);
+    if (area >= 65536) return kClsMixed | fast;  // (the table's entries are counts modulo 2^16)
+    const int cnt = ((int)sat[Y1 * satW + X1] - (int)sat[Y0 * satW + X1] - (int)sat[Y1 * satW + X0] +
+                     (int)sat[Y0 * satW + X0]) & 0xffff;
     if (cnt == 0) return kClsCarved;  // no foreground in the rectangle
-    return (cnt == (X1 - X0) * (Y1 - Y0)) ? kClsFg : (kClsMixed | fast);
+    return (cnt == area) ? kClsFg : (kClsMixed | fast);
 }
 
 // Pre-pass over coarse tiles of 64 x 32 x 32 voxels (64 sub-tiles each; striped

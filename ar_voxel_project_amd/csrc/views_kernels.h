@@ -112,8 +112,9 @@ __global__ __launch_bounds__(256) void views_bits_generic_kernel(const uint8_t *
 
 // ---- summed-area table, in one pass over the output ------------------------------------------
 //
-// table[Y][X] = foreground pixels in rows < Y, columns < X, for Y <= H, X <= W; ld (>= W + 1,
-// a multiple of 32) entries per row, so that every row starts on a 128-byte line.  The table is
+// table[Y][X] = foreground pixels in rows < Y, columns < X, for Y <= H, X <= W, stored modulo
+// 2^16 (two bytes per entry: see classify_box); ld (>= W + 1, a multiple of 64) entries per row,
+// so that every row starts on a 128-byte line.  The table is
 // cut into tiles of 64 COLUMNS OF THE TABLE x 64 image rows: tile (I, J) holds the entries
 // X = 64 J + lane of the rows Y = 64 I + r + 1 -- whole lines -- and entry X counts the pixel
 // columns up to x = X - 1: the tile's "columns" c = 0..63 are the pixel columns 64 J - 1 + c
@@ -198,11 +199,11 @@ __global__ __launch_bounds__(64) void views_table_kernel(const uint32_t *__restr
                                                          const int *__restrict__ rowsum,
                                                          const int *__restrict__ T,
                                                          const int *__restrict__ tilesum,
-                                                         int *__restrict__ sat, int satStride,
+                                                         uint16_t *__restrict__ sat, int satStride,
                                                          int ld) {
     const int J = blockIdx.x, I = blockIdx.y, v = blockIdx.z, lane = threadIdx.x;
     const uint32_t *bits = bg + (size_t)v * bgWords;
-    int *tab = sat + (size_t)v * satStride;
+    uint16_t *tab = sat + (size_t)v * satStride;  // entries modulo 2^16 (carve_kernels.h, classify_box)
     const int X = 64 * J + lane, yr = I * kTileRows + lane;  // X: this lane's table column
     const unsigned long long mine = tile_row_fg(bits, bgWords, W, H, yr, J);  // row `lane`
     // Lin: running sum over this tile's rows of the row sums of the tile columns to the left
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(64) void views_table_kernel(const uint32_t *__restr
                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)fg, 0u));
         acc += below + (int)((fg >> lane) & 1ull);
         const int lin = __builtin_amdgcn_readlane(left, r);
-        if (X <= W) tab[(size_t)(I * kTileRows + r + 1) * ld + X] = acc + lin;
+        if (X <= W) tab[(size_t)(I * kTileRows + r + 1) * ld + X] = (uint16_t)(acc + lin);
     }
 }
 
