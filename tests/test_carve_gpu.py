@@ -675,3 +675,52 @@ def _device_bytes(ptr, n):
     rc = hip.hipMemcpy(out.ctypes.data, ctypes.c_void_p(ptr), n, 2)  # hipMemcpyDeviceToHost
     assert rc == 0, rc
     return out
+
+
+@pytest.mark.parametrize("dims,kw", [((128, 96, 72), {}), ((72, 64, 80), {}),
+                                     ((128, 128, 128), {"z_range": (40, 104)}),
+                                     ((64, 64, 128), {"stripes": (2, 1)})])
+def test_lazy_state_readers_agree_with_the_written_records(arvx, oracle, dims, kw):
+    """After the carve of a fresh model the coarse tiles it settled as a whole exist only as
+    their code (csrc/arvx_device.h, lazy state).  Every reader that takes the codes -- byte
+    download, bit-plane download, occupancy packing (both row widths), the colour pass's surface
+    -- must say what the same state says once it has been written out (arvx_export_model forces
+    that), and what the oracle says."""
+    import torch
+    X, Y, Z = dims
+    sc = scenes.syn.sphere_scene(max(dims), 6, W=320, H=240, with_images=True)
+    with arvx.Context(X, Y, Z, sc.voxel_size, **kw) as ctx:
+        want = oracle.carve_planes(X, Y, sc.voxel_size, sc.M, sc.masks, ctx.planes)
+        ctx.set_views(sc.M, sc.masks, campos=sc.campos)
+        ctx.carve()
+        lazy = dict(state=ctx.download_state(), planes=ctx.download_planes())
+        nw = (X * Y * len(ctx.planes) + 31) // 32
+        words = torch.zeros(nw, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.pack_occupancy(words.data_ptr())
+        ctx.synchronize()
+        lazy["packed"] = words.cpu().numpy().copy()
+        if "stripes" not in kw:
+            ctx.set_images(sc.images)
+            ctx.color(arvx.COLOR_AVERAGE)
+            lazy["surface"] = ctx.surface()
+        ctx.export_model(False)  # a stage that wants records: the lazy tiles are written out
+        full = dict(state=ctx.download_state(), planes=ctx.download_planes())
+        words.zero_()
+        torch.cuda.synchronize()
+        ctx.pack_occupancy(words.data_ptr())
+        ctx.synchronize()
+        full["packed"] = words.cpu().numpy().copy()
+        if "stripes" not in kw:
+            ctx.color(arvx.COLOR_AVERAGE)
+            full["surface"] = ctx.surface()
+    assert_same(lazy["state"], want, "lazy download vs oracle")
+    assert_same(full["state"], want, "written-out download vs oracle")
+    for k in ("planes", "surface"):
+        if k in lazy:
+            assert all(np.array_equal(a, b) for a, b in zip(lazy[k], full[k])), k
+    assert np.array_equal(lazy["packed"], full["packed"])
+    bits = np.packbits((want.reshape(-1) & 1).astype(np.uint8), bitorder="little")
+    got = lazy["packed"].view(np.uint8)[:len(bits)]
+    assert np.array_equal(got, bits)
+    assert 0.0 < (want & 1).mean() < 1.0 and (want == 2).mean() > 0.3  # big carved regions: lazy tiles
