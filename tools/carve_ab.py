@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Carve time of the current library per grid and row-sum grouping, and the same for other builds
-on the same box, interleaved: python tools/carve_ab.py "512 1024" [libA.so libB.so ...]
+on the same box, interleaved: python tools/carve_ab.py "512 1024" [libA.so libB.so+VAR=1 ...]
+(`+VAR=value` after a library sets that environment variable for its runs: the switches of an
+-DARVX_EXPERIMENTS build)
 (GPU required; A/B within one process run, device-to-device spread is ~10 %)."""
 import os
 import subprocess
@@ -71,8 +73,12 @@ def main():
     for rnd in range(2):
         for lib in libs:
             env = dict(os.environ)
-            if lib:
-                env["ARVX_LIB_PATH"] = os.path.abspath(lib)
+            path, *sets = lib.split("+")
+            if path:
+                env["ARVX_LIB_PATH"] = os.path.abspath(path)
+            for kv in sets:
+                k, _, v = kv.partition("=")
+                env[k] = v
             print(f"== {lib or 'current build'} (round {rnd})", flush=True)
             subprocess.run([sys.executable, __file__, "--child", grids], env=env)
 
