@@ -29,7 +29,7 @@ SYMBOLS = [
     "arvx_version", "arvx_last_error", "arvx_device_count", "arvx_projection_assoc",
     "arvx_ctx_create_slab_halo",
     "arvx_set_projection_assoc", "arvx_ctx_set_projection_assoc", "arvx_ctx_projection_assoc",
-    "arvx_selftest_project", "arvx_selftest_depth",
+    "arvx_selftest_project", "arvx_selftest_depth", "arvx_selftest_view_tables",
     "arvx_ctx_create", "arvx_ctx_create_slab", "arvx_ctx_create_striped", "arvx_ctx_destroy",
     "arvx_ctx_set_stream", "arvx_ctx_set_exchange_stream", "arvx_ctx_synchronize", "arvx_ctx_voxels",
     "arvx_compose_projection", "arvx_set_views", "arvx_set_views_device",
@@ -263,6 +263,20 @@ class Context:
         self._ck(self._lib.arvx_selftest_project(self._h, n, M.ctypes.data, C.c_float(voxel_size),
                                                  xyz.ctypes.data, out.ctypes.data))
         return out[:3 * n].reshape(n, 3), out[3 * n:].reshape(n, 2)
+
+    def selftest_view_tables(self, view: int, W: int, H: int):
+        """(background bit plane as a (H, W) bool array, summed-area table as (H + 1, W + 1)
+        uint16) of one view, as derived by set_views (include/arvx/arvx.h)."""
+        self._lib.arvx_selftest_view_tables.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                        C.POINTER(C.c_int)]
+        ld = C.c_int()
+        self._ck(self._lib.arvx_selftest_view_tables(self._h, view, None, None, C.byref(ld)))
+        bits = np.zeros((W * H + 31) // 32, np.uint32)
+        table = np.zeros((H + 1, ld.value), np.uint16)
+        self._ck(self._lib.arvx_selftest_view_tables(self._h, view, bits.ctypes.data, table.ctypes.data,
+                                                     C.byref(ld)))
+        bg = np.unpackbits(bits.view(np.uint8), bitorder="little")[:W * H].reshape(H, W).astype(bool)
+        return bg, table[:, :W + 1].copy()
 
     def selftest_depth(self, campos, voxel_size, xyz):
         xyz = np.ascontiguousarray(xyz, np.int32).reshape(-1, 3)

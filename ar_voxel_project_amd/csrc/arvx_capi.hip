@@ -480,10 +480,11 @@ static int views_preprocess(Ctx *ctx, const uint8_t *d_masks, int C) {
     const size_t n_rs = (size_t)V * H * TJ, n_T = (size_t)V * TI * TJ * 64, n_ts = (size_t)V * TI * TJ;
     if (int rc = ensure_scratch(ctx, (n_rs + n_T + n_ts) * sizeof(int) + 64)) return rc;
     int *d_rs = (int *)ctx->d_scratch, *d_T = d_rs + n_rs, *d_ts = d_T + n_T;
-    hipLaunchKernelGGL(arvx::views_tile_sums_kernel, dim3(TJ, TI, V), dim3(64), 0, ctx->stream,
-                       ctx->d_bg, ctx->bgWords, W, H, TJ, TI, d_rs, d_T, d_ts);
-    hipLaunchKernelGGL(arvx::views_table_kernel, dim3(TJ, TI, V), dim3(64), 0, ctx->stream,
-                       ctx->d_bg, ctx->bgWords, W, H, TJ, TI, d_rs, d_T, d_ts, ctx->d_sat,
+    const unsigned tgrid = (unsigned)(((size_t)TJ * TI * V + 3) / 4);
+    hipLaunchKernelGGL(arvx::views_tile_sums_kernel, dim3(tgrid), dim3(256), 0, ctx->stream,
+                       ctx->d_bg, ctx->bgWords, W, H, TJ, TI, V, d_rs, d_T, d_ts);
+    hipLaunchKernelGGL(arvx::views_table_kernel, dim3(tgrid), dim3(256), 0, ctx->stream,
+                       ctx->d_bg, ctx->bgWords, W, H, TJ, TI, V, d_rs, d_T, d_ts, ctx->d_sat,
                        ctx->satStride, ctx->satW);
     ARVX_HIP(hipGetLastError());
     ctx->views_ready = true;
@@ -1598,6 +1599,24 @@ int arvx_selftest_depth(arvx_ctx *ctx, int64_t n, const float campos[3], float v
         hipLaunchKernelGGL(arvx::selftest_depth_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256),
                            0, ctx->stream, m, voxel_size, d_xyz, (long long)n, d_out);
     });
+}
+
+int arvx_selftest_view_tables(arvx_ctx *ctx, int view, uint32_t *bg_bits, uint16_t *table, int *ld) {
+    ARVX_CHECK_CTX(ctx);
+    if (!ctx->views_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
+    if (view < 0 || view >= ctx->V) return fail(ARVX_ERR_INVALID, "view %d outside [0,%d)", view, ctx->V);
+    if (!ld) return fail(ARVX_ERR_INVALID, "null ld");
+    *ld = ctx->satW;
+    const size_t words = ((size_t)ctx->W * ctx->H + 31) / 32;
+    if (bg_bits)
+        ARVX_HIP(hipMemcpyAsync(bg_bits, ctx->d_bg + (size_t)view * ctx->bgWords, words * sizeof(uint32_t),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    if (table)
+        ARVX_HIP(hipMemcpyAsync(table, ctx->d_sat + (size_t)view * ctx->satStride,
+                                (size_t)ctx->satStride * sizeof(uint16_t), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    return ARVX_OK;
 }
 
 int arvx_selftest_round(arvx_ctx *ctx, int64_t *mismatches) {

@@ -113,26 +113,29 @@ __global__ __launch_bounds__(256) void views_bits_generic_kernel(const uint8_t *
 // ---- summed-area table, in one pass over the output ------------------------------------------
 //
 // table[Y][X] = foreground pixels in rows < Y, columns < X, for Y <= H, X <= W, stored modulo
-// 2^16 (two bytes per entry: see classify_box); ld (>= W + 1, a multiple of 64) entries per row,
-// so that every row starts on a 128-byte line.  The table is
-// cut into tiles of 64 COLUMNS OF THE TABLE x 64 image rows: tile (I, J) holds the entries
-// X = 64 J + lane of the rows Y = 64 I + r + 1 -- whole lines -- and entry X counts the pixel
-// columns up to x = X - 1: the tile's "columns" c = 0..63 are the pixel columns 64 J - 1 + c
-// (column -1 does not exist: no foreground).  With fgc(y, c) = foreground of pixel row y in
-// the tile's column c:
+// 2^16 (two bytes per entry: see classify_box); ld = 64 * ceil((W + 1) / 64) entries per row, so
+// that every row starts on a 128-byte line.  The table is cut into tiles of 64 columns x 64 image
+// rows: tile (I, J) holds the entries X = 64 J + c, c = lane, of the rows Y = 64 I + r + 1 --
+// whole lines -- and covers the pixel columns 64 J .. 64 J + 63 (for 640-pixel rows a row of the
+// tile is two aligned words of the bit plane).  With fg(y, c) = foreground of pixel (64 J + c, y):
 //   table[y + 1][64 J + c] = LT(I, J) + Lin(y, J) + A(I, J, c) + sum over the tile's rows
-//                            y' <= y of inrow(y', c)
-//   inrow(y', c) = fg of row y' in the tile's columns <= c          (popcount up to the lane)
+//                            y' <= y of below(y', c)
+//   below(y', c) = fg of row y' in the tile's columns < c           (v_mbcnt: bits below the lane)
 //   Lin(y, J)    = fg of the tile's rows <= y in the tile columns left of J
 //   LT(I, J)     = fg above tile row I and left of tile column J
-//   A(I, J, c)   = fg of the rows above tile row I in the tile's columns <= c
+//   A(I, J, c)   = fg of the rows above tile row I in the tile's columns < c
 // views_tile_sums_kernel takes three small arrays from the bit plane (per row and tile column
-// the row's count, per tile row and tile column c the running count along c, per tile its
-// total); views_table_kernel sums what it needs of them (a few independent loads per lane) and
-// writes the table: per row two scalar reads of the row's bits, a popcount, two adds and the
-// store.  The table's bytes are written once and never read back.  In both kernels lane r
-// first LOADS row r's 64 bits (one round trip for the whole tile) and the rows are then taken
-// from the lanes one by one.
+// the row's count, per tile row and tile column the running count along c, per tile its total);
+// views_table_kernel sums what it needs of them (a few independent loads per lane) and writes the
+// table: per row three lane reads (the row's bits, its count to the left), the two halves of
+// v_mbcnt adding onto the running value, one add and the store -- six vector instructions for 64
+// entries.  The table's bytes are written once and never read back; the lanes of the last tile
+// column beyond X = W write into the row's padding (ld = 64 TJ), so that no store is predicated.
+// In both kernels lane r first LOADS row r's 64 bits (one round trip for the whole tile) and the
+// rows are then taken from the lanes one by one.  Four tiles per workgroup, one per wave.
+// (Round 3, measured with tools/vt_probe.sh: the tile's columns used to be shifted by one pixel
+// (inclusive counts: a 64-bit shift and a mask per row on top, the row loop was 13 instructions
+// and bound by their issue at three waves per SIMD).)
 #ifndef ARVX_TILE_ROWS
 #define ARVX_TILE_ROWS 64
 #endif
@@ -146,67 +149,83 @@ __device__ __forceinline__ unsigned long long row_fg64(const uint32_t *__restric
     const long long pos = (long long)y * W + x0;
     const int w = (int)(pos >> 5), sh = (int)(pos & 31);
     const int last = bgWords - 1;  // the always-zero word
-    const unsigned long long lo = bits[min(w, last)], mid = bits[min(w + 1, last)],
-                             hi = bits[min(w + 2, last)];
-    unsigned long long bg = ((lo | (mid << 32)) >> sh);
-    if (sh) bg |= hi << (64 - sh);
     const int n = min(64, W - x0);  // valid columns
     const unsigned long long valid = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    const unsigned long long lo = bits[min(w, last)], mid = bits[min(w + 1, last)];
+    unsigned long long bg = lo | (mid << 32);
+    if (sh) {  // (wave-uniform whenever W is a multiple of 32)
+        const unsigned long long hi = bits[min(w + 2, last)];
+        bg = (bg >> sh) | (hi << (64 - sh));
+    }
     return ~bg & valid;
 }
 
-// the tile's 64 columns of row y: bit c = foreground of pixel column 64 J - 1 + c
+// the tile's 64 columns of row y: bit c = foreground of pixel column 64 J + c
 __device__ __forceinline__ unsigned long long tile_row_fg(const uint32_t *__restrict__ bits,
                                                           int bgWords, int W, int H, int y, int J) {
-    if (J == 0) return row_fg64(bits, bgWords, W, H, y, 0) << 1;  // (column -1: nothing)
-    return row_fg64(bits, bgWords, W, H, y, 64 * J - 1);
+    return row_fg64(bits, bgWords, W, H, y, 64 * J);
 }
 
-__device__ __forceinline__ unsigned long long lane_value64(unsigned long long v, int srcLane) {
-    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, srcLane);
-    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), srcLane);
-    return ((unsigned long long)hi << 32) | lo;
+// four tiles per workgroup: this wave's tile, or false behind the last one
+__device__ __forceinline__ bool wave_tile(int TJ, int TI, int V, int &J, int &I, int &v) {
+    const int tile = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (tile >= TJ * TI * V) return false;
+    J = tile % TJ;
+    I = (tile / TJ) % TI;
+    v = tile / (TJ * TI);
+    return true;
 }
 
 // one wave per tile: rowsum[v][y][J] = fg of row y inside tile column J; T[v][I][J][c] = fg of
-// tile row I in the tile's columns <= c; tilesum[v][I][J] = fg of the tile
-__global__ __launch_bounds__(64) void views_tile_sums_kernel(const uint32_t *__restrict__ bg,
-                                                             int bgWords, int W, int H, int TJ,
-                                                             int TI, int *__restrict__ rowsum,
-                                                             int *__restrict__ T,
-                                                             int *__restrict__ tilesum) {
-    const int J = blockIdx.x, I = blockIdx.y, v = blockIdx.z, lane = threadIdx.x;
+// tile row I in the tile's columns < c; tilesum[v][I][J] = fg of the tile
+__global__ __launch_bounds__(256) void views_tile_sums_kernel(const uint32_t *__restrict__ bg,
+                                                              int bgWords, int W, int H, int TJ,
+                                                              int TI, int V, int *__restrict__ rowsum,
+                                                              int *__restrict__ T,
+                                                              int *__restrict__ tilesum) {
+    int J, I, v;
+    if (!wave_tile(TJ, TI, V, J, I, v)) return;
+    const int lane = threadIdx.x & 63;
     const uint32_t *bits = bg + (size_t)v * bgWords;
     const int yr = I * kTileRows + lane;
     const unsigned long long mine = tile_row_fg(bits, bgWords, W, H, yr, J);  // row `lane`
     if (yr < H) rowsum[((size_t)v * H + yr) * TJ + J] = __popcll(mine);
+    // column c's count: the rows that have bit c set, counted by a ballot (scalar) and handed to
+    // lane c -- two vector instructions per column
+    const uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32);
     int col = 0;
 #pragma unroll
-    for (int r = 0; r < kTileRows; ++r) col += (int)((lane_value64(mine, r) >> lane) & 1ull);
+    for (int c = 0; c < 64; ++c) {
+        const unsigned long long rows = __ballot((((c < 32) ? lo : hi) >> (c & 31)) & 1u);
+        const int n = __popcll(rows);  // (scalar)
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(col) : "s"(n), "n"(c));
+    }
     int sc = col;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const int t = __shfl_up(sc, d);
         if (lane >= d) sc += t;
     }
-    T[(((size_t)v * TI + I) * TJ + J) * 64 + lane] = sc;
+    T[(((size_t)v * TI + I) * TJ + J) * 64 + lane] = sc - col;
     if (lane == 63) tilesum[((size_t)v * TI + I) * TJ + J] = sc;
 }
 
 // one wave per tile: the table entries of its 64 columns x 64 rows
-__global__ __launch_bounds__(64) void views_table_kernel(const uint32_t *__restrict__ bg,
-                                                         int bgWords, int W, int H, int TJ, int TI,
-                                                         const int *__restrict__ rowsum,
-                                                         const int *__restrict__ T,
-                                                         const int *__restrict__ tilesum,
-                                                         uint16_t *__restrict__ sat, int satStride,
-                                                         int ld) {
-    const int J = blockIdx.x, I = blockIdx.y, v = blockIdx.z, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void views_table_kernel(const uint32_t *__restrict__ bg,
+                                                          int bgWords, int W, int H, int TJ, int TI,
+                                                          int V, const int *__restrict__ rowsum,
+                                                          const int *__restrict__ T,
+                                                          const int *__restrict__ tilesum,
+                                                          uint16_t *__restrict__ sat, int satStride,
+                                                          int ld) {
+    int J, I, v;
+    if (!wave_tile(TJ, TI, V, J, I, v)) return;
+    const int lane = threadIdx.x & 63;
     const uint32_t *bits = bg + (size_t)v * bgWords;
     uint16_t *tab = sat + (size_t)v * satStride;  // entries modulo 2^16 (carve_kernels.h, classify_box)
-    const int X = 64 * J + lane, yr = I * kTileRows + lane;  // X: this lane's table column
+    const int yr = I * kTileRows + lane;
     const unsigned long long mine = tile_row_fg(bits, bgWords, W, H, yr, J);  // row `lane`
-    // Lin: running sum over this tile's rows of the row sums of the tile columns to the left
+    // row `lane`'s count in the tile columns to the left (Lin grows by it from row to row)
     int left = 0;
     if (yr < H)
         for (int k = 0; k < J; ++k) left += rowsum[((size_t)v * H + yr) * TJ + k];
@@ -217,22 +236,20 @@ __global__ __launch_bounds__(64) void views_table_kernel(const uint32_t *__restr
     int acc = 0;
     for (int k = 0; k < I; ++k) acc += T[(((size_t)v * TI + k) * TJ + J) * 64 + lane];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(left, d);
-        if (lane >= d) left += t;
-    }
-#pragma unroll
     for (int d = 32; d >= 1; d >>= 1) lt += __shfl_xor(lt, d);
-    if (I == 0 && X <= W) tab[X] = 0;  // row 0 of the table
+    const unsigned off = 64u * (unsigned)J + (unsigned)lane;  // this lane's table column X
+    if (I == 0) tab[off] = 0;                                   // row 0 of the table
     const int nrows = min(kTileRows, H - I * kTileRows);
-    acc += lt;
+    const uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32);
+    uint32_t run = (uint32_t)(acc + lt);
+    uint16_t *row = tab + (size_t)(I * kTileRows + 1) * ld;  // (wave-uniform: scalar registers)
+#pragma unroll 4
     for (int r = 0; r < nrows; ++r) {
-        const unsigned long long fg = lane_value64(mine, r);
-        const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fg >> 32),
-                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)fg, 0u));
-        acc += below + (int)((fg >> lane) & 1ull);
-        const int lin = __builtin_amdgcn_readlane(left, r);
-        if (X <= W) tab[(size_t)(I * kTileRows + r + 1) * ld + X] = (uint16_t)(acc + lin);
+        const uint32_t flo = __builtin_amdgcn_readlane(lo, r), fhi = __builtin_amdgcn_readlane(hi, r);
+        run = __builtin_amdgcn_mbcnt_hi(fhi, __builtin_amdgcn_mbcnt_lo(flo, run));
+        run += (uint32_t)__builtin_amdgcn_readlane(left, r);
+        row[off] = (uint16_t)run;
+        row += ld;
     }
 }
 

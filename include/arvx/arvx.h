@@ -364,6 +364,13 @@ int arvx_selftest_project(arvx_ctx *ctx, int64_t n, const float M[12], float vox
 int arvx_selftest_depth(arvx_ctx *ctx, int64_t n, const float campos[3], float voxel_size,
                         const int32_t *xyz, float *depth);
 
+/* Self-test hook: what arvx_set_views[_device] derived for view `view` -- its background bit
+ * plane (bit i of word i / 32 = pixel i is background; (W*H + 31) / 32 words) and the
+ * summed-area table the rectangle tests read: (H + 1) rows of *ld two-byte entries, entry
+ * [Y][X], X <= W, = foreground pixels in rows < Y and columns < X, modulo 2^16.  Either buffer may
+ * be null; *ld is always set (size the table buffer after a first call with both null). */
+int arvx_selftest_view_tables(arvx_ctx *ctx, int view, uint32_t *bg_bits, uint16_t *table, int *ld);
+
 /* Self-test hook: the kernels' one-instruction pixel rounding (v_cvt_rpi_i32_f32) against
  * std::round on every float in (-0.5, 2^24], i.e. every quotient that can fall inside an
  * image; *mismatches must come back 0. */

@@ -558,6 +558,38 @@ def test_view_preprocessing_paths(arvx, oracle, W, H, C):
             assert_same(ctx.download_state(), want, f"{W}x{H}x{C} device masks")
 
 
+@pytest.mark.parametrize("W,H,C", [(64, 3, 1), (640, 480, 1), (640, 480, 3), (65, 64, 1), (63, 40, 1),
+                                   (127, 70, 3), (130, 129, 4), (192, 117, 1), (96, 64, 3),
+                                   (1000, 700, 1), (2000, 150, 1)])
+def test_view_tables_against_numpy(arvx, W, H, C):
+    """arvx_selftest_view_tables: the background bit plane and the summed-area table derived by
+    arvx_set_views[_device] (csrc/views_kernels.h), entry for entry: bit = all channel bytes zero
+    (reference src/VoxelCarving.cpp:49-50); table[Y][X] = foreground pixels in rows < Y and columns
+    < X, modulo 2^16 (1000 x 700 all foreground runs far past 2^16).  Through the carve alone a
+    wrong entry could hide behind a conservative "mixed" answer."""
+    import torch
+    V = 3
+    _, _, M = scenes.random_cameras(V, 0.512, seed=W + H, W=W, H=H, inside=False)
+    masks = scenes.noise_masks(V, H, W, C=C, block=7, p_bg=0.45, seed=W * 3 + H + C)
+    masks[1] = 255  # every pixel foreground
+    masks[2][:, : W // 2] = 0  # left half background
+    d_masks = torch.from_numpy(np.ascontiguousarray(masks)).cuda()
+    with arvx.Context(8, 8, 8, np.float32(0.064)) as ctx:
+        for src in ("host", "device"):
+            if src == "host":
+                ctx.set_views(M, masks)
+            else:
+                ctx.set_views_device(M, d_masks.data_ptr(), W, H, C)
+            for v in range(V):
+                bg, table = ctx.selftest_view_tables(v, W, H)
+                want_bg = (masks[v].reshape(H, W, -1) == 0).all(axis=2)
+                assert np.array_equal(bg, want_bg), f"{src} view {v}: bit plane"
+                full = np.zeros((H + 1, W + 1), np.int64)
+                full[1:, 1:] = np.cumsum(np.cumsum(~want_bg, axis=0, dtype=np.int64), axis=1)
+                bad = np.argwhere(table != (full & 0xffff).astype(np.uint16))
+                assert bad.size == 0, f"{src} view {v}: {len(bad)} entries differ, first at {bad[0]}"
+
+
 @pytest.mark.parametrize("dims", [(2112, 8, 9), (8, 2112, 9), (9, 8, 2112), (4160, 3, 5)])
 def test_long_thin_grids(arvx, oracle, dims):
     """One extent far beyond the others: thousands of tiles / coarse tiles along a single axis."""
