@@ -1076,7 +1076,8 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         const size_t cap = ((size_t)p.tilesX * p.tilesY * p.tilesZ * 4 + 7) / 8;
         const size_t nitems = cap * arvx::kWorkLists;
         // one persistent workgroup per workgroup slot of the chip (4 per CU at 128 VGPRs)
-        const unsigned pgrid = (unsigned)ncu * 4u;
+        static const int exact_wgs = experiment_int("ARVX_EXACT_WGS_PER_CU");  // (A/B builds)
+        const unsigned pgrid = (unsigned)ncu * (exact_wgs > 0 ? (unsigned)exact_wgs : 4u);
         const size_t nwaves = (size_t)pgrid * 4;
         const size_t nctr_pool = (size_t)arvx::kPoolCounters * arvx::kCounterStride;
         const size_t ints = nctr + nctr_pool;  // list fill counters, pool ticket counters

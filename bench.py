@@ -9,9 +9,21 @@ of radius 0.35E, ring cameras, 640x480 masks).  The u8 masks and the state plane
 resident in HBM before the timed region starts; everything DERIVED from the masks --
 the 1-bit background planes and the summed-area tables the carve kernels read -- is
 rebuilt inside every timed step (arvx_set_views_device), then arvx_carve runs.
-`value` / `ms_per_step` are that whole step; `carve_kernel_ms` is the carve alone and
-`views_kernel_ms` the derivation, both by HIP events on the launch stream, recorded on
-five of the K timed steps (the events themselves cost GPU time between dependent kernels).
+`value` / `ms_per_step` are that whole step.
+
+Jobs in flight (--jobs, default 4).  A step is a chain of six kernels of which the first five are
+bound by latency (a few thousand waves each, dependent reads) and the last one by vector issue,
+ending on a tail of long items: one step after the other leaves the chip partly idle most of the
+time.  The K timed steps are therefore dealt to `jobs` contexts, each on its own stream (job k on
+slot k % jobs): every step is still a whole step on a fresh model with its own derived views, all
+K are complete inside the timed region, and the final model of every slot is compared
+(`slots_agree`, `parity_vs_oracle`).  `value` / `ms_per_step` = K steps / wall time of that;
+`latency_ms_per_step` / `sequential_value` = the same step run one job after the other (K / 4
+steps, same timing frame), which is also where `carve_kernel_ms` (the carve alone),
+`views_kernel_ms` (the derivation) and the `roofline` come from: HIP events on the launch stream
+around single launches, recorded on five of those steps (the events themselves cost GPU time
+between dependent kernels).  --jobs 1 gives the sequential run alone (the profiles under
+profiles/ are taken that way: overlapping launches have no duration of their own).
 
 metric  Mvoxel-views/s = voxels x views / carve time  (BASELINE.json)
 N = 1   512^3 grid x 36 views (the configuration the metric is quoted on)
@@ -227,6 +239,12 @@ def main():
                          "trial fails or a packet overflows), in-place all-gather of contiguous "
                          "slabs, or the north star's all-reduce (SUM over zero-filled planes, "
                          "striped slabs)")
+    ap.add_argument("--jobs", type=int, default=4,
+                    help="jobs in flight per GPU: every job is a whole step (fresh model, views "
+                         "derived, carved); job k runs on context and stream k %% jobs, so that the "
+                         "latency-bound head of one job (view tables, tile classification) runs "
+                         "beside the issue-bound exact kernel of another.  1 = one job after the "
+                         "other (what `latency_ms_per_step` and the kernel times are measured on)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ablation", action="store_true",
                     help="skip the NO_CULL ablation leg (keeps a profile to one kernel variant)")
@@ -277,7 +295,8 @@ def main():
     # a sample of the timed steps: five of them (fewer when K < 20), evenly spaced.
     EV = {"none": 0, "carve": 1, "all": 2}[os.environ.get("ARVX_BENCH_EVENTS", "all")]
 
-    def run_config(base, V, steps, warmup, collective, no_cull=False):
+    def run_config(base, V, steps, warmup, collective, no_cull=False, jobs=1):
+        jobs = max(1, jobs)
         X, Y, Z = sharding.grid_for(world, base)
         sc = synthetic.sphere_scene(max(X, Y, Z), V)
         sc.X, sc.Y, sc.Z = X, Y, Z
@@ -287,17 +306,24 @@ def main():
         # striped (load-balanced) slabs wherever the collective can place scattered words;
         # the plain all-gather needs contiguous ones
         layout = "striped" if (world > 1 and collective != "allgather") else "slab"
-        if layout == "striped":
-            ctx = capi.Context(X, Y, Z, sc.voxel_size, device=local_rank, stripes=(world, rank))
-        else:
-            ctx = capi.Context(X, Y, Z, sc.voxel_size, device=local_rank, z_range=(zlo, zhi))
-        # a real (non-null) HIP stream shared by torch and the library, so that the
-        # torch.cuda.Event pairs below bracket exactly the carve kernel launch
-        stream = torch.cuda.Stream(device=dev)
+        # one context and one real (non-null) HIP stream per job slot, shared by torch and the
+        # library, so that the torch.cuda.Event pairs below bracket exactly the carve launch
+        ctxs, streams = [], []
+        for _ in range(jobs):
+            if layout == "striped":
+                c = capi.Context(X, Y, Z, sc.voxel_size, device=local_rank, stripes=(world, rank))
+            else:
+                c = capi.Context(X, Y, Z, sc.voxel_size, device=local_rank, z_range=(zlo, zhi))
+            st = torch.cuda.Stream(device=dev)
+            c.set_stream(st.cuda_stream)
+            ctxs.append(c)
+            streams.append(st)
+        ctx, stream = ctxs[0], streams[0]
         torch.cuda.set_stream(stream)
-        ctx.set_stream(stream.cuda_stream)
         d_masks = torch.from_numpy(sc.masks).to(dev)  # resident before timing
-        ctx.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
+        torch.cuda.synchronize()  # (the upload ran on the null stream)
+        for c in ctxs:
+            c.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
         ex = None
         if world > 1 and collective != "none":
             ex = sharding.OccupancyExchange(X, Y, Z, world, rank, dev, mode=collective, buffers=2,
@@ -306,6 +332,8 @@ def main():
         ev = {(2 * k + 1) * steps // (2 * n_ev): tuple(torch.cuda.Event(enable_timing=True)
                                                        for _ in range(3))
               for k in range(n_ev)}
+        if jobs > 1:  # kernels of several jobs interleave: a launch has no duration of its own
+            ev = {}
         nstep = [0]
         merge_ok = [None]
         # N > 1: the hand-off of job k -- pack, compress, the collective, expand: HBM-bound
@@ -313,10 +341,13 @@ def main():
         # (tools/rank_step_time.py) -- goes to a stream of its own and runs beside the views
         # and the carve of job k + 1.  Two events order the streams: the pack waits for the
         # carve whose records it reads, the next carve for that pack.
+        # (With several jobs in flight the hand-offs still go through ONE side stream and one
+        # exchange object, in job order -- the same order on every rank.)
         side = torch.cuda.Stream(device=dev) if ex is not None else None
         if side is not None:
-            ctx.set_exchange_stream(side.cuda_stream)
-        packed = [None]  # recorded on `side` behind the latest pack
+            for c in ctxs:
+                c.set_exchange_stream(side.cuda_stream)
+        packed = [None] * jobs  # per slot: recorded on `side` behind the slot's latest pack
 
         def step(i=None):
             # one job: fresh model -> carve all views -> (N>1) merge the occupancy of
@@ -324,6 +355,8 @@ def main():
             # k+1 carves (two packed buffers); the final wait is inside the timing.
             if i not in ev:
                 i = None
+            slot = nstep[0] % jobs
+            ctx, stream = ctxs[slot], streams[slot]
             ctx.reset()
             if i is not None and EV >= 2:
                 ev[i][0].record(stream)
@@ -331,8 +364,8 @@ def main():
             ctx.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
             if i is not None and EV >= 1:
                 ev[i][1].record(stream)
-            if packed[0] is not None:
-                stream.wait_event(packed[0])  # the previous job's pack has read the records
+            if packed[slot] is not None:
+                stream.wait_event(packed[slot])  # the slot's previous pack has read the records
             ctx.carve(flags)
             if i is not None and EV >= 1:
                 ev[i][2].record(stream)
@@ -347,8 +380,8 @@ def main():
                         ctx.pack_occupancy(ex.local[b].data_ptr())
                     else:
                         ctx.pack_occupancy_global(ex.full[b].data_ptr())
-                    packed[0] = torch.cuda.Event()
-                    packed[0].record(side)
+                    packed[slot] = torch.cuda.Event()
+                    packed[slot].record(side)
                     ex.launch(b, async_op=True)
             nstep[0] += 1
 
@@ -391,11 +424,22 @@ def main():
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        views_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev.values()])) if EV >= 2 else float("nan")
-        kern_ms = float(np.mean([b.elapsed_time(c) for _, b, c in ev.values()])) if EV >= 1 else float("nan")
+        views_ms = (float(np.mean([a.elapsed_time(b) for a, b, _ in ev.values()]))
+                    if EV >= 2 and ev else float("nan"))
+        kern_ms = (float(np.mean([b.elapsed_time(c) for _, b, c in ev.values()]))
+                   if EV >= 1 and ev else float("nan"))
         occ = None
         overflowed = bool(ex is not None and ex.overflowed())
+        # the slot of the LAST job: its planes are what the last exchange merged
+        last = (nstep[0] - 1) % jobs
+        ctx = ctxs[last]
         st = ctx.download_state() if (rank == 0 or ex is not None) else None
+        # every slot that ran a job must hold the same model
+        slots_agree = True
+        if st is not None:
+            for k, c in enumerate(ctxs):
+                if k != last and k < nstep[0]:
+                    slots_agree = slots_agree and bool(np.array_equal(c.download_state(), st))
         merged_count_ok = None
         if ex is not None:  # the merged plane must hold as many voxels as the slabs together
             cnt = torch.tensor([int((st & 1).sum())], dtype=torch.int64, device=dev)
@@ -411,16 +455,20 @@ def main():
                 mine = np.packbits((st.reshape(len(ctx.planes), -1) & 1).astype(np.uint8),
                                    axis=1, bitorder="little")
                 merge_ok[0] = bool(np.array_equal(got, mine)) and merged_count_ok
-        ctx.close()
+        for c in ctxs:
+            c.close()
         del d_masks
         nplanes = len(ctx.planes) if hasattr(ctx, "planes") else zhi - zlo
         xbytes = None
         if ex is not None:  # bytes each rank contributes to the collective
             xbytes = ((ex.header + packet_cap) * 8 if collective == "compressed"
                       else ex.total_words * 4 if collective == "allreduce" else ex.my_words * 4)
+        kern_ms = None if kern_ms != kern_ms else kern_ms  # (no NaN in the JSON line)
+        views_ms = None if views_ms != views_ms else views_ms
         return dict(X=X, Y=Y, Z=Z, V=V, dt=dt, kern_ms=kern_ms, views_ms=views_ms, sc=sc, occ=occ,
                     state=st if (world == 1 and rank == 0) else None,
                     nplanes=nplanes, layout=layout, ev_steps=len(ev), nvox=nvox_global, merge_ok=merge_ok[0],
+                    jobs=jobs, slots_agree=slots_agree,
                     overflowed=overflowed, exchange_bytes_per_rank=xbytes)
 
     if world > 1 and args.collective == "compressed":
@@ -436,11 +484,24 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if not int(flag.item()):
             args.collective = "allgather"
-    r = run_config(args.grid, args.views, args.steps, args.warmup, args.collective)
+    def measure(base, V, steps, warmup, collective, jobs):
+        """The throughput run (`jobs` in flight) and, for jobs > 1, a short run of one job after
+        the other in the same frame for what only that can give: a step's latency and the
+        durations of its kernels (HIP events around single launches)."""
+        m = run_config(base, V, steps, warmup, collective, jobs=jobs)
+        m["latency_ms"] = m["dt"] / steps * 1e3
+        if jobs > 1 and not m["overflowed"]:
+            k = max(8, steps // 4)
+            q = run_config(base, V, k, min(warmup, 3), collective, jobs=1)
+            m.update(kern_ms=q["kern_ms"], views_ms=q["views_ms"], ev_steps=q["ev_steps"],
+                     latency_ms=q["dt"] / k * 1e3, latency_steps=k)
+        return m
+
+    r = measure(args.grid, args.views, args.steps, args.warmup, args.collective, args.jobs)
     if r["overflowed"]:
         # a packet outgrew its size inside the timed region: that run does not count
         args.collective = "allgather"
-        r = run_config(args.grid, args.views, args.steps, args.warmup, args.collective)
+        r = measure(args.grid, args.views, args.steps, args.warmup, args.collective, args.jobs)
     vv = r["nvox"] * r["V"]
     value = vv * args.steps / r["dt"] / 1e6
     ms_per_step = r["dt"] / args.steps * 1e3
@@ -527,15 +588,26 @@ def main():
                                f"tables from the resident u8 masks, then dense carve of a fresh "
                                f"model by all views",
                    "grid": [r["X"], r["Y"], r["Z"]], "views": r["V"],
+                   "jobs_in_flight": r["jobs"],
                    "parallelism": f"z-slab x{world} ({r['layout']})" if world > 1 else "single GPU",
                    "collective": args.collective if world > 1 else "none",
                    "merged_plane_holds_rank0_planes": r["merge_ok"],
                    "exchange_bytes_per_rank": r["exchange_bytes_per_rank"],
                    "cull": not args.no_cull},
+        "latency_ms_per_step": r["latency_ms"],
+        "jobs_in_flight_note": (
+            f"`value` / `ms_per_step`: {args.steps} whole steps, {r['jobs']} in flight (job k on context "
+            f"and stream k % {r['jobs']}; every slot's final model compared: slots_agree); "
+            f"`latency_ms_per_step`, the kernel times and the roofline: "
+            f"{r.get('latency_steps', args.steps)} steps one after the other, same frame"
+            if r["jobs"] > 1 else "one job after the other"),
+        "slots_agree": r["slots_agree"],
+        "sequential_value": vv / (r["latency_ms"] * 1e-3) / 1e6,
         "carve_kernel_ms": r["kern_ms"], "views_kernel_ms": r["views_ms"],
         "kernel_ms_from": f"HIP events on the launch stream around {r['ev_steps']} of the "
-                          f"{args.steps} timed steps (an event is a packet between dependent "
-                          f"kernels: three per step cost 13.6 us of a 0.146 ms step)",
+                          f"{r.get('latency_steps', args.steps)} steps run one after the other (an "
+                          f"event is a packet between dependent kernels: three per step cost "
+                          f"13.6 us of a 0.146 ms step)",
         "carve_only_value": vv / (r["kern_ms"] * 1e-3) / 1e6,
         "occupied_fraction": r["occ"],
         "roofline": roofline,
@@ -550,6 +622,7 @@ def main():
             xb = c["exchange_bytes_per_rank"]
             return {"ms_per_step": c["dt"] / k * 1e3, "value": c["nvox"] * c["V"] / (c["dt"] / k) / 1e6,
                     "unit": "Mvoxel-views/s", "steps": k, "layout": c["layout"],
+                    "jobs_in_flight": c["jobs"], "latency_ms_per_step": c["latency_ms"],
                     "exchange_bytes_per_rank": xb, "merge_ok": c["merge_ok"],
                     "carve_kernel_ms": c["kern_ms"], "views_kernel_ms": c["views_ms"]}
         coll = {args.collective: coll_entry(r, args.steps)}
@@ -558,7 +631,7 @@ def main():
             if mode in coll:
                 continue
             try:
-                coll[mode] = coll_entry(run_config(args.grid, args.views, kc, 2, mode), kc)
+                coll[mode] = coll_entry(measure(args.grid, args.views, kc, 2, mode, args.jobs), kc)
             except Exception as ex:  # noqa: BLE001
                 coll[mode] = {"error": f"{type(ex).__name__}: {ex}"}
         if rank == 0:
@@ -572,12 +645,13 @@ def main():
         # BASELINE config 4 as it is written: 1024^3 x 72 views over the 8 GPUs
         try:
             k = max(3, args.steps // 2)
-            c4 = run_config(512, 72, k, 2, args.collective)
+            c4 = measure(512, 72, k, 2, args.collective, args.jobs)
             if rank == 0:
                 out["c4_1024x72"] = {
                     "workload": f"{c4['X']}x{c4['Y']}x{c4['Z']} x 72 views, 8 GPUs",
                     "value": c4["nvox"] * 72 / (c4["dt"] / k) / 1e6, "unit": "Mvoxel-views/s",
-                    "ms_per_step": c4["dt"] / k * 1e3, "carve_kernel_ms": c4["kern_ms"],
+                    "ms_per_step": c4["dt"] / k * 1e3, "latency_ms_per_step": c4["latency_ms"],
+                    "jobs_in_flight": c4["jobs"], "carve_kernel_ms": c4["kern_ms"],
                     "views_kernel_ms": c4["views_ms"], "merge_ok": c4["merge_ok"]}
         except Exception as ex:  # noqa: BLE001
             if rank == 0:
@@ -607,7 +681,7 @@ def main():
     if rank == 0 and world == 1 and args.extra_grid and args.extra_grid != args.grid:
         try:
             k = max(3, args.steps // 4)
-            e = run_config(args.extra_grid, args.views, k, 1, "none")
+            e = measure(args.extra_grid, args.views, k, 1, "none", args.jobs)
             evv = e["nvox"] * e["V"]
             eb = evv + e["V"] * e["sc"].W * e["sc"].H
             out["extra"] = {
@@ -615,6 +689,7 @@ def main():
                 "value": evv / (e["dt"] / k) / 1e6,
                 "unit": "Mvoxel-views/s", "carve_kernel_ms": e["kern_ms"],
                 "views_kernel_ms": e["views_ms"], "ms_per_step": e["dt"] / k * 1e3,
+                "jobs_in_flight": e["jobs"], "latency_ms_per_step": e["latency_ms"],
                 "roofline_frac": eb / (e["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "occupied_fraction": e["occ"]}
         except Exception as ex:  # e.g. not enough memory on a shared box
