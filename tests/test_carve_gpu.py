@@ -590,6 +590,51 @@ def test_view_tables_against_numpy(arvx, W, H, C):
                 assert bad.size == 0, f"{src} view {v}: {len(bad)} entries differ, first at {bad[0]}"
 
 
+@pytest.mark.parametrize("N,V,W,H", [(64, 6, 160, 120), (256, 36, 640, 480)])
+def test_jobs_in_flight_on_several_contexts(arvx, N, V, W, H):
+    """Several jobs in flight, as bench.py --jobs runs them: job k on context and stream k % 3,
+    scenes alternating, nothing between the jobs but stream order inside a slot.  Every job's
+    packed occupancy must be that of its scene carved alone (contexts share nothing: each has its
+    own tables, lists and work buffers).  At 256^3 x 36 views of 640 x 480 the view derivation of
+    one job really runs beside the exact kernel of another."""
+    import torch
+    scs = [scenes.syn.sphere_scene(N, V, W=W, H=H), scenes.syn.box_scene((N, N, N), V, W=W, H=H)]
+    n = N * N * N // 64
+    want = []
+    with arvx.Context(N, N, N, scs[0].voxel_size) as c:  # one job at a time
+        for sc in scs:
+            c.set_views(sc.M, sc.masks)
+            c.reset()
+            c.carve()
+            d = torch.zeros(n, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            c.pack_occupancy(d.data_ptr())
+            c.synchronize()
+            want.append(d.clone())
+    assert not torch.equal(want[0], want[1])
+    d_masks = [torch.from_numpy(np.ascontiguousarray(sc.masks)).cuda() for sc in scs]
+    slots, jobs = 3, 14
+    streams = [torch.cuda.Stream() for _ in range(slots)]
+    ctxs = [arvx.Context(N, N, N, scs[0].voxel_size) for _ in range(slots)]
+    got = [torch.zeros(n, dtype=torch.int64, device="cuda") for _ in range(jobs)]
+    torch.cuda.synchronize()
+    try:
+        for c, st in zip(ctxs, streams):
+            c.set_stream(st.cuda_stream)
+        for k in range(jobs):
+            c, sc = ctxs[k % slots], scs[(k * 5 // 3) % 2]
+            c.reset()
+            c.set_views_device(sc.M, d_masks[(k * 5 // 3) % 2].data_ptr(), sc.W, sc.H, 1)
+            c.carve()
+            c.pack_occupancy(got[k].data_ptr())  # (same stream: ordered behind the carve)
+        torch.cuda.synchronize()
+    finally:
+        for c in ctxs:
+            c.close()
+    for k in range(jobs):
+        assert torch.equal(got[k], want[(k * 5 // 3) % 2]), f"job {k}"
+
+
 @pytest.mark.parametrize("dims", [(2112, 8, 9), (8, 2112, 9), (9, 8, 2112), (4160, 3, 5)])
 def test_long_thin_grids(arvx, oracle, dims):
     """One extent far beyond the others: thousands of tiles / coarse tiles along a single axis."""

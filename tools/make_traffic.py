@@ -50,7 +50,7 @@ def main():
                                        if k in ks and "SQ_INSTS_VALU" in ks[k]},
             "source": f"profiles/{name}/summary.json tag {tag} (rocprofv3 --pmc FETCH_SIZE / "
                       "WRITE_SIZE / SQ_* in separate passes over `bench.py --steps 10 --warmup 2 "
-                      "--no-cpu --no-ablation --no-workloads --extra-grid 0`, tools/profile.sh; bytes = 2 x FETCH "
+                      "--no-cpu --no-ablation --no-workloads --jobs 1 --extra-grid 0`, tools/profile.sh; bytes = 2 x FETCH "
                       "+ WRITE per the guide's gfx950 correction, raw counters beside it)"}
     json.dump(out, open(tpath, "w"), indent=1)
     for k, v in out.items():
