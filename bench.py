@@ -341,13 +341,13 @@ def main():
         # (tools/rank_step_time.py) -- goes to a stream of its own and runs beside the views
         # and the carve of job k + 1.  Two events order the streams: the pack waits for the
         # carve whose records it reads, the next carve for that pack.
-        # (With several jobs in flight the hand-offs still go through ONE side stream and one
-        # exchange object, in job order -- the same order on every rank.)
-        side = torch.cuda.Stream(device=dev) if ex is not None else None
-        if side is not None:
-            for c in ctxs:
-                c.set_exchange_stream(side.cuda_stream)
-        packed = [None] * jobs  # per slot: recorded on `side` behind the slot's latest pack
+        # (With several jobs in flight: one exchange object with two packed buffers, used in
+        # turn, and one side stream per BUFFER -- whatever touches buffer b is ordered by its
+        # stream, the pack / compress / expand kernels of one job run beside the collective of
+        # the job before, and the collectives themselves are issued in job order, the same
+        # order on every rank.)
+        sides = [torch.cuda.Stream(device=dev) for _ in range(2)] if ex is not None else None
+        packed = [None] * jobs  # per slot: recorded behind the slot's latest pack
 
         def step(i=None):
             # one job: fresh model -> carve all views -> (N>1) merge the occupancy of
@@ -371,8 +371,11 @@ def main():
                 ev[i][2].record(stream)
             if ex is not None:
                 b = nstep[0] % 2
+                side = sides[b]
                 carved = torch.cuda.Event()
                 carved.record(stream)
+                ctx.set_exchange_stream(side.cuda_stream)  # pack / compress / expand of this job
+                ex.codec = ctx
                 with torch.cuda.stream(side):
                     side.wait_event(carved)
                     ex.prepare(b, verify=False)  # compressed: overflow is checked after drain()
@@ -387,8 +390,11 @@ def main():
 
         def drain():
             if ex is not None:
-                with torch.cuda.stream(side):
-                    ex.wait_all(verify=False)
+                for b in range(2):
+                    ctxs[0].set_exchange_stream(sides[b].cuda_stream)  # (the expand of buffer b)
+                    ex.codec = ctxs[0]
+                    with torch.cuda.stream(sides[b]):
+                        ex.wait(b, verify=False)
             torch.cuda.synchronize()
 
         # (the interpreter's cyclic collector pauses for 40-85 ms once torch is loaded -- seen at
@@ -513,7 +519,7 @@ def main():
     alg_bytes = nv_rank * r["V"] + r["V"] * r["sc"].W * r["sc"].H
     achieved = alg_bytes / (r["kern_ms"] * 1e-3) / 1e9
     traffic = traffic_step = None
-    valu = valu_all = None
+    valu = valu_all = valu_views = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and world == 1:
         try:
@@ -526,6 +532,7 @@ def main():
             # 256 CUs x 4 SIMD-32, one wave64 instruction per 2 cycles at 2.4 GHz (the guide's
             # FP32 vector peak counted in instructions; fp64 adds / converts issue slower)
             valu_all = ent.get("valu_wave_instructions") or None
+            valu_views = ent.get("valu_wave_instructions_views") or None
             ins = ent.get("valu_wave_instructions", {}).get("exact")
             t_ns = ent.get("kernel_avg_ns_rocprofv3", {}).get("exact")
             if ins and t_ns:
@@ -570,6 +577,15 @@ def main():
                                  "frac": (phys / HBM_PEAK_GBS) if phys else None,
                                  "note": "2 x FETCH_SIZE + WRITE_SIZE per the guide's gfx950 "
                                          "correction"},
+                "step_jobs_in_flight": (lambda ins: {
+                    "what": "all vector instructions of a step (the six kernels, "
+                            "profiles/traffic.json) / this run's ms_per_step with "
+                            f"{r['jobs']} jobs in flight",
+                    "valu_wave_instructions": ins, "ms_per_step": ms_per_step,
+                    "achieved": ins / (ms_per_step * 1e-3) / 1e9, "peak": VALU_PEAK,
+                    "unit": "G wave-instructions/s",
+                    "frac": ins / (ms_per_step * 1e-3) / 1e9 / VALU_PEAK} if ins else None)(
+                        (ins_all + sum(valu_views.values())) if (ins_all and valu_views) else None),
                 "step": {"kernels": "views_bits + views_tile_sums + views_table "
                                     "(arvx_set_views_device) + the three carve kernels",
                          "kernel_ms": step_kernel_ms,

@@ -48,6 +48,8 @@ def main():
             "carve_kernels_ns": ns(CARVE), "views_kernels_ns": ns(VIEWS),
             "valu_wave_instructions": {k: ks[k]["SQ_INSTS_VALU"]["mean"] for k in CARVE
                                        if k in ks and "SQ_INSTS_VALU" in ks[k]},
+            "valu_wave_instructions_views": {k: ks[k]["SQ_INSTS_VALU"]["mean"] for k in VIEWS
+                                             if k in ks and "SQ_INSTS_VALU" in ks[k]},
             "source": f"profiles/{name}/summary.json tag {tag} (rocprofv3 --pmc FETCH_SIZE / "
                       "WRITE_SIZE / SQ_* in separate passes over `bench.py --steps 10 --warmup 2 "
                       "--no-cpu --no-ablation --no-workloads --jobs 1 --extra-grid 0`, tools/profile.sh; bytes = 2 x FETCH "
