@@ -8,7 +8,9 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "arvx/calibration.hpp"
@@ -139,6 +141,48 @@ static int run_carve(const char *scene, const char *out, const char *mode) {
             model.handleUnseen();
             if (arvx::applyClosure(&model, 3) != 0) return 5;
             cells = arvx::marchingCubesCells(model);
+        } else if (!std::strcmp(mode, "threads")) {
+            // several jobs in flight from several host threads: every thread owns its models
+            // (contexts share nothing; calls on ONE context are not thread safe, calls on
+            // different contexts are), runs the pipeline a few times and keeps its last model
+            constexpr int kThreads = 3, kRounds = 3;
+            std::vector<std::unique_ptr<Model>> last(kThreads);
+            std::vector<int> rc(kThreads, 0);
+            std::vector<std::thread> pool;
+            for (int t = 0; t < kThreads; ++t)
+                pool.emplace_back([&, t] {
+                    try {
+                        for (int r = 0; r < kRounds; ++r) {
+                            auto m = std::make_unique<Model>(model);  // an independent copy
+                            arvx::carve(intr, *m, views);
+                            arvx::reconstructAvgColor(intr, *m, views);
+                            m->handleUnseen();
+                            if (arvx::applyClosure(m.get(), 3) != 0) rc[t] = 5;
+                            last[t] = std::move(m);
+                        }
+                    } catch (const arvx::Error &e) {
+                        std::fprintf(stderr, "thread %d: arvx::Error %d: %s\n", t, e.code, e.what());
+                        rc[t] = 3;
+                    }
+                });
+            for (auto &th : pool) th.join();
+            for (int t = 0; t < kThreads; ++t)
+                if (rc[t]) return rc[t];
+            arvx::carve(intr, model, views);
+            arvx::reconstructAvgColor(intr, model, views);
+            model.handleUnseen();
+            if (arvx::applyClosure(&model, 3) != 0) return 5;
+            for (int t = 0; t < kThreads; ++t)
+                for (int z = 0; z < Z; ++z)
+                    for (int y = 0; y < Y; ++y)
+                        for (int x = 0; x < X; ++x) {
+                            const Vec4f a = model.get(x, y, z), b = last[t]->get(x, y, z);
+                            if (std::memcmp(a.v, b.v, 16) ||
+                                model.visited(Vec3i(x, y, z)) != last[t]->visited(Vec3i(x, y, z))) {
+                                std::fprintf(stderr, "thread %d differs at %d %d %d\n", t, x, y, z);
+                                return 7;
+                            }
+                        }
         } else { std::fprintf(stderr, "unknown mode %s\n", mode); return 2; }
     } catch (const arvx::Error &e) {
         std::fprintf(stderr, "arvx::Error %d: %s\n", e.code, e.what());

@@ -82,7 +82,7 @@ def read_result(path, n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["carve", "carve_steps", "closest", "average_unseen", "fast",
-                                  "closure", "closure_mc", "recarve_colored"])
+                                  "closure", "closure_mc", "recarve_colored", "threads"])
 def test_cpp_entry_points_match_oracle(host_bin, oracle, tmp_path, mode):
     X, Y, Z, V = 30, 20, 12, 5
     sc = scenes.syn.sphere_scene(32, V, W=96, H=72, with_images=True)
@@ -109,10 +109,11 @@ def test_cpp_entry_points_match_oracle(host_bin, oracle, tmp_path, mode):
         # handleUnseen paints never-seen voxels; the second carve changes nothing the
         # first did not (it is idempotent) -- but a never-seen voxel stays unseen too
         want = oracle.handle_unseen(st, want)
-    if mode in ("average_unseen", "closure", "closure_mc"):
+    if mode in ("average_unseen", "closure", "closure_mc", "threads"):
         want = oracle.color(X, Y, Z, s, M, sc.campos, sc.images, 1, want)
         want = oracle.handle_unseen(st, want)
-    if mode in ("closure", "closure_mc"):
+    if mode in ("closure", "closure_mc", "threads"):  # (threads: three host threads, three models
+        # each, all equal to the main thread's -- checked by the binary -- and to the oracle)
         want = oracle.closure(X, Y, Z, want)
         assert "LOG - PP: starting dilution." in r.stdout
     assert np.array_equal(seen, (st.reshape(-1) & 2) == 2)
