@@ -870,32 +870,61 @@ __global__ __launch_bounds__(256, 4) void carve_classify_dense_kernel(const Carv
             if (flag) atomicOr(&s_flag[sub], flag);
         }
         __syncthreads();
-        // ---- phase 2: a wave per sub-tile, a quarter of the unit's each: settle (one record
-        // store, nothing to wait for) ...
-        for (int sl = wave; sl < U; sl += 4) {
-            const int sidx = s0 + sl, tl = sidx >> 2, sw = sidx & 3;
-            const int tx = cx;
-            const int ty = cty + (tl & ((1 << p.cyShift) - 1)), tz = ctz + (tl >> p.cyShift);
-            // (tiles and sub-tiles of an edge coarse tile that lie outside the grid keep the
-            // "finished" records they were allocated with)
-            if (ty >= p.tilesY || tz >= p.tilesZ || tx * kTileX + sw * kSubX >= p.X) continue;
-            bool any_mixed = false;
-#pragma unroll
-            for (int c = 0; c < kMaxChunks; ++c)
-                if (c < p.nchunks) any_mixed = any_mixed || uniform64(s_mixed[c][sl]) != 0;
-            const unsigned flag = __builtin_amdgcn_readfirstlane(s_flag[sl]);
-            const bool any_carved = flag & 1u, any_fg = flag & 2u;
-            uint16_t *const rec = p.rec + rec_index(p, tx, ty, tz, sw) * kRecU16;
+        // ---- phase 2: the records the unit settles (and the initial state of shared items),
+        // 16 bytes per thread: chunk c of a record = the eight occupancy rows of plane c (c < 8)
+        // or the eight seen rows of plane c - 8.  (A wave per sub-tile with four bytes per lane
+        // did the sub-tile's index arithmetic 64 lanes wide for 256 bytes: at 1024^3 that was
+        // about half of this kernel's vector instructions.)
+        {
             const bool fresh = p.flags & 4u;
-            if (any_carved) {  // carved implies seen (src/VoxelCarving.cpp:50-54): no load needed
-                subtile_store_done(rec, lane);
-            } else if (!any_mixed) {
-                if (fresh)
-                    subtile_store_const(p, rec, lane, tx, ty, tz, sw, true, any_fg);
-                else if (any_fg && lane >= 32)
-                    reinterpret_cast<uint32_t *>(rec)[lane] = 0xffffffffu;  // the seen half
-            } else if ((p.flags & 12u) == 12u) {
-                subtile_store_const(p, rec, lane, tx, ty, tz, sw, true, false);
+            for (int q = threadIdx.x; q < (U << 4); q += 256) {
+                const int sl = q >> 4, c = q & 15;
+                const int sidx = s0 + sl, tl = sidx >> 2, sw = sidx & 3;
+                const int tx = cx;
+                const int ty = cty + (tl & ((1 << p.cyShift) - 1)), tz = ctz + (tl >> p.cyShift);
+                const int x0 = tx * kTileX + sw * kSubX;
+                // (tiles and sub-tiles of an edge coarse tile that lie outside the grid keep the
+                // "finished" records they were allocated with)
+                if (ty >= p.tilesY || tz >= p.tilesZ || x0 >= p.X) continue;
+                bool any_mixed = false;
+#pragma unroll
+                for (int k = 0; k < kMaxChunks; ++k)
+                    if (k < p.nchunks) any_mixed = any_mixed || s_mixed[k][sl] != 0;
+                const unsigned flag = s_flag[sl];
+                const bool any_carved = flag & 1u, any_fg = flag & 2u;
+                const bool seen_half = c >= 8;
+                uint4 v;
+                if (any_carved) {  // carved implies seen (src/VoxelCarving.cpp:50-54)
+                    v.x = v.y = v.z = v.w = seen_half ? 0xffffffffu : 0u;
+                } else if (!any_mixed && !fresh) {
+                    // no view needs a closer look and none carves: occupancy stays, and every
+                    // voxel is seen if some view sees the whole box (src/VoxelCarving.cpp:54)
+                    if (!(any_fg && seen_half)) continue;
+                    v.x = v.y = v.z = v.w = 0xffffffffu;
+                } else if (!any_mixed || (p.flags & 12u) == 12u) {
+                    // a fresh model's record from constants: occupied inside the grid, seen where
+                    // a view sees the whole box (outside the grid: always) -- and, for a sub-tile
+                    // the exact kernel may hand to several waves that merge their results with
+                    // atomics, the initial state (a fresh model exists only as a flag until now)
+                    const bool seen = !any_mixed && any_fg;
+                    const int z = tz * kTileZ + (c & 7);
+                    const int ny = z < p.Z ? min(kTileY, p.Y - ty * kTileY) : 0;  // rows inside
+                    const uint32_t xm = 0xffffu >> (kSubX - min(kSubX, p.X - x0));
+                    uint32_t w[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t in = (2 * k < ny ? xm : 0u) | (2 * k + 1 < ny ? xm << 16 : 0u);
+                        w[k] = !seen_half ? in : (seen ? 0xffffffffu : ~in);
+                    }
+                    v.x = w[0];
+                    v.y = w[1];
+                    v.z = w[2];
+                    v.w = w[3];
+                } else {
+                    continue;
+                }
+                uint16_t *const rec = p.rec + rec_index(p, tx, ty, tz, sw) * kRecU16;
+                reinterpret_cast<uint4 *>(rec)[c] = v;
             }
         }
         // ... and queue: lane = sub-tile, so that the unit's appends to the work lists (an atomic
