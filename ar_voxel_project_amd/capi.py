@@ -39,7 +39,7 @@ SYMBOLS = [
     "arvx_host_unregister", "arvx_handle_unseen", "arvx_undistort", "arvx_undistort_device",
     "arvx_pack_occupancy", "arvx_pack_occupancy_global", "arvx_carve", "arvx_carve_views", "arvx_fast_carve",
     "arvx_color", "arvx_surface_count", "arvx_surface_download",
-    "arvx_surface_depth_download",
+    "arvx_surface_depth_download", "arvx_color_samples",
     "arvx_colors_upload", "arvx_closure", "arvx_closure_count", "arvx_closure_download",
     "arvx_closure_download32",
     "arvx_mc_cells", "arvx_mc_cells_download", "arvx_mc_mesh", "arvx_mc_mesh_download",
@@ -482,6 +482,18 @@ class Context:
         if n.value:
             self._ck(self._lib.arvx_surface_depth_download(self._h, _fp(d)))
         return d
+
+    SAMPLE_DTYPE = np.dtype([("r", np.uint8), ("g", np.uint8), ("b", np.uint8), ("valid", np.uint8),
+                             ("depth", np.float32)])
+
+    def color_samples(self, index) -> np.ndarray:
+        """The colour lists behind the vote (Model::addColor / getColors of the reference):
+        (n, V) records r, g, b, valid, depth for n voxels (flat indices over the owned planes)."""
+        index = np.ascontiguousarray(index, dtype=np.int64)
+        out = np.zeros((len(index), self.V), self.SAMPLE_DTYPE)
+        self._lib.arvx_color_samples.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        self._ck(self._lib.arvx_color_samples(self._h, len(index), index.ctypes.data, out.ctypes.data))
+        return out
 
     def upload_colors(self, index, rgb) -> None:
         index = np.ascontiguousarray(index, dtype=np.int64)

@@ -1425,6 +1425,50 @@ int arvx_color(arvx_ctx *ctx, int mode) {
     return ARVX_OK;
 }
 
+int arvx_color_samples(arvx_ctx *ctx, int64_t n, const int64_t *index, arvx_color_sample *out) {
+    ARVX_CHECK_CTX(ctx);
+    static_assert(sizeof(arvx_color_sample) == 8, "r, g, b, valid, depth");
+    if (!ctx->cameras_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
+    if (!ctx->images_ready) return fail(ARVX_ERR_STATE, "arvx_set_images has not been called");
+    if (!ctx->has_campos) return fail(ARVX_ERR_STATE, "arvx_set_views was given no campos");
+    if (n < 0 || (n && (!index || !out))) return fail(ARVX_ERR_INVALID, "null index / out or n < 0");
+    if (n == 0) return ARVX_OK;
+    const int64_t nown = (int64_t)ctx->X * ctx->Y * (ctx->z1 - ctx->z0);
+    for (int64_t k = 0; k < n; ++k)
+        if (index[k] < 0 || index[k] >= nown)
+            return fail(ARVX_ERR_INVALID, "voxel index %lld outside [0,%lld)", (long long)index[k],
+                        (long long)nown);
+    const size_t total = (size_t)n * ctx->V;
+    if (int rc = ensure_scratch(ctx, (size_t)n * sizeof(long long) + total * sizeof(uint2) + 64)) return rc;
+    uint2 *d_out = (uint2 *)ctx->d_scratch;
+    long long *d_idx = (long long *)(d_out + total);
+    ARVX_HIP(hipMemcpyAsync(d_idx, index, (size_t)n * sizeof(long long), hipMemcpyHostToDevice,
+                            ctx->stream));
+    arvx::VoteParams vp{};
+    vp.n = n;
+    vp.X = ctx->X;
+    vp.Y = ctx->Y;
+    vp.zglob0 = ctx->z0;  // (indices run over the owned planes)
+    vp.s = ctx->s;
+    vp.V = ctx->V;
+    vp.W = ctx->W;
+    vp.H = ctx->H;
+    vp.M = ctx->d_M;
+    vp.campos = ctx->d_campos;
+    vp.images = ctx->d_images;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (ctx->assoc == ARVX_ASSOC_LEFT)
+        hipLaunchKernelGGL(arvx::color_samples_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, vp,
+                           d_idx, d_out);
+    else
+        hipLaunchKernelGGL(arvx::color_samples_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, vp,
+                           d_idx, d_out);
+    ARVX_HIP(hipGetLastError());
+    ARVX_HIP(hipMemcpyAsync(out, d_out, total * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
+    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    return ARVX_OK;
+}
+
 int arvx_surface_count(arvx_ctx *ctx, int64_t *count) {
     if (!ctx || !count) return fail(ARVX_ERR_INVALID, "null argument");
     if (!ctx->color_ready) return fail(ARVX_ERR_STATE, "no colour result (call arvx_color)");

@@ -118,6 +118,33 @@ __global__ __launch_bounds__(256) void selftest_depth_kernel(const SelftestMatri
     depth[i] = sample_depth(cam.m, w0, w1, w2);
 }
 
+// the samples themselves (arvx_color_samples): one thread per (voxel, view); 8 bytes out:
+// r, g, b, valid, depth -- the DCLR entries Model::addColor would get, in view order
+template <bool LEFT>
+__global__ __launch_bounds__(256) void color_samples_kernel(const VoteParams p,
+                                                            const long long *__restrict__ index,
+                                                            uint2 *__restrict__ out) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.n * p.V) return;
+    const long long k = t / p.V;
+    const int v = (int)(t % p.V);
+    const long long i = index[k];
+    const int x = (int)(i % p.X);
+    const int y = (int)((i / p.X) % p.Y);
+    const int z = p.zglob0 + (int)(i / ((long long)p.X * p.Y));
+    float a[3];
+    project_rows<LEFT>(p.M + 12 * v, p.s, x, y, z, a);
+    int pix;
+    uint2 o = make_uint2(0u, 0u);
+    if (pixel_of(a[0], a[1], a[2], p.W, p.H, pix)) {  // ColorReconstruction.h:54-57
+        const uint8_t *q = p.images + ((size_t)v * p.W * p.H + pix) * 3;  // Vec3b is BGR
+        const float w0 = (float)y * p.s, w1 = (float)x * p.s, w2 = (float)(-z) * p.s;
+        o.x = (unsigned)q[2] | ((unsigned)q[1] << 8) | ((unsigned)q[0] << 16) | (1u << 24);
+        o.y = __float_as_uint(sample_depth(p.campos + 3 * v, w0, w1, w2));
+    }
+    out[t] = o;
+}
+
 template <bool LEFT>
 __global__ __launch_bounds__(256) void color_vote_kernel(const VoteParams p) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;

@@ -284,6 +284,20 @@ int arvx_surface_download(arvx_ctx *ctx, int64_t *index, float *rgb);
 /* Smallest sample depth of each coloured voxel (same order), as the reference
  * computes it: (float)cv::norm(cameras[i] - world), src/ColorReconstruction.h:59. */
 int arvx_surface_depth_download(arvx_ctx *ctx, float *depth);
+/* The per-voxel colour lists behind the vote -- what the reference's voxel_pass appends with
+ * Model::addColor (src/ColorReconstruction.h:44-60, src/Model.h:142-149) and getColors returns:
+ * for each of n voxels (flat index over the context's own planes, any order) V samples in view
+ * order, out[k * V + i] = view i's sample of voxel k: valid = 1 and (r, g, b) = the pixel the
+ * voxel projects to in image i with depth = (float)cv::norm(cameras[i] - world), or valid = 0
+ * when it projects outside the image.  Needs the cameras (with campos) and the images of the
+ * colour pass (arvx_set_views, arvx_set_images); the occupancy is not looked at -- which voxels
+ * a pass visits (occupied, not inner) is the caller's knowledge (arvx_surface_download). */
+typedef struct arvx_color_sample {
+    uint8_t r, g, b, valid;
+    float depth;
+} arvx_color_sample;
+int arvx_color_samples(arvx_ctx *ctx, int64_t n, const int64_t *index, arvx_color_sample *out);
+
 /* Replace the device-side sparse colours by a caller-supplied list (n voxels,
  * ascending flat index, 3 floats RGB each, w = 1): lets a host Model that was
  * coloured elsewhere go through arvx_closure / arvx_export_model. */

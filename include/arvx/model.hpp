@@ -197,9 +197,31 @@ class Model {
     void addColor(int x, int y, int z, const Vec4f &color, float depth) {  // src/Model.h:142-145
         color_lists_[flatten(x, y, z)].push_back(DCLR{color, depth});
     }
-    std::vector<DCLR> getColors(int x, int y, int z) const {  // src/Model.h:147-149
-        auto it = color_lists_.find(flatten(x, y, z));
-        return it == color_lists_.end() ? std::vector<DCLR>() : it->second;
+    // src/Model.h:147-149.  The lists of the LAST colour pass on the device are not kept per
+    // voxel (the reference's vector of vectors costs 24 bytes per voxel before the first sample):
+    // the pass leaves the list of the voxels it coloured, and a voxel's samples -- the DCLR
+    // entries voxel_pass would have appended, in view order -- are recomputed by the device on
+    // request (arvx_color_samples) while the context still holds that pass's cameras and images;
+    // after another carve or a new set of views the device part is empty.  Samples added with
+    // addColor on the host follow the device's.
+    std::vector<DCLR> getColors(int x, int y, int z) const {
+        std::vector<DCLR> out;
+        const int64_t flat = flatten(x, y, z);
+        if (link_ && link_->ctx && !sampled_.empty() &&
+            std::binary_search(sampled_.begin(), sampled_.end(), flat)) {
+            std::vector<arvx_color_sample> smp((size_t)sample_views_);
+            if (arvx_color_samples(link_->ctx, 1, &flat, smp.data()) == ARVX_OK)
+                for (const arvx_color_sample &c : smp)
+                    if (c.valid) out.push_back(DCLR{Vec4f((float)c.r, (float)c.g, (float)c.b, 1.f), c.depth});
+        }
+        auto it = color_lists_.find((int)flat);
+        if (it != color_lists_.end()) out.insert(out.end(), it->second.begin(), it->second.end());
+        return out;
+    }
+    // the colour pass: the voxels it coloured (ascending flat index) and its number of views
+    void set_sampled(std::vector<int64_t> &&index, int views) {
+        sampled_ = std::move(index);
+        sample_views_ = views;
     }
 
     void see(int x, int y, int z) {  // src/Model.h:151
@@ -514,6 +536,8 @@ class Model {
     HostVector<Vec4f> fval_;
     std::unordered_map<int, Vec4f> overlay_;  // ... and what single set() calls stored since
     std::unordered_map<int, std::vector<DCLR>> color_lists_;
+    std::vector<int64_t> sampled_;  // voxels the last device colour pass coloured (getColors)
+    int sample_views_ = 0;
     std::shared_ptr<detail::DeviceLink> link_;
 
     int flatten(int x, int y, int z) const {  // src/Model.h:104-106

@@ -137,6 +137,7 @@ inline void color_pass(const Intrinsics &intr, Model &model, const std::vector<V
     if (n) check(arvx_surface_download(ctx, idx.data(), rgb.data()), "arvx_surface_download");
     model.set_sorted(idx, rgb.data(), 3, false);
     model.set_colors_on_device(!had_colors);
+    model.set_sampled(std::move(idx), (int)views.size());  // (Model::getColors asks the device)
 }
 
 }  // namespace detail

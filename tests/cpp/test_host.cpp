@@ -118,6 +118,28 @@ static int run_carve(const char *scene, const char *out, const char *mode) {
         else if (!std::strcmp(mode, "closest")) {
             arvx::carve(intr, model, views);
             arvx::reconstructClosestColor(intr, model, views);
+            // Model::getColors (src/Model.h:147-149): the samples behind the vote.  A voxel has a
+            // list exactly when the pass coloured it, and the closest sample (strict <, the
+            // first view wins, src/ColorReconstruction.cpp:33-40) is the colour it got.
+            size_t with_list = 0;
+            for (int z = 0; z < Z; ++z)
+                for (int y = 0; y < Y; ++y)
+                    for (int x = 0; x < X; ++x) {
+                        const std::vector<arvx::DCLR> cl = model.getColors(x, y, z);
+                        const bool visited = model.get(x, y, z)(3) != 0 && !model.isInner(x, y, z);
+                        if (cl.empty()) continue;
+                        ++with_list;
+                        if (!visited || cl.size() > (size_t)V) return 8;
+                        size_t best = 0;
+                        for (size_t k = 1; k < cl.size(); ++k)
+                            if (cl[k].depth < cl[best].depth) best = k;
+                        const Vec4f got = model.get(x, y, z);
+                        if (std::memcmp(got.v, cl[best].color.v, 16)) return 9;
+                    }
+            if (!with_list) return 10;
+            Model copy(model);  // (a copy has no device context: only what addColor stored)
+            copy.addColor(1, 2, 3, Vec4f(1, 2, 3, 1), 0.5f);
+            if (copy.getColors(1, 2, 3).size() != 1 || !copy.getColors(2, 2, 3).empty()) return 11;
         } else if (!std::strcmp(mode, "recarve_colored")) {
             // a coloured, painted model goes through the carve again: state comes back
             // as bit planes; colours and paint stay where voxels survive

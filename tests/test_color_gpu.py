@@ -65,6 +65,53 @@ def test_min_depth_is_bit_exact(arvx, oracle):
         assert np.float32(min(dd)) == depth[k]
 
 
+@pytest.mark.parametrize("z_range", [None, (5, 21)])
+def test_color_samples_are_the_lists_behind_the_vote(arvx, z_range):
+    """arvx_color_samples: the per-view samples Model::addColor would collect (reference
+    src/ColorReconstruction.h:44-60): validity, pixel and depth against the numpy restatement,
+    sample for sample; and both votes (closest: strict <, first view wins; average: rounded
+    mean) recomputed from the samples give the colours arvx_color voted."""
+    N, V, W, H = 32, 7, 160, 120
+    sc = scenes.syn.sphere_scene(N, V, W=W, H=H, with_images=True)
+    z0 = z_range[0] if z_range else 0
+    with arvx.Context(N, N, N, sc.voxel_size, z_range=z_range) as ctx:
+        ctx.set_views(sc.M, sc.masks, campos=sc.campos)
+        ctx.set_images(sc.images)
+        ctx.carve()
+        voted = {}
+        for mode in (0, 1):
+            ctx.color(mode)
+            voted[mode] = ctx.surface()
+        idx = voted[0][0]
+        assert len(idx) > 50 and np.array_equal(idx, voted[1][0])
+        # every coloured voxel, and a few that are not on the list (inside and far outside)
+        extra = np.array([0, N * N * 3 + 17, (N // 2) * (1 + N) + N * N * 4], np.int64)
+        ask = np.concatenate([idx, extra])
+        smp = ctx.color_samples(ask)
+        with pytest.raises(arvx.ArvxError):
+            ctx.color_samples(np.array([N * N * N], np.int64))
+    assert smp.shape == (len(ask), V)
+    x, y, z = ask % N, (ask // N) % N, ask // (N * N) + z0
+    for v in range(V):
+        inside, px, py = npr.project(sc.M[v], sc.voxel_size, x, y, z, W, H)
+        assert np.array_equal(smp["valid"][:, v].astype(bool), inside), f"view {v}: validity"
+        bgr = sc.images[v][py, px]
+        for name, ch in (("r", 2), ("g", 1), ("b", 0)):
+            assert np.array_equal(smp[name][:, v][inside], bgr[:, ch][inside]), f"view {v}: {name}"
+        d = npr.depth(sc.campos[v], sc.voxel_size, x, y, z)
+        assert np.array_equal(smp["depth"][:, v][inside], d[inside]), f"view {v}: depth"
+        assert not smp["depth"][:, v][~inside].any()
+    s = smp[:len(idx)]
+    ok = s["valid"].astype(bool)
+    assert ok.any(axis=1).all()  # a coloured voxel has at least one sample
+    rgb = np.stack([s["r"], s["g"], s["b"]], axis=2).astype(np.float32)
+    first_min = np.argmin(np.where(ok, s["depth"], np.inf), axis=1)  # first of equal minima
+    assert np.array_equal(rgb[np.arange(len(idx)), first_min], voted[0][1]), "closest colour"
+    n = ok.sum(axis=1).astype(np.float32)
+    mean = (np.where(ok[..., None], rgb, 0).sum(axis=1, dtype=np.float32) / n[:, None]).astype(np.float32)
+    assert np.array_equal(npr.round_half_away(mean).astype(np.float32), voted[1][1]), "average colour"
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_color_on_z_slabs_uses_halo(arvx, oracle, mode):
     """isInner needs the plane above and below a slab: recomputed locally as halo."""
