@@ -18,7 +18,7 @@ time.  The K timed steps are therefore dealt to `jobs` contexts, each on its own
 slot k % jobs): every step is still a whole step on a fresh model with its own derived views, all
 K are complete inside the timed region, and the final model of every slot is compared
 (`slots_agree`, `parity_vs_oracle`).  `value` / `ms_per_step` = K steps / wall time of that;
-`latency_ms_per_step` / `sequential_value` = the same step run one job after the other (K / 4
+`latency_ms_per_step` / `sequential_value` = the same step run one job after the other (K / 2
 steps, same timing frame), which is also where `carve_kernel_ms` (the carve alone),
 `views_kernel_ms` (the derivation) and the `roofline` come from: HIP events on the launch stream
 around single launches, recorded on five of those steps (the events themselves cost GPU time
@@ -497,8 +497,8 @@ def main():
         m = run_config(base, V, steps, warmup, collective, jobs=jobs)
         m["latency_ms"] = m["dt"] / steps * 1e3
         if jobs > 1 and not m["overflowed"]:
-            k = max(8, steps // 4)
-            q = run_config(base, V, k, min(warmup, 3), collective, jobs=1)
+            k = max(8, steps // 2)
+            q = run_config(base, V, k, min(warmup, 5), collective, jobs=1)
             m.update(kern_ms=q["kern_ms"], views_ms=q["views_ms"], ev_steps=q["ev_steps"],
                      latency_ms=q["dt"] / k * 1e3, latency_steps=k)
         return m
