@@ -1182,7 +1182,7 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         const bool dense = false;
 #endif
         if (dense)  // one workgroup per listed coarse tile and turn
-            hipLaunchKernelGGL(arvx::carve_classify_dense_kernel, dim3((unsigned)ncu * 4u), dim3(256),
+            hipLaunchKernelGGL(arvx::carve_classify_dense_kernel, dim3((unsigned)ncu * (unsigned)ARVX_DENSE_WGS_PER_CU), dim3(256),
                                0, ctx->stream, p);
         else
             hipLaunchKernelGGL(arvx::carve_classify_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, p);

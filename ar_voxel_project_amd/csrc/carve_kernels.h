@@ -793,7 +793,12 @@ __global__ __launch_bounds__(256, 8) void carve_classify_kernel(const CarveParam
 // lanes busy and a lane's box is formed once per unit.  The lanes OR their answers into LDS;
 // then every wave settles or queues a quarter of the unit's sub-tiles exactly as the kernel
 // above does (one record store per sub-tile).
-__global__ __launch_bounds__(256, 4) void carve_classify_dense_kernel(const CarveParams p) {
+// (6 workgroups per CU: 75 VGPRs, no scratch.  4: step +2 % at 512^3 and 768^3 -- fewer units in
+// flight for the same chain of dependent reads; 8: 64 VGPRs with 20 B of scratch, no better.)
+#ifndef ARVX_DENSE_WGS_PER_CU
+#define ARVX_DENSE_WGS_PER_CU 6
+#endif
+__global__ __launch_bounds__(256, ARVX_DENSE_WGS_PER_CU) void carve_classify_dense_kernel(const CarveParams p) {
     __shared__ unsigned long long s_mixed[kMaxChunks][64], s_fast[kMaxChunks][64];
     __shared__ unsigned s_flag[64];  // bit0: some view carves the sub-tile, bit1: some view sees all of it
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
