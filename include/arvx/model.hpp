@@ -251,6 +251,53 @@ class Model {
         paint_is_unseen_ = true;
     }
 
+    // src/Model.cpp:49-107: the debug mesh -- one unit cube (8 vertices, 6 quads in the voxel's
+    // colour) per voxel that is there and not inner, x outermost and z innermost, as OFF text.
+    // Written in two passes over the surface voxels instead of through two vectors.
+    bool WriteModel(const std::string &filename) const {
+        std::cout << "LOG - Debug: generating debug mesh from model..." << std::endl;
+        std::ofstream out(filename);
+        if (!out.is_open()) {
+            std::cerr << "LOG(ERR) - Debug: could not open file " << filename
+                      << ". Aborting mesh generation!" << std::endl;
+            return false;
+        }
+        struct Cube {
+            int x, y, z;
+            unsigned r, g, b;
+        };
+        std::vector<Cube> cubes;
+        for (int x = 0; x < getX(); x++)
+            for (int y = 0; y < getY(); y++)
+                for (int z = 0; z < getZ(); z++) {
+                    const Vec4f c = get(x, y, z);
+                    if (c(3) == 0 || isInner(x, y, z)) continue;
+                    cubes.push_back(Cube{x, y, z, (unsigned)c.x(), (unsigned)c.y(), (unsigned)c.z()});
+                }
+        out << "OFF" << std::endl;
+        out << cubes.size() * 8 << " " << cubes.size() * 6 << " 0" << std::endl;
+        // corner k of a cube: bit0 = +x ... in the reference's order id, r, u, h, ru, rh, uh, ruh
+        static const int corner[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1},
+                                         {1, 1, 0}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}};
+        for (const Cube &c : cubes)
+            for (const auto &d : corner)
+                out << (float)(c.x + d[0]) << " " << (float)(c.y + d[1]) << " " << (float)(c.z + d[2])
+                    << std::endl;
+        // front, back, left, right, top, bottom
+        static const int quad[6][4] = {{0, 2, 4, 1}, {3, 5, 7, 6}, {0, 2, 6, 3},
+                                       {1, 4, 7, 5}, {2, 6, 7, 4}, {0, 3, 5, 1}};
+        size_t base = 0;
+        for (const Cube &c : cubes) {
+            for (const auto &q : quad)
+                out << "4 " << base + q[0] << " " << base + q[1] << " " << base + q[2] << " "
+                    << base + q[3] << " " << c.r << " " << c.g << " " << c.b << std::endl;
+            base += 8;
+        }
+        out.close();
+        std::cout << "LOG - Debug: debug mesh written." << std::endl;
+        return true;
+    }
+
     std::string to_string() const {  // src/Model.cpp:20-34
         std::ostringstream ss;
         for (int z = 0; z < getZ(); z++) {

@@ -163,6 +163,12 @@ static int run_carve(const char *scene, const char *out, const char *mode) {
             model.handleUnseen();
             if (arvx::applyClosure(&model, 3) != 0) return 5;
             cells = arvx::marchingCubesCells(model);
+        } else if (!std::strcmp(mode, "debug_mesh")) {  // Model::WriteModel, src/Model.cpp:49-107
+            arvx::carve(intr, model, views);
+            arvx::reconstructClosestColor(intr, model, views);
+            model.handleUnseen();
+            if (!model.WriteModel(std::string(out) + ".off")) return 12;
+            if (model.WriteModel("/nonexistent-dir/x.off")) return 13;
         } else if (!std::strcmp(mode, "threads")) {
             // several jobs in flight from several host threads: every thread owns its models
             // (contexts share nothing; calls on ONE context are not thread safe, calls on

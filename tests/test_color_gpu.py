@@ -162,12 +162,21 @@ def test_color_matches_golden(arvx, name):
 def test_color_call_order_errors(arvx):
     sc = scenes.syn.sphere_scene(16, 3, W=96, H=72, with_images=True)
     with arvx.Context(16, 16, 16, sc.voxel_size) as ctx:
+        one = np.array([5], np.int64)
+        with pytest.raises(arvx.ArvxError):
+            ctx.selftest_view_tables(0, 96, 72)  # no views yet
         ctx.set_views(sc.M, sc.masks)  # no campos
         with pytest.raises(arvx.ArvxError):
+            ctx.selftest_view_tables(3, 96, 72)  # view 3 of 3
+        with pytest.raises(arvx.ArvxError):
             ctx.color(0)  # no images
+        with pytest.raises(arvx.ArvxError):
+            ctx.color_samples(one)  # no images
         ctx.set_images(sc.images)
         with pytest.raises(arvx.ArvxError):
             ctx.color(0)  # no campos
+        with pytest.raises(arvx.ArvxError):
+            ctx.color_samples(one)  # no campos
         ctx.set_views(sc.M, sc.masks, campos=sc.campos)
         ctx.set_images(sc.images)
         ctx.carve()
@@ -178,3 +187,8 @@ def test_color_call_order_errors(arvx):
         ctx.carve()  # state changed: colour result is stale
         with pytest.raises(arvx.ArvxError):
             ctx.surface()
+        assert ctx.color_samples(one).shape == (1, 3)  # (the samples do not depend on the state)
+        assert ctx.color_samples(np.zeros(0, np.int64)).shape == (0, 3)
+        ctx.set_views(sc.M, sc.masks, campos=sc.campos)  # new views drop the images
+        with pytest.raises(arvx.ArvxError):
+            ctx.color_samples(one)

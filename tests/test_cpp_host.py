@@ -126,6 +126,47 @@ def test_cpp_entry_points_match_oracle(host_bin, oracle, tmp_path, mode):
 
 
 @pytest.mark.gpu
+def test_cpp_debug_mesh(host_bin, oracle, tmp_path):
+    """Model::WriteModel (reference src/Model.cpp:49-107): a cube per voxel that is there and not
+    inner, x outermost, in the voxel's colour -- the text restated here from the oracle's model."""
+    X, Y, Z, V = 14, 11, 9, 4
+    sc = scenes.syn.sphere_scene(16, V, W=96, H=72, with_images=True)
+    s = np.float32(0.512 / 14)
+    st0 = np.ones((Z, Y, X), np.uint8)
+    scene, out = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
+    write_scene(scene, X, Y, Z, s, sc.K, sc.Rt, sc.masks, sc.images, st0)
+    r = subprocess.run([host_bin, "carve", scene, out, "debug_mesh"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "LOG - Debug: generating debug mesh from model..." in r.stdout
+    assert "LOG - Debug: debug mesh written." in r.stdout
+    assert "LOG(ERR) - Debug: could not open file /nonexistent-dir/x.off" in r.stderr
+    M = oracle.compose(sc.K, sc.Rt)
+    st = oracle.carve(X, Y, Z, s, M, sc.masks)
+    want = oracle.color(X, Y, Z, s, M, sc.campos, sc.images, 0, oracle.model_from_state(st))
+    want = oracle.handle_unseen(st, want).reshape(Z, Y, X, 4)
+    occ = np.pad(want[..., 3] != 0, 1, constant_values=False)
+    verts, faces = [], []
+    corner = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1)]
+    quads = [(0, 2, 4, 1), (3, 5, 7, 6), (0, 2, 6, 3), (1, 4, 7, 5), (2, 6, 7, 4), (0, 3, 5, 1)]
+    for x in range(X):
+        for y in range(Y):
+            for z in range(Z):
+                if not occ[z + 1, y + 1, x + 1]:
+                    continue
+                if (occ[z + 1, y + 1, x] and occ[z + 1, y + 1, x + 2] and occ[z + 1, y, x + 1] and
+                        occ[z + 1, y + 2, x + 1] and occ[z, y + 1, x + 1] and occ[z + 2, y + 1, x + 1]):
+                    continue
+                b = len(verts)
+                verts += [f"{x + dx} {y + dy} {z + dz}" for dx, dy, dz in corner]
+                c = want[z, y, x]
+                faces += [f"4 {b + q[0]} {b + q[1]} {b + q[2]} {b + q[3]} {int(c[0])} {int(c[1])} {int(c[2])}"
+                          for q in quads]
+    assert len(verts) > 100
+    text = "\n".join(["OFF", f"{len(verts)} {len(faces)} 0"] + verts + faces) + "\n"
+    assert open(out + ".off").read() == text
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["carve", "fast", "closest"])
 def test_cpp_entry_points_on_a_new_model(host_bin, oracle, tmp_path, mode):
     """A Model nobody touched goes to the GPU as arvx_state_reset, not as an upload."""
