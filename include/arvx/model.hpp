@@ -254,7 +254,7 @@ class Model {
     // src/Model.cpp:49-107: the debug mesh -- one unit cube (8 vertices, 6 quads in the voxel's
     // colour) per voxel that is there and not inner, x outermost and z innermost, as OFF text.
     // Written in two passes over the surface voxels instead of through two vectors.
-    bool WriteModel(const std::string &filename) const {
+    bool WriteModel(const std::string &filename = "./out/model_mesh.off") const {
         std::cout << "LOG - Debug: generating debug mesh from model..." << std::endl;
         std::ofstream out(filename);
         if (!out.is_open()) {
