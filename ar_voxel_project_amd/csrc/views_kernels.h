@@ -127,9 +127,9 @@ __global__ __launch_bounds__(256) void views_bits_generic_kernel(const uint8_t *
 // views_tile_sums_kernel takes three small arrays from the bit plane (per row and tile column
 // the row's count, per tile row and tile column the running count along c, per tile its total);
 // views_table_kernel sums what it needs of them (a few independent loads per lane) and writes the
-// table: per row three lane reads (the row's bits, its count to the left), the two halves of
-// v_mbcnt adding onto the running value, one add and the store -- six vector instructions for 64
-// entries.  The table's bytes are written once and never read back; the lanes of the last tile
+// table: per row one broadcast LDS read (the row's bits, its count to the left), the two halves
+// of v_mbcnt adding onto the running value, one add, the pointer and the store -- four vector
+// instructions for 64 entries.  The table's bytes are written once and never read back; the lanes of the last tile
 // column beyond X = W write into the row's padding (ld = 64 TJ), so that no store is predicated.
 // In both kernels lane r first LOADS row r's 64 bits (one round trip for the whole tile) and the
 // rows are then taken from the lanes one by one.  Four tiles per workgroup, one per wave.
@@ -164,6 +164,12 @@ __device__ __forceinline__ unsigned long long row_fg64(const uint32_t *__restric
 __device__ __forceinline__ unsigned long long tile_row_fg(const uint32_t *__restrict__ bits,
                                                           int bgWords, int W, int H, int y, int J) {
     return row_fg64(bits, bgWords, W, H, y, 64 * J);
+}
+
+// a wave's own LDS writes are visible to its own reads behind this (no workgroup barrier needed)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // four tiles per workgroup: this wave's tile, or false behind the last one
@@ -240,14 +246,18 @@ __global__ __launch_bounds__(256) void views_table_kernel(const uint32_t *__rest
     const unsigned off = 64u * (unsigned)J + (unsigned)lane;  // this lane's table column X
     if (I == 0) tab[off] = 0;                                   // row 0 of the table
     const int nrows = min(kTileRows, H - I * kTileRows);
-    const uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32);
+    // the rows go through LDS: one broadcast read per row (bits + count to the left) instead of
+    // three lane reads -- 4 vector instructions per row of 64 entries
+    __shared__ uint4 s_row[4][kTileRows];
+    uint4 *const rows = s_row[threadIdx.x >> 6];
+    rows[lane] = make_uint4((uint32_t)mine, (uint32_t)(mine >> 32), (uint32_t)left, 0u);
+    wave_lds_fence();
     uint32_t run = (uint32_t)(acc + lt);
     uint16_t *row = tab + (size_t)(I * kTileRows + 1) * ld;  // (wave-uniform: scalar registers)
 #pragma unroll 4
     for (int r = 0; r < nrows; ++r) {
-        const uint32_t flo = __builtin_amdgcn_readlane(lo, r), fhi = __builtin_amdgcn_readlane(hi, r);
-        run = __builtin_amdgcn_mbcnt_hi(fhi, __builtin_amdgcn_mbcnt_lo(flo, run));
-        run += (uint32_t)__builtin_amdgcn_readlane(left, r);
+        const uint4 f = rows[r];
+        run = __builtin_amdgcn_mbcnt_hi(f.y, __builtin_amdgcn_mbcnt_lo(f.x, run)) + f.z;
         row[off] = (uint16_t)run;
         row += ld;
     }
