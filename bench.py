@@ -322,8 +322,12 @@ def main():
         torch.cuda.set_stream(stream)
         d_masks = torch.from_numpy(sc.masks).to(dev)  # resident before timing
         torch.cuda.synchronize()  # (the upload ran on the null stream)
-        for c in ctxs:
+        for c in ctxs:  # set-up of a slot: its buffers exist before anything is counted
             c.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
+            if jobs > 1:  # (the W warm-up steps may not reach every slot)
+                c.reset()
+                c.carve(flags)
+        torch.cuda.synchronize()
         ex = None
         if world > 1 and collective != "none":
             ex = sharding.OccupancyExchange(X, Y, Z, world, rank, dev, mode=collective, buffers=2,
