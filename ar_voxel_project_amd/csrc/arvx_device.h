@@ -79,6 +79,7 @@ struct CarveParams {
     unsigned long long *coarseMixed;  // [ncoarse][nchunks] views to re-classify per sub-tile
     unsigned long long *coarseFg;     // [ncoarse][nchunks] views that see only foreground
     uint8_t *coarseCarved;            // [ncoarse] 0 undecided, 1 carved, 2 all seen, 3 none seen
+    int coarsePerWg;                  // coarse tiles per workgroup of carve_coarse_kernel
     int *undecidedList;               // [ncoarse] coarse tiles carve_classify_kernel walks
     int *undecidedCount;              // its length (this launch) ...
     int *undecidedCountNext;          // ... and the counter the next launch will use

@@ -193,29 +193,85 @@ __device__ __forceinline__ int coarse_classify(const CarveParams &p, const int c
     return any_carved ? 1 : (any_mixed ? 0 : (any_fg ? 2 : 3));
 }
 
-// Up to kCoarseWaves coarse tiles per workgroup (blockDim.x / 64), one wave each.  Lazy state (flags bit7): nothing
-// else happens to a decided tile -- no fill launch follows --, so the undecided ones go on the
-// classify kernels' list from here: collected in LDS, ONE append per workgroup (an append per
-// tile, ~450 at 512^3 on one counter, was 5 of this kernel's 11 us).
+// Up to kCoarseWaves coarse tiles per workgroup (p.coarsePerWg).  A lane is a (tile, view) PAIR:
+// the workgroup's tiles x views are dealt to the lanes densely (with one wave per tile and lane =
+// view, 36 views kept 36 of 64 lanes busy), the answers are OR-ed into LDS, and one thread per
+// tile writes its masks and its code.  Lazy state (flags bit7): nothing else happens to a decided
+// tile -- no fill launch follows --, so the undecided ones go on the classify kernels' list from
+// here: collected in LDS, ONE append per workgroup (an append per tile, ~450 at 512^3 on one
+// counter, was 5 of this kernel's 11 us).
 constexpr int kCoarseWaves = 16;
 __global__ __launch_bounds__(64 * kCoarseWaves) void carve_coarse_kernel(const CarveParams p) {
+    __shared__ float s_box[kCoarseWaves][6];
+    __shared__ unsigned long long s_mixed[kCoarseWaves][kMaxChunks], s_fg[kCoarseWaves][kMaxChunks];
+    __shared__ int s_carved[kCoarseWaves];
     __shared__ int s_ct[kCoarseWaves];
     __shared__ int s_n, s_base;
     coarse_reset_counters(p);
-    const int ct = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const bool listing = (p.flags & 128u) && p.undecidedList;  // workgroup-uniform
-    if (listing) {
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
+    const int cw = p.coarsePerWg;
+    const int ncoarse = p.coarseX * p.coarseY * p.coarseZ;
+    const int t0 = blockIdx.x * cw, nt = min(cw, ncoarse - t0);  // this workgroup's tiles
+    const bool listing = (p.flags & 128u) && p.undecidedList;    // workgroup-uniform
+    if ((int)threadIdx.x < nt) {
+        const int ct = t0 + threadIdx.x;
+        const int cx = ct % p.coarseX;
+        const int cy = (ct / p.coarseX) % p.coarseY;
+        const int cz = ct / (p.coarseX * p.coarseY);
+        const int cyN = 8 << p.cyShift, czN = 8 << p.czShift;
+        const int x0 = cx * kCoarseX, y0 = cy * cyN, z0 = cz * czN;
+        // (striped slabs: the box spans the foreign planes in between as well -- conservative)
+        const BoxW b = make_box(p.s, x0, min(x0 + kCoarseX - 1, p.X - 1), y0,
+                                min(y0 + cyN - 1, p.Y - 1), global_z(p, z0),
+                                global_z(p, min(z0 + czN - 1, p.Z - 1)));
+        float *o = s_box[threadIdx.x];
+        o[0] = b.wy0, o[1] = b.wy1, o[2] = b.wx0, o[3] = b.wx1, o[4] = b.wz0, o[5] = b.wz1;
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; ++c) s_mixed[threadIdx.x][c] = s_fg[threadIdx.x][c] = 0ull;
+        s_carved[threadIdx.x] = 0;
     }
-    if (ct < p.coarseX * p.coarseY * p.coarseZ) {
-        const int code = coarse_classify(p, ct, lane);
-        if (lane == 0) {
-            p.coarseCarved[ct] = (uint8_t)code;
-            if (listing && !(code == 1 || (code >= 2 && (p.flags & 4u))))
-                s_ct[atomicAdd(&s_n, 1)] = ct;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int V = p.v1 - p.v0;
+    const float rV = 1.0f / (float)V;
+    for (int q = threadIdx.x; q < nt * V; q += blockDim.x) {
+        // q = tile * V + view  (q < 16 * 256: the float quotient is off by at most one)
+        int tile = (int)((float)q * rV);
+        int view = q - tile * V;
+        if (view < 0) {
+            --tile;
+            view += V;
+        } else if (view >= V) {
+            ++tile;
+            view -= V;
         }
+        const float *sb = s_box[tile];
+        BoxW box;
+        box.wy0 = sb[0], box.wy1 = sb[1], box.wx0 = sb[2], box.wx1 = sb[3], box.wz0 = sb[4],
+        box.wz1 = sb[5];
+        const int myv = p.v0 + view;
+        const int cls = classify_box(p.M + 12 * myv, box, p.W, p.H, p.sat + (size_t)myv * p.satStride,
+                                     p.satW) & 3;
+        const unsigned long long bit = 1ull << (view & 63);
+        if (cls == kClsMixed) atomicOr(&s_mixed[tile][view >> 6], bit);
+        if (cls == kClsFg) atomicOr(&s_fg[tile][view >> 6], bit);
+        if (cls == kClsCarved) s_carved[tile] = 1;  // (any writer writes the same)
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nt) {
+        const int ct = t0 + threadIdx.x;
+        bool any_mixed = false, any_fg = false;
+        for (int c = 0; c < p.nchunks; ++c) {
+            const unsigned long long m = s_mixed[threadIdx.x][c], f = s_fg[threadIdx.x][c];
+            p.coarseMixed[(size_t)ct * p.nchunks + c] = m;
+            p.coarseFg[(size_t)ct * p.nchunks + c] = f;
+            any_mixed = any_mixed || m;
+            any_fg = any_fg || f;
+        }
+        // 1: some view carves the whole tile.  2 / 3: no view needs a closer look and none carves
+        // -- every voxel keeps its occupancy and is seen (2) or not even seen (3).  0: undecided.
+        const int code = s_carved[threadIdx.x] ? 1 : (any_mixed ? 0 : (any_fg ? 2 : 3));
+        p.coarseCarved[ct] = (uint8_t)code;
+        if (listing && !(code == 1 || (code >= 2 && (p.flags & 4u)))) s_ct[atomicAdd(&s_n, 1)] = ct;
     }
     if (listing) {
         __syncthreads();
