@@ -1,0 +1,58 @@
+"""bench.py as the driver runs it: the one-GPU line and -- rehearsed with two ranks on one GPU
+over gloo (ARVX_BENCH_ONE_GPU=1) -- the N > 1 line with every collective, several jobs in flight
+and the hand-off on its side streams.  Small grids: what is checked is the contract of the JSON
+line and that every merge holds the right planes, not the numbers."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def last_json_line(text):
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_one_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--grid", "128", "--steps", "9",
+                        "--warmup", "2", "--extra-grid", "0", "--no-workloads", "--no-ablation"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json_line(r.stdout)
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 9 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["config"]["jobs_in_flight"] == 4 and d["slots_agree"] is True
+    assert d["parity_vs_oracle"] is True
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["latency_ms_per_step"] > 0
+    assert d["roofline"]["kernel_ms"] > 0 and d["cpu_baseline"]["value"] > 0
+    assert d["vs_baseline"] is None and d["scaling"] == "weak"
+
+
+def test_two_rank_rehearsal_every_collective():
+    env = dict(os.environ, ARVX_BENCH_ONE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29531",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "128", "--steps", "9",
+                        "--warmup", "2", "--no-mgpu"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json_line(r.stdout)
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["config"]["jobs_in_flight"] == 4 and d["slots_agree"] is True
+    assert d["config"]["merged_plane_holds_rank0_planes"] is True
+    assert set(d["collectives"]) == {"compressed", "allreduce", "allgather"}
+    for name, c in d["collectives"].items():
+        assert "error" not in c, (name, c)
+        assert c["merge_ok"] is True, name
+        assert c["ms_per_step"] > 0 and c["exchange_bytes_per_rank"] > 0
+    assert d["collective_backend"]["ranks"] == 2
