@@ -560,7 +560,8 @@ def test_view_preprocessing_paths(arvx, oracle, W, H, C):
 
 @pytest.mark.parametrize("W,H,C", [(64, 3, 1), (640, 480, 1), (640, 480, 3), (65, 64, 1), (63, 40, 1),
                                    (127, 70, 3), (130, 129, 4), (192, 117, 1), (96, 64, 3),
-                                   (1000, 700, 1), (2000, 150, 1)])
+                                   (1000, 700, 1), (2000, 150, 1), (1024, 100, 1), (128, 65, 1),
+                                   (128, 65, 3)])
 def test_view_tables_against_numpy(arvx, W, H, C):
     """arvx_selftest_view_tables: the background bit plane and the summed-area table derived by
     arvx_set_views[_device] (csrc/views_kernels.h), entry for entry: bit = all channel bytes zero
