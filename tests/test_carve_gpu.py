@@ -389,6 +389,40 @@ def test_cull_matches_no_cull_bench_scene_512(arvx):
     assert abs(float((a & 1).mean()) - 0.1806) < 0.001
 
 
+def test_size_independent_properties_at_the_target_size_1024(arvx):
+    """1024^3 x 36 views: what carving guarantees whatever the size (reference
+    src/VoxelCarving.cpp:38-60: a voxel is carved iff SOME view shows background at its pixel, seen
+    iff SOME view has it inside the image) -- on the paths a fresh carve alone does not take:
+      * idempotence: carving the carved model again changes nothing (a model that is not fresh:
+        no lazy codes, the coarse fill kernel, records read before they are written);
+      * the views in two halves, first the second half then the first: the same model (order of
+        the views, state carried between calls);
+      * a Z slab is the same planes of the whole grid."""
+    N, V = 1024, 36
+    sc = scenes.syn.sphere_scene(N, V)
+    with arvx.Context(N, N, N, sc.voxel_size) as ctx:
+        ctx.set_views(sc.M, sc.masks)
+        ctx.carve(0)
+        occ, seen = ctx.download_planes()
+        ctx.carve(0)  # again, on the carved model
+        occ2, seen2 = ctx.download_planes()
+        assert np.array_equal(occ, occ2) and np.array_equal(seen, seen2), "idempotence"
+        ctx.reset()
+        ctx.carve_views(V // 2, V - V // 2)
+        ctx.carve_views(0, V // 2)
+        occ3, seen3 = ctx.download_planes()
+        assert np.array_equal(occ, occ3) and np.array_equal(seen, seen3), "views in two halves"
+    frac = np.bitwise_count(occ).sum() / N ** 3
+    assert abs(float(frac) - 0.1806) < 0.001
+    z0, z1 = 384, 648  # (not a multiple of the coarse tile's 32 planes at the upper end)
+    wpp = occ.size // N  # words per plane
+    with arvx.Context(N, N, N, sc.voxel_size, z_range=(z0, z1)) as ctx:
+        ctx.set_views(sc.M, sc.masks)
+        ctx.carve(0)
+        so, ss = ctx.download_planes()
+    assert np.array_equal(so, occ[z0 * wpp:z1 * wpp]) and np.array_equal(ss, seen[z0 * wpp:z1 * wpp]), "slab"
+
+
 def test_cull_matches_no_cull_target_config_1024(arvx):
     """The north-star target configuration, 1024^3 x 36 views: culled == brute force."""
     sc = scenes.syn.sphere_scene(1024, 36)
