@@ -688,6 +688,10 @@ static void state_changes(Ctx *ctx, bool keeps_paint) {
     ctx->closure_ready = false;
     if (!keeps_paint) ctx->paint_valid = false;
 }
+// ... and one that may occupy or un-see voxels (everything but carving, the greedy carve and
+// handleUnseen, which leave a tile that is carved and seen / seen as a whole as it is) also
+// drops what earlier carves settled for whole coarse tiles (CarveParams::cstate)
+static void state_rewritten(Ctx *ctx) { ctx->cstate_tiles = 0; }
 
 // Bytes of local planes [zl0, zl0 + nz), already in the staging buffer, into the records
 // (+ bit2 into the paint plane).  Ends with a host synchronisation.
@@ -731,6 +735,7 @@ static int records_into_bytes(Ctx *ctx, int zl0, int nz) {
 int arvx_state_reset(arvx_ctx *ctx) {
     ARVX_CHECK_CTX(ctx);
     state_changes(ctx, false);
+    state_rewritten(ctx);
     ctx->fresh_pending = true;  // materialised by need_rec, or never (a carve of a fresh model
     ctx->rec_valid = false;     // writes every record)
     ctx->lazy = false;
@@ -744,6 +749,7 @@ int arvx_state_upload(arvx_ctx *ctx, const uint8_t *state) {
     // paint of the owned planes is replaced; what the halo planes hold stays
     const bool halo_paint = ctx->paint_valid && ctx->nvox_ext != ctx->nvox;
     state_changes(ctx, halo_paint);
+    state_rewritten(ctx);
     ARVX_HIP(hipMemcpyAsync(ctx->owned(), state, ctx->nvox, hipMemcpyHostToDevice, ctx->stream));
     return bytes_into_records(ctx, ctx->z0 - ctx->ze0, ctx->z1 - ctx->z0);
 }
@@ -754,6 +760,7 @@ int arvx_state_upload_halo(arvx_ctx *ctx, const uint8_t *plane_below, const uint
     if (ctx->stripe_world > 1) return fail(ARVX_ERR_STATE, "striped slabs keep no halo planes");
     if (!ctx->d_state) ARVX_HIP(hipMalloc(&ctx->d_state, ctx->nvox_ext));
     state_changes(ctx, true);
+    state_rewritten(ctx);
     if (plane_below && ctx->ze0 < ctx->z0) {  // plane z0 - 1
         ARVX_HIP(hipMemcpyAsync(ctx->owned() - plane, plane_below, plane, hipMemcpyHostToDevice,
                                 ctx->stream));
@@ -781,6 +788,7 @@ int arvx_state_upload_planes(arvx_ctx *ctx, const uint32_t *occ, const uint32_t 
     if (!occ || !seen) return fail(ARVX_ERR_INVALID, "null plane");
     if (int mrc = need_rec(ctx)) return mrc;  // (halo planes keep what they hold)
     state_changes(ctx, false);
+    state_rewritten(ctx);
     const int nz = ctx->z1 - ctx->z0;
     const size_t nwords = (size_t)((ctx->X + 31) / 32) * ctx->Y * nz;
     if (int rc = ensure_scratch(ctx, 2 * nwords * sizeof(uint32_t) + 64)) return rc;
@@ -1047,6 +1055,7 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
     p.v1 = first + count;
     p.flags = (flags & 3u) | (fresh ? 4u : 0u);
     p.ccode = nullptr;  // (the carve reads records only where it has written them)
+    p.cstate = nullptr;
     p.nchunks = (count + 63) / 64;
     if (flags & ARVX_CARVE_STATS) ARVX_HIP(hipMemsetAsync(ctx->d_stats, 0, 64, ctx->stream));
     // rows of tiles (along x) are dealt to the XCDs cyclically: see carve_fused_kernel
@@ -1105,6 +1114,15 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
             ARVX_HIP(ctx->pool_ccode.reserve(ncoarse + 64));
             p.coarseCarved = (uint8_t *)ctx->pool_ccode.p;
             p.flags |= 128u;
+        }
+        // the model's own records: what this and earlier carves settle for whole coarse tiles
+        // is remembered (CarveParams::cstate); a fresh carve rewrites every entry
+        if (split && rec == ctx->d_rec) {
+            ARVX_HIP(ctx->pool_cstate.reserve(ncoarse + 64));
+            if (!fresh && ctx->cstate_tiles != ncoarse)
+                ARVX_HIP(hipMemsetAsync(ctx->pool_cstate.p, 0, ncoarse, ctx->stream));
+            p.cstate = (uint8_t *)ctx->pool_cstate.p;
+            ctx->cstate_tiles = 0;  // (valid again once the launches are out)
         }
         if (split) {
             int *lst = (int *)((uint8_t *)ctx->d_coarse + off_list);
@@ -1218,6 +1236,7 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         ctx->carve_layout = layout_when_done;
         ++ctx->carve_seq;
         if (lazy) ctx->lazy = true;
+        if (p.cstate) ctx->cstate_tiles = ncoarse;
         return ARVX_OK;
     }
 #ifdef ARVX_TIMELINE
@@ -1870,6 +1889,7 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
         hipLaunchKernelGGL(arvx::rec_or_bitgrid_kernel, dim3(gw), dim3(256), 0, ctx->stream, rp, 0,
                            g.Z, d_fill);
         ARVX_HIP(hipGetLastError());
+        state_rewritten(ctx);  // (voxels of tiles an earlier carve emptied may be occupied again)
         ctx->h_clo_index.resize((size_t)total);
         ARVX_HIP(hipMemcpyAsync(ctx->h_clo_index.data(), ctx->d_clo_index,
                                 (size_t)total * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

@@ -67,6 +67,8 @@ struct Ctx {
     // lazy state (arvx_device.h): after the carve of a fresh model the coarse tiles it settled
     // as a whole exist only as their code in `ccode`; their records are not written
     DevPool pool_ccode;
+    DevPool pool_cstate;         // per coarse tile: settled by earlier carves (CarveParams::cstate)
+    size_t cstate_tiles = 0;     // ... valid for this many tiles of the current layout (0: not)
     bool lazy = false;
     uint8_t *d_state = nullptr;  // byte staging, planes ze0..ze1-1 (lazy)
     uint8_t *owned() const { return d_state + (size_t)(z0 - ze0) * X * Y; }
@@ -156,6 +158,8 @@ struct Ctx {
         pool_xscratch.release();
         pool_paint.release();
         pool_ccode.release();
+        pool_cstate.release();
+        cstate_tiles = 0;
         pool_col_bits.release();
         pool_col_rank.release();
         pool_clo_bits.release();

@@ -80,6 +80,12 @@ struct CarveParams {
     unsigned long long *coarseFg;     // [ncoarse][nchunks] views that see only foreground
     uint8_t *coarseCarved;            // [ncoarse] 0 undecided, 1 carved, 2 all seen, 3 none seen
     int coarsePerWg;                  // coarse tiles per workgroup of carve_coarse_kernel
+    // what earlier carves of THIS model settled for whole coarse tiles, or null: bit0 = every
+    // voxel carved and seen, bit1 = every voxel seen.  Both are monotone under carving (a later
+    // view cannot un-carve or un-see), so a carve of a model that is not fresh skips the tiles
+    // with bit0 and does not revisit an all-foreground tile with bit1; the host drops the
+    // summary when something else writes the state (uploads, the closure).
+    uint8_t *cstate;
     int *undecidedList;               // [ncoarse] coarse tiles carve_classify_kernel walks
     int *undecidedCount;              // its length (this launch) ...
     int *undecidedCountNext;          // ... and the counter the next launch will use

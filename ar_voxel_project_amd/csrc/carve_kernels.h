@@ -271,6 +271,7 @@ __global__ __launch_bounds__(64 * kCoarseWaves) void carve_coarse_kernel(const C
         // -- every voxel keeps its occupancy and is seen (2) or not even seen (3).  0: undecided.
         const int code = s_carved[threadIdx.x] ? 1 : (any_mixed ? 0 : (any_fg ? 2 : 3));
         p.coarseCarved[ct] = (uint8_t)code;
+        if (p.cstate && (p.flags & 4u)) p.cstate[ct] = code == 1 ? 3 : (code == 2 ? 2 : 0);
         if (listing && !(code == 1 || (code >= 2 && (p.flags & 4u)))) s_ct[atomicAdd(&s_n, 1)] = ct;
     }
     if (listing) {
@@ -352,14 +353,29 @@ __global__ __launch_bounds__(256) void carve_coarse_fill_kernel(const CarveParam
     __shared__ int s_code;
     coarse_reset_counters(p);
     const int ct = blockIdx.x;
+    // what earlier carves settled for the whole tile (workgroup-uniform; zero without a summary)
+    const int known = (p.cstate && !(p.flags & 4u)) ? p.cstate[ct] : 0;
+    if (known & 1) {  // carved and seen as a whole before: nothing a view could change
+        if (threadIdx.x == 0) p.coarseCarved[ct] = 1;
+        return;
+    }
     if (threadIdx.x < 64) {
         const int code = coarse_classify(p, ct, threadIdx.x);
         if (threadIdx.x == 0) {
             p.coarseCarved[ct] = (uint8_t)code;
             s_code = code;
+            if (p.cstate) {
+                if (p.flags & 4u) p.cstate[ct] = code == 1 ? 3 : (code == 2 ? 2 : 0);
+                else if (code == 1) p.cstate[ct] = 3;
+                else if (code == 2) p.cstate[ct] = (uint8_t)(known | 2);  // (the classify kernel
+                // of this launch stores the seen bits)
+            }
         }
     }
     __syncthreads();
+    // On a model that is not fresh a tile no view looks into (3), or one that some view sees as
+    // a whole (2) when every voxel was seen before, has nothing left to do.
+    if (!(p.flags & 4u) && (s_code == 3 || (s_code == 2 && (known & 2)))) return;
     coarse_fill(p, ct, s_code);
 }
 

@@ -389,6 +389,68 @@ def test_cull_matches_no_cull_bench_scene_512(arvx):
     assert abs(float((a & 1).mean()) - 0.1806) < 0.001
 
 
+def _flat_views(X, Y, s):
+    """One view that looks along z: pixel (u, v) = voxel (x, y) (Model::toWord swaps x and y)."""
+    M = np.zeros((1, 3, 4), np.float32)
+    M[0, 0, 1] = 1.0 / s  # u = world[1] / s = x
+    M[0, 1, 0] = 1.0 / s  # v = world[0] / s = y
+    M[0, 2, 3] = 1.0
+    return M
+
+
+def test_tile_summary_is_dropped_when_something_else_writes_the_state(arvx, oracle):
+    """A carve remembers which coarse tiles (64 x 32 x 32 voxels) it emptied as a whole and a
+    later carve of the same model skips them (CarveParams::cstate).  Carving cannot undo that --
+    an upload or the closure can: the summary must not survive them.  A view along z with
+    background in the rows y < 32 empties the coarse tiles of those rows; then
+      * an upload of an all-occupied model and the same carve: emptied again, and
+      * the closure (a dilation: reference F10) puts voxels of row y = 31 back: carved again."""
+    X, Y, Z = 64, 96, 64
+    s = np.float32(0.01)
+    M = _flat_views(X, Y, s)
+    masks = np.full((1, Y, X), 255, np.uint8)
+    masks[0, :32, :] = 0
+    want1 = oracle.carve(X, Y, Z, s, M, masks)
+    assert (want1[:, :32, :] == 2).all() and (want1[:, 32:, :] == 3).all()
+    with arvx.Context(X, Y, Z, s) as ctx:
+        ctx.set_views(M, masks)
+        ctx.carve()
+        assert_same(ctx.download_state(), want1, "first carve")
+        ctx.carve()  # (nothing left to do in the emptied tiles)
+        assert_same(ctx.download_state(), want1, "second carve")
+        full = np.full((Z, Y, X), 1, np.uint8)
+        ctx.upload_state(full)
+        ctx.carve()
+        assert_same(ctx.download_state(), want1, "after an upload")
+        ctx.upload_planes(*planes_of(full))
+        ctx.carve()
+        assert_same(ctx.download_state(), want1, "after an upload of planes")
+        idx, _ = ctx.closure(3, True)
+        after = ctx.download_state()
+        filled = np.zeros(X * Y * Z, bool)
+        filled[idx] = True
+        filled = filled.reshape(Z, Y, X)
+        assert filled[:, 31, :].all() and not filled[:, :31, :].any()
+        assert ((after & 1) == 1)[filled].all()
+        ctx.carve()  # the voxels of row 31 project onto background: carved again
+        assert_same(ctx.download_state(), oracle.carve(X, Y, Z, s, M, masks, state=after), "after the closure")
+        assert ((ctx.download_state() & 1) == 0)[filled].all()
+
+
+def test_views_one_by_one_on_emptied_and_seen_tiles(arvx, oracle):
+    """The same summary, view by view on a grid with many coarse tiles: tiles emptied or seen as a
+    whole by earlier views are not revisited, the result is that of the oracle after every view."""
+    N, V = 160, 9
+    sc = scenes.syn.sphere_scene(N, V, W=320, H=240)
+    cur = np.full((N, N, N), 1, np.uint8)
+    with arvx.Context(N, N, N, sc.voxel_size) as ctx:
+        ctx.set_views(sc.M, sc.masks)
+        for i in list(range(V)) + [2, 0]:
+            ctx.carve_views(i, 1)
+            cur = oracle.carve_view(N, N, N, sc.voxel_size, sc.M[i], sc.masks[i], cur)
+            assert_same(ctx.download_state(), cur, f"view {i}")
+
+
 def test_size_independent_properties_at_the_target_size_1024(arvx):
     """1024^3 x 36 views: what carving guarantees whatever the size (reference
     src/VoxelCarving.cpp:38-60: a voxel is carved iff SOME view shows background at its pixel, seen
