@@ -1154,14 +1154,22 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
             // no workgroup per tile is needed when nothing is filled)
             // (16 tiles per workgroup where that still leaves a workgroup per compute unit:
             // fewer appends to the list's counter; 4 on small grids)
-            const int cw = ncoarse >= (size_t)16 * ncu ? arvx::kCoarseWaves : 4;
-            p.coarsePerWg = cw;
-            // (tile, view) pairs dealt to the lanes densely: as many waves as the pairs need
-            const size_t pairs = (size_t)cw * (size_t)(p.v1 - p.v0);
-            const unsigned threads = (unsigned)std::min<size_t>(64 * arvx::kCoarseWaves, (pairs + 63) / 64 * 64);
-            hipLaunchKernelGGL(arvx::carve_coarse_kernel, dim3((unsigned)((ncoarse + cw - 1) / cw)),
-                               dim3(std::max(threads, 64u)), 0, ctx->stream, p);
-            ARVX_HIP(hipGetLastError());
+            if (p.nchunks > arvx::kMaxChunks) {  // (only the fused kernel takes that many views)
+                hipLaunchKernelGGL(arvx::carve_coarse_wave_kernel, dim3((unsigned)((ncoarse + 3) / 4)),
+                                   dim3(256), 0, ctx->stream, p);
+                ARVX_HIP(hipGetLastError());
+            } else {
+                const int cw = ncoarse >= (size_t)16 * ncu ? arvx::kCoarseWaves : 4;
+                p.coarsePerWg = cw;
+                // (tile, view) pairs dealt to the lanes densely: as many waves as the pairs need
+                const size_t pairs = (size_t)cw * (size_t)(p.v1 - p.v0);
+                const unsigned threads =
+                    (unsigned)std::min<size_t>(64 * arvx::kCoarseWaves, (pairs + 63) / 64 * 64);
+                hipLaunchKernelGGL(arvx::carve_coarse_kernel,
+                                   dim3((unsigned)((ncoarse + cw - 1) / cw)),
+                                   dim3(std::max(threads, 64u)), 0, ctx->stream, p);
+                ARVX_HIP(hipGetLastError());
+            }
         }
     }
     // the statistics counters live in the row-mapped variant

@@ -282,6 +282,16 @@ __global__ __launch_bounds__(64 * kCoarseWaves) void carve_coarse_kernel(const C
     }
 }
 
+// More than 64 * kMaxChunks views (the fused kernel's pre-pass; its masks do not fit the LDS
+// arrays above): one wave per coarse tile, lane = view, chunk after chunk.
+__global__ __launch_bounds__(256) void carve_coarse_wave_kernel(const CarveParams p) {
+    coarse_reset_counters(p);
+    const int ct = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ct >= p.coarseX * p.coarseY * p.coarseZ) return;
+    const int code = coarse_classify(p, ct, threadIdx.x & 63);
+    if ((threadIdx.x & 63) == 0) p.coarseCarved[ct] = (uint8_t)code;
+}
+
 // Coarse tiles that the pre-pass decided are constant: carved + seen (code 1), or, for a
 // fresh model, untouched occupancy with (2) / without (3) the seen bit.  One workgroup writes
 // the coarse tile's records -- 16 KB in one piece (8 KB on striped slabs).
