@@ -1555,12 +1555,14 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
             // the items of the heavy weight classes get the SIMD's issue slots first
             // (512^3: -1.2 %, 1024^3: no change; the waves of a SIMD mostly hold items of
             // similar weight, and a view is bound by the SIMD's issue rate either way)
+#ifndef ARVX_NO_SETPRIO  // (A/B builds)
             switch (list >> 4) {
                 case 0: __builtin_amdgcn_s_setprio(3); break;
                 case 1: __builtin_amdgcn_s_setprio(2); break;
                 case 2: __builtin_amdgcn_s_setprio(1); break;
                 default: __builtin_amdgcn_s_setprio(0); break;
             }
+#endif
             const unsigned long long info = p.itemInfo[it];
             // (the first chunk's view masks are requested with the item, not after its set-up)
             unsigned long long mixed0 = p.itemMasks[it * p.nchunks * 2];
