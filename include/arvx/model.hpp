@@ -75,7 +75,7 @@ inline Vec4f unseen_color() { return Vec4f(204, 0, 0, 1); }    // UNSEEN_COLOR, 
 
 class Error : public std::runtime_error {
    public:
-    Error(int code, const std::string &what) : std::runtime_error(what), code(code) {}
+    Error(int rc, const std::string &what) : std::runtime_error(what), code(rc) {}
     int code;
 };
 
