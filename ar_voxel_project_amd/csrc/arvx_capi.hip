@@ -859,10 +859,26 @@ int arvx_state_device_ptr(arvx_ctx *ctx, void **ptr, size_t *bytes) {
     return ARVX_OK;
 }
 
+// X % 64 == 0 and an 8-byte aligned destination: the tile-wise pack (state_kernels.h)
+static int launch_pack_tiles(Ctx *ctx, int global, void *dev_words) {
+    if (int mrc = need_rec(ctx, true)) return mrc;
+    arvx::CarveParams g;
+    carve_geometry(ctx, g);
+    g.rec = ctx->d_rec;
+    const int zl0 = ctx->z0 - ctx->ze0, nz = ctx->z1 - ctx->z0;
+    const int ntz = ((zl0 + nz - 1) >> 3) - (zl0 >> 3) + 1;
+    const size_t tiles = (size_t)g.tilesX * g.tilesY * ntz;
+    hipLaunchKernelGGL(arvx::pack_occupancy_tile_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0,
+                       ctx->stream, g, zl0, nz, global, (unsigned long long *)dev_words);
+    ARVX_HIP(hipGetLastError());
+    return ARVX_OK;
+}
+
 int arvx_pack_occupancy(arvx_ctx *ctx, void *dev_words) {
     ARVX_CHECK_CTX(ctx);
     ExchangeStreamScope exchange_scope(ctx);
     if (!dev_words) return fail(ARVX_ERR_INVALID, "null dev_words");
+    if (ctx->X % 64 == 0 && (uintptr_t)dev_words % 8 == 0) return launch_pack_tiles(ctx, 0, dev_words);
     if (ctx->X % 32 == 0 && (uintptr_t)dev_words % 4 == 0) {
         // straight from the records: 2 bits per voxel in, 1 out
         if (int mrc = need_rec(ctx, true)) return mrc;
@@ -916,6 +932,8 @@ int arvx_pack_occupancy_global(arvx_ctx *ctx, void *dev_global_words) {
     if (!dev_global_words) return fail(ARVX_ERR_INVALID, "null dev_global_words");
     const size_t plane = (size_t)ctx->X * ctx->Y;
     if (plane % 64) return fail(ARVX_ERR_INVALID, "X*Y must be a multiple of 64");
+    if (ctx->X % 64 == 0 && (uintptr_t)dev_global_words % 8 == 0)
+        return launch_pack_tiles(ctx, 1, dev_global_words);
     if (ctx->X % 32 == 0) {
         if (int mrc = need_rec(ctx, true)) return mrc;
         arvx::CarveParams g;

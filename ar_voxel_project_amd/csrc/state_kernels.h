@@ -134,6 +134,40 @@ __global__ __launch_bounds__(256) void pack_occupancy_rec_kernel(const CarvePara
     out[(zo * p.Y + y) * wpr + k] = w;
 }
 
+// X % 64 == 0, 8-byte aligned output: one WAVE per tile of 64 x 8 x 8 voxels, lane = one of the
+// tile's 64 rows (y, z).  The four sub-tiles' occupancy entries of a row are four 2-byte loads
+// that a wave issues as four contiguous 128-byte pieces (the kernel above reads the same bytes
+// two per thread, 256 bytes apart, and does the tile's index arithmetic once per output word);
+// a lane writes its row's 64 voxels as one 8-byte word; four tiles along x per workgroup, so
+// that their pieces of a row meet in one line.  A tile of a settled coarse tile (lazy code) is
+// not read at all.
+__global__ __launch_bounds__(256) void pack_occupancy_tile_kernel(const CarveParams p, int zl0,
+                                                                  int nz, int global,
+                                                                  unsigned long long *__restrict__ out) {
+    const int tz0 = zl0 >> 3, ntz = ((zl0 + nz - 1) >> 3) - tz0 + 1;
+    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= (long long)p.tilesX * p.tilesY * ntz) return;
+    const int tx = (int)(t % p.tilesX), ty = (int)((t / p.tilesX) % p.tilesY);
+    const int tz = tz0 + (int)(t / ((long long)p.tilesX * p.tilesY));
+    const int lane = threadIdx.x & 63;  // row r = zrow * 8 + yrow, as in the records
+    const int y = ty * kTileY + (lane & 7), z = tz * kTileZ + (lane >> 3);
+    const int code = lazy_code(p, tx, ty, tz);  // (wave-uniform)
+    unsigned long long w = 0;
+#pragma unroll
+    for (int sw = 0; sw < 4; ++sw) {
+        uint32_t e;
+        if (code) {
+            e = lazy_occ(p, code, tx, ty, tz, sw, lane);
+        } else {
+            e = p.rec[rec_index(p, tx, ty, tz, sw) * kRecU16 + lane];
+        }
+        w |= (unsigned long long)(e & 0xffffu) << (16 * sw);
+    }
+    if (y >= p.Y || z < zl0 || z >= zl0 + nz) return;
+    const size_t zo = global ? (size_t)global_z(p, z) : (size_t)(z - zl0);
+    out[(zo * p.Y + y) * (size_t)(p.X >> 6) + tx] = w;
+}
+
 // The same for any X % 8 == 0 (e.g. the 648- and 816-wide grids of the 2- and 4-GPU weak
 // scaling): a byte of the flat packing holds eight voxels of ONE row; a thread assembles one
 // output word from its four bytes.  n_bytes = X * Y * nz / 8 (a multiple of 4 is not needed:
