@@ -15,6 +15,13 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def last_json_line(text):
     lines = [ln for ln in text.splitlines() if ln.startswith("{")]
     assert lines, text[-2000:]
@@ -40,7 +47,7 @@ def test_one_gpu_line():
 def test_two_rank_rehearsal_every_collective():
     env = dict(os.environ, ARVX_BENCH_ONE_GPU="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29531",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "128", "--steps", "9",
                         "--warmup", "2", "--no-mgpu"],
                        capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
