@@ -117,3 +117,36 @@ def test_c5_human_dataset_512_carve_colour_mc(arvx, oracle):
             depth = ctx.surface_depth()
             assert depth.shape == (len(idx),) and np.isfinite(depth).all()
             del want
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_weak_scaling_grids_one_rank(arvx, oracle, world):
+    """The grids bench.py --gpus N carves (sharding.grid_for: 640 x 640 x 656, 800 x 800 x 832,
+    1024^3 -- X not a multiple of 64 at N = 4), 36 views, as the bench cuts them: the first and the
+    last rank's 8-plane stripes and, for the plain all-gather, a contiguous slab; three stripes
+    of each against the oracle, and the packed occupancy (tile-wise or word-wise pack) against
+    the state it was packed from."""
+    import torch
+    from ar_voxel_project_amd import sharding
+    X, Y, Z = sharding.grid_for(world, 512)
+    sc = scenes.syn.sphere_scene(max(X, Y, Z), 36)
+    for rank in (0, world - 1):
+        for layout in ("striped", "slab"):
+            kw = ({"stripes": (world, rank)} if layout == "striped"
+                  else {"z_range": sharding.slab_of(Z, world, rank)})
+            with arvx.Context(X, Y, Z, sc.voxel_size, **kw) as ctx:
+                ctx.set_views(sc.M, sc.masks)
+                ctx.carve()
+                st = ctx.download_state()
+                planes = np.asarray(ctx.planes)
+                words = torch.zeros(X * Y * len(planes) // 64, dtype=torch.int64, device="cuda")
+                torch.cuda.synchronize()
+                ctx.pack_occupancy(words.data_ptr())
+                ctx.synchronize()
+            n = len(planes)
+            assert st.shape == (n, Y, X)
+            pick = np.r_[0:8, n // 2 // 8 * 8:n // 2 // 8 * 8 + 8, n - 8:n]
+            want = oracle.carve_planes(X, Y, sc.voxel_size, sc.M, sc.masks, planes[pick])
+            assert np.array_equal(st[pick], want), f"world {world} rank {rank} {layout}"
+            bits = np.unpackbits(words.cpu().numpy().view(np.uint8), bitorder="little")
+            assert np.array_equal(bits.reshape(n, Y, X), st & 1), f"pack: world {world} rank {rank} {layout}"
