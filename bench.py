@@ -34,9 +34,10 @@ N > 1   one rank per GPU; rank r carves Z slab r of a grid that holds N x 512^3
         by one kernel on the receivers) over striped, load-balanced slabs,
         --collective allgather for the plain in-place all-gather of contiguous slabs,
         --collective allreduce for the north star's all-reduce (striped slabs).
-        The hand-off of step k (pack, compress, collective, expand) runs on a second
-        stream beside step k + 1 (arvx_ctx_set_exchange_stream); every job's hand-off
-        is inside the timed region.
+        With several jobs in flight every slot hands its job over in its own stream (pack,
+        compress, collective, expand: the other slots' kernels run beside them); with
+        --jobs 1 the hand-off of step k runs on a second stream beside step k + 1
+        (arvx_ctx_set_exchange_stream).  Every job's hand-off is inside the timed region.
 
 The JSON line also carries `roofline` (algorithmic HBM bytes of SURVEY 8d / the
 carve kernel's launch time measured with HIP events on its own stream) and
@@ -328,10 +329,20 @@ def main():
                 c.reset()
                 c.carve(flags)
         torch.cuda.synchronize()
-        ex = None
+        # N > 1: the merge of the packed occupancy.  One job at a time: ONE exchange object with
+        # two packed buffers and the hand-off on a side stream (below).  Several jobs in flight:
+        # every slot has an exchange object of its own and hands its job over in its OWN stream
+        # -- no event between streams at all; the other slots' kernels run beside it
+        # (tools/rank_step_time.py: a rank's step at 8 GPUs without the collective, 4 jobs in
+        # flight: 91 us with two side streams and their events, 88 us this way; 134 us for one
+        # job at a time with the hand-off behind the carve, 120 us beside the next one).
+        own = jobs > 1
+        ex, exs = None, []
         if world > 1 and collective != "none":
-            ex = sharding.OccupancyExchange(X, Y, Z, world, rank, dev, mode=collective, buffers=2,
-                                            layout=layout, codec=ctx)
+            exs = [sharding.OccupancyExchange(X, Y, Z, world, rank, dev, mode=collective,
+                                              buffers=1 if own else 2, layout=layout, codec=ctxs[k])
+                   for k in range(jobs if own else 1)]
+            ex = exs[0]
         n_ev = max(1, min(5, steps // 4))  # timed steps that carry events, evenly spaced
         ev = {(2 * k + 1) * steps // (2 * n_ev): tuple(torch.cuda.Event(enable_timing=True)
                                                        for _ in range(3))
@@ -345,12 +356,10 @@ def main():
         # (tools/rank_step_time.py) -- goes to a stream of its own and runs beside the views
         # and the carve of job k + 1.  Two events order the streams: the pack waits for the
         # carve whose records it reads, the next carve for that pack.
-        # (With several jobs in flight: one exchange object with two packed buffers, used in
-        # turn, and one side stream per BUFFER -- whatever touches buffer b is ordered by its
-        # stream, the pack / compress / expand kernels of one job run beside the collective of
-        # the job before, and the collectives themselves are issued in job order, the same
+        # (Several jobs in flight: see above; the collectives are issued in job order, the same
         # order on every rank.)
-        sides = [torch.cuda.Stream(device=dev) for _ in range(2)] if ex is not None else None
+        sides = ([torch.cuda.Stream(device=dev) for _ in range(2)]
+                 if ex is not None and not own else None)
         packed = [None] * jobs  # per slot: recorded behind the slot's latest pack
 
         def step(i=None):
@@ -373,7 +382,16 @@ def main():
             ctx.carve(flags)
             if i is not None and EV >= 1:
                 ev[i][2].record(stream)
-            if ex is not None:
+            if ex is not None and own:
+                xs = exs[slot]
+                with torch.cuda.stream(stream):  # (the collective is ordered against this stream)
+                    xs.prepare(0, verify=False)  # the slot's previous exchange: wait, expand
+                    if collective == "compressed":
+                        ctx.pack_occupancy(xs.local[0].data_ptr())
+                    else:
+                        ctx.pack_occupancy_global(xs.full[0].data_ptr())
+                    xs.launch(0, async_op=True)
+            elif ex is not None:
                 b = nstep[0] % 2
                 side = sides[b]
                 carved = torch.cuda.Event()
@@ -393,7 +411,11 @@ def main():
             nstep[0] += 1
 
         def drain():
-            if ex is not None:
+            if ex is not None and own:
+                for k, xs in enumerate(exs):
+                    with torch.cuda.stream(streams[k]):
+                        xs.wait(0, verify=False)
+            elif ex is not None:
                 for b in range(2):
                     ctxs[0].set_exchange_stream(sides[b].cuda_stream)  # (the expand of buffer b)
                     ex.codec = ctxs[0]
@@ -417,7 +439,12 @@ def main():
                 step()
                 drain()
             # packets start at the worst-case size; size them to what this scene needs
-            packet_cap = ex.retune((nstep[0] - 1) % 2)
+            if own:  # (from the slot of the latest job; the same packets on every rank)
+                packet_cap = exs[(nstep[0] - 1) % jobs].retune(0)
+                for xs in exs:
+                    xs.cap = packet_cap
+            else:
+                packet_cap = ex.retune((nstep[0] - 1) % 2)
         barrier()
         torch.cuda.synchronize()
         try:
@@ -439,9 +466,10 @@ def main():
         kern_ms = (float(np.mean([b.elapsed_time(c) for _, b, c in ev.values()]))
                    if EV >= 1 and ev else float("nan"))
         occ = None
-        overflowed = bool(ex is not None and ex.overflowed())
+        overflowed = any(xs.overflowed() for xs in exs)
         # the slot of the LAST job: its planes are what the last exchange merged
         last = (nstep[0] - 1) % jobs
+        merged_plane = (exs[last].full[0] if own else ex.full[(nstep[0] - 1) % 2]) if ex is not None else None
         ctx = ctxs[last]
         st = ctx.download_state() if (rank == 0 or ex is not None) else None
         # every slot that ran a job must hold the same model
@@ -455,12 +483,12 @@ def main():
             cnt = torch.tensor([int((st & 1).sum())], dtype=torch.int64, device=dev)
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
             if rank == 0:
-                merged = ex.full[(nstep[0] - 1) % 2].cpu().numpy().view(np.uint64)
+                merged = merged_plane.cpu().numpy().view(np.uint64)
                 merged_count_ok = bool(int(np.bitwise_count(merged).sum()) == int(cnt.item()))
         if rank == 0:
             occ = float((st & 1).mean())
             if ex is not None:  # the merged plane must hold this rank's planes
-                got = ex.full[(nstep[0] - 1) % 2].cpu().numpy().view(np.uint8)
+                got = merged_plane.cpu().numpy().view(np.uint8)
                 got = got.reshape(Z, X * Y // 8)[ctx.planes]
                 mine = np.packbits((st.reshape(len(ctx.planes), -1) & 1).astype(np.uint8),
                                    axis=1, bitorder="little")

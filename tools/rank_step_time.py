@@ -93,3 +93,59 @@ for rank in (0, world // 2):
           f"step {b:.1f} us", flush=True)
     ctx.set_exchange_stream(0)
     ctx.close()
+
+    # ... and with several jobs in flight (bench.py --jobs): (A) the hand-offs on two side streams
+    # as bench.py had them at first, one per packed buffer, ordered against the slots' streams by
+    # events; (B) every slot does its own hand-off in its own stream, no event at all
+    def run_slots(variant, slots=4, steps=120):
+        cs = [capi.Context(X, Y, Z, sc.voxel_size, stripes=(world, rank)) for _ in range(slots)]
+        sts = [torch.cuda.Stream(device=dev) for _ in range(slots)]
+        for c, st in zip(cs, sts):
+            c.set_stream(st.cuda_stream)
+            c.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
+            c.reset()
+            c.carve()
+        nb = 2 if variant == "A" else slots
+        locals_ = [torch.zeros(n64, dtype=torch.int64, device=dev) for _ in range(nb)]
+        pkss = [torch.zeros(world * S, dtype=torch.int64, device=dev) for _ in range(nb)]
+        fulls = [torch.zeros(n64 * world, dtype=torch.int64, device=dev) for _ in range(nb)]
+        sides = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        packed = [None] * slots
+        best = None
+        for rep in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                s_, c, st = k % slots, cs[k % slots], sts[k % slots]
+                c.reset()
+                c.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
+                if variant == "A":
+                    b = k % 2
+                    if packed[s_] is not None:
+                        st.wait_event(packed[s_])
+                    c.carve()
+                    carved = torch.cuda.Event()
+                    carved.record(st)
+                    c.set_exchange_stream(sides[b].cuda_stream)
+                    sides[b].wait_event(carved)
+                    c.pack_occupancy(locals_[b].data_ptr())
+                    packed[s_] = torch.cuda.Event()
+                    packed[s_].record(sides[b])
+                else:
+                    b = s_
+                    c.carve()
+                    c.pack_occupancy(locals_[b].data_ptr())
+                c.occupancy_compress(locals_[b].data_ptr(), n64, pkss[b].data_ptr(), cap)
+                c.occupancy_expand_striped(pkss[b].data_ptr(), world, n64, cap, wpg, fulls[b].data_ptr(),
+                                           flag.data_ptr())
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - t0) / steps * 1e6
+            best = us if best is None or us < best else best
+        for c in cs:
+            c.set_exchange_stream(0)
+            c.close()
+        return best
+
+    for _ in range(2):
+        print(f"world {world} rank {rank}: 4 jobs in flight, per step: hand-offs on two side streams "
+              f"{run_slots('A'):.1f} us, in the slot's own stream {run_slots('B'):.1f} us", flush=True)
