@@ -124,6 +124,24 @@ void release_stream(int device, hipStream_t s) {  // s: synchronised by the call
 
 // ---- bit-plane helpers (bitplane_kernels.h) ----------------------------------------------
 
+// After a synchronisation of ctx->stream: did a kernel that waits for other workgroups give up
+// (arvx_ctx.h, h_fault)?  The results of that launch are then undefined.
+static int check_fault(Ctx *ctx) {
+    if (!ctx->h_fault || !*ctx->h_fault) return ARVX_OK;
+    const unsigned what = *ctx->h_fault;
+    *ctx->h_fault = 0u;
+    ctx->vstrip_key = 0;   // the ticket counters no longer match the launches: start over
+    ctx->carve_layout = 0;
+    return fail(ARVX_ERR_HIP, "a kernel gave up waiting for another workgroup (mark %u): the "
+                "results of the calls since the last synchronisation are undefined", what);
+}
+
+#define ARVX_SYNC(ctx)                                        \
+    do {                                                      \
+        ARVX_HIP(hipStreamSynchronize((ctx)->stream));        \
+        if (int arvx_f_ = check_fault(ctx)) return arvx_f_;   \
+    } while (0)
+
 static int ensure_scratch(Ctx *ctx, size_t need) {
     if (ctx->scratch_bytes >= need) return ARVX_OK;
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -171,7 +189,7 @@ static int bit_compact_count(Ctx *ctx, const unsigned long long *bits, size_t nw
     ARVX_HIP(hipGetLastError());
     ARVX_HIP(hipMemcpyAsync(total, d_off + nblk, sizeof *total, hipMemcpyDeviceToHost,
                             ctx->stream));
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ARVX_SYNC(ctx);
     return ARVX_OK;
 }
 
@@ -199,7 +217,7 @@ static int selftest_xyz(Ctx *ctx, int64_t n, const int32_t *xyz, size_t out_floa
     ARVX_HIP(hipGetLastError());
     ARVX_HIP(hipMemcpyAsync(out, d_out, out_floats * sizeof(float), hipMemcpyDeviceToHost,
                             ctx->stream));
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ARVX_SYNC(ctx);
     return ARVX_OK;
 }
 
@@ -300,6 +318,15 @@ int arvx_ctx_create_slab_halo(arvx_ctx **out, int device, int X, int Y, int Z, f
         arvx_ctx_destroy(c);
         return arvx::fail_hip(e, "hipMalloc(stats)", __FILE__, __LINE__);
     }
+    e = hipHostMalloc((void **)&c->h_fault, 64, hipHostMallocMapped);
+    if (e == hipSuccess) {
+        *c->h_fault = 0u;
+        e = hipHostGetDevicePointer((void **)&c->d_fault, c->h_fault, 0);
+    }
+    if (e != hipSuccess) {
+        arvx_ctx_destroy(c);
+        return arvx::fail_hip(e, "hipHostMalloc(fault word)", __FILE__, __LINE__);
+    }
     c->fresh_pending = true;  // a fresh Model exists only as this flag: see need_rec
     e = hipMemsetAsync(c->d_stats, 0, 64, c->stream);
     if (e != hipSuccess) {
@@ -351,6 +378,7 @@ int arvx_ctx_destroy(arvx_ctx *ctx) {
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_coarse) (void)hipFree(ctx->d_coarse);
+    if (ctx->h_fault) (void)hipHostFree(ctx->h_fault);
     if (ctx->own_stream) {
         (void)hipStreamSynchronize(ctx->own_stream);
         release_stream(ctx->device, ctx->own_stream);
@@ -361,7 +389,7 @@ int arvx_ctx_destroy(arvx_ctx *ctx) {
 
 int arvx_ctx_set_stream(arvx_ctx *ctx, void *hip_stream) {
     ARVX_CHECK_CTX(ctx);
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ARVX_SYNC(ctx);
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     // the carve's alternating list counters are zeroed by the PREVIOUS carve in stream order:
     // on another stream they start over (launch_carve zeroes both when the layout is unset)
@@ -378,7 +406,7 @@ int arvx_ctx_set_exchange_stream(arvx_ctx *ctx, void *hip_stream) {
 int arvx_ctx_synchronize(arvx_ctx *ctx) {
     ARVX_CHECK_CTX(ctx);
     ARVX_HIP(hipStreamSynchronize(ctx->stream));
-    return ARVX_OK;
+    return check_fault(ctx);
 }
 
 int arvx_ctx_voxels(const arvx_ctx *ctx, int64_t *count) {
@@ -412,7 +440,9 @@ static int views_common(Ctx *ctx, int V, const float *M, const float *campos, in
     ctx->H = H;
     // one word more than the pixels need: bit 32 * (bgWords - 1) is a background bit that is
     // always 0, which the block-mapped exact kernel reads for voxels outside the image
-    ctx->bgWords = (int)(((size_t)W * H + 31) / 32) + 1;
+    // (padded to whole 128-byte lines per view: views_strip_kernel writes a view's plane as
+    // aligned 8-byte words and whole lines; only the last word is ever read as "always zero")
+    ctx->bgWords = (int)(((((size_t)W * H + 31) / 32 + 1) + 31) / 32 * 32);
     // summed-area table (views_kernels.h): (H + 1) rows of W + 1 entries, the rows padded to
     // whole 128-byte lines so that the table kernel's stores are line-aligned
     ctx->satW = (W + 1 + 63) / 64 * 64;  // (two-byte entries: 64 per 128-byte line)
@@ -457,6 +487,33 @@ static int views_common(Ctx *ctx, int V, const float *M, const float *campos, in
 static int views_preprocess(Ctx *ctx, const uint8_t *d_masks, int C) {
     const int npix = ctx->W * ctx->H;
     ARVX_HIP(hipGetLastError());  // anything stale would be blamed on the launches below
+    // one-channel masks with rows of whole 64-pixel tiles: ONE launch, a workgroup per strip of
+    // 64 rows (views_kernels.h, views_strip_kernel); every other format: the three launches below
+    static const bool three_launches = experiment_flag("ARVX_VIEWS_THREE_LAUNCHES");
+    if (C == 1 && ctx->W % 64 == 0 && ctx->W / 64 + 1 <= arvx::kStripMaxWaves && ctx->H <= 4096 &&
+        ((uintptr_t)d_masks & 15u) == 0 && !three_launches) {
+        const int TIs = (ctx->H + 63) / 64;
+        // ticket counters (one per view, never reset) + the strips' published column counts;
+        // zeroed once per layout (the tickets count launches from there)
+        const size_t G = (size_t)ctx->W / 2;
+        const size_t off_gran = ((size_t)ctx->V * sizeof(unsigned long long) + 255) / 256 * 256;
+        const size_t vbytes = off_gran + (size_t)ctx->V * TIs * G * sizeof(unsigned long long);
+        const size_t key = ((size_t)ctx->V << 40) ^ ((size_t)TIs << 24) ^ G;
+        if (ctx->vstrip_key != key || ctx->pool_vstrip.cap < vbytes) {
+            ARVX_HIP(ctx->pool_vstrip.reserve(vbytes));
+            ARVX_HIP(hipMemsetAsync(ctx->pool_vstrip.p, 0, vbytes, ctx->stream));
+            ctx->vstrip_key = key;
+        }
+        unsigned long long *ctr = (unsigned long long *)ctx->pool_vstrip.p;
+        unsigned long long *gran = (unsigned long long *)((uint8_t *)ctx->pool_vstrip.p + off_gran);
+        hipLaunchKernelGGL(arvx::views_strip_kernel, dim3(TIs, ctx->V), dim3(64 * (ctx->W / 64 + 1)),
+                           0, ctx->stream, d_masks, ctx->W, ctx->H, TIs, ctx->d_bg, ctx->bgWords,
+                           ctx->d_sat, ctx->satStride, ctx->satW, ctr, gran, ctx->d_fault);
+        ARVX_HIP(hipGetLastError());
+        ctx->views_ready = true;
+        ctx->cameras_ready = true;
+        return ARVX_OK;
+    }
     if (C == 1 && npix % 32 == 0 && ((uintptr_t)d_masks & 15u) == 0) {
         hipLaunchKernelGGL(arvx::views_bits16_kernel, dim3((npix / 16 + 255) / 256, ctx->V),
                            dim3(256), 0, ctx->stream, d_masks, npix, ctx->d_bg, ctx->bgWords);
@@ -498,7 +555,7 @@ int arvx_set_views(arvx_ctx *ctx, int V, const float *M, const float *campos,
     if (!masks) {  // cameras only: enough for arvx_color
         if (int rc0 = views_common(ctx, V, M, campos, W, H, C > 0 ? C : 1)) return rc0;
         ctx->cameras_ready = true;
-        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+        ARVX_SYNC(ctx);
         return ARVX_OK;
     }
     if (W >= 1 && C >= 1 && stride < (size_t)W * C)
@@ -521,7 +578,7 @@ int arvx_set_views(arvx_ctx *ctx, int V, const float *M, const float *campos,
     }
     rc = views_preprocess(ctx, d_raw, C);
     if (rc) return rc;
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));  // host buffers may go away
+    ARVX_SYNC(ctx);  // host buffers may go away
     return ARVX_OK;
 }
 
@@ -600,7 +657,7 @@ int arvx_undistort(arvx_ctx *ctx, int V, const uint8_t *const *src, int W, int H
     for (int i = 0; i < V; ++i)
         ARVX_HIP(hipMemcpy2DAsync(dst[i], stride, d_dst + img * i, rowb, rowb, H,
                                   hipMemcpyDeviceToHost, ctx->stream));
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ARVX_SYNC(ctx);
     return ARVX_OK;
 }
 
@@ -713,7 +770,7 @@ static int bytes_into_records(Ctx *ctx, int zl0, int nz) {
     ARVX_HIP(hipGetLastError());
     int any = 0;
     ARVX_HIP(hipMemcpyAsync(&any, d_any, sizeof any, hipMemcpyDeviceToHost, ctx->stream));
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));  // (also: the host bytes may go away)
+    ARVX_SYNC(ctx);  // (also: the host bytes may go away)
     ctx->paint_valid = had || any != 0;
     return ARVX_OK;
 }
@@ -779,7 +836,7 @@ int arvx_state_download(arvx_ctx *ctx, uint8_t *state) {
     if (!state) return fail(ARVX_ERR_INVALID, "null state");
     if (int mrc = records_into_bytes(ctx, ctx->z0 - ctx->ze0, ctx->z1 - ctx->z0)) return mrc;
     ARVX_HIP(hipMemcpyAsync(state, ctx->owned(), ctx->nvox, hipMemcpyDeviceToHost, ctx->stream));
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ARVX_SYNC(ctx);
     return ARVX_OK;
 }
 
@@ -801,7 +858,7 @@ int arvx_state_upload_planes(arvx_ctx *ctx, const uint32_t *occ, const uint32_t 
     hipLaunchKernelGGL(arvx::rec_from_planes_kernel, dim3((unsigned)((nwords + 255) / 256)),
                        dim3(256), 0, ctx->stream, g, ctx->z0 - ctx->ze0, nz, d_occ, d_seen);
     ARVX_HIP(hipGetLastError());
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));  // the host planes may go away
+    ARVX_SYNC(ctx);  // the host planes may go away
     return ARVX_OK;
 }
 
@@ -821,7 +878,7 @@ int arvx_state_download_planes(arvx_ctx *ctx, uint32_t *occ, uint32_t *seen) {
     ARVX_HIP(hipGetLastError());
     ARVX_HIP(hipMemcpyAsync(occ, d_occ, nwords * 4, hipMemcpyDeviceToHost, ctx->stream));
     ARVX_HIP(hipMemcpyAsync(seen, d_seen, nwords * 4, hipMemcpyDeviceToHost, ctx->stream));
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ARVX_SYNC(ctx);
     return ARVX_OK;
 }
 
@@ -1313,7 +1370,7 @@ int arvx_get_stats(arvx_ctx *ctx, arvx_stats *out) {
     if (!out) return fail(ARVX_ERR_INVALID, "null out");
     unsigned long long h[8];
     ARVX_HIP(hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ARVX_SYNC(ctx);
     memset(out, 0, sizeof *out);
     out->subtiles = h[0];
     out->subtiles_carved = h[1];
@@ -1371,7 +1428,7 @@ int arvx_set_images(arvx_ctx *ctx, const uint8_t *const *images, size_t stride) 
             ARVX_HIP(hipMemcpy2DAsync(ctx->d_images + img * i, rowb, images[i], stride, rowb,
                                       ctx->H, hipMemcpyHostToDevice, ctx->stream));
     }
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ARVX_SYNC(ctx);
     ctx->images_ready = true;
     ctx->color_ready = false;
     ctx->closure_ready = false;
@@ -1462,14 +1519,14 @@ int arvx_color(arvx_ctx *ctx, int mode) {
                                 (size_t)total * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         ARVX_HIP(hipMemcpyAsync(ctx->h_surf_has.data(), ctx->d_surf_has, (size_t)total,
                                 hipMemcpyDeviceToHost, ctx->stream));
-        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+        ARVX_SYNC(ctx);
     }
     size_t own_lo, own_hi;
     long long own_base;
     owned_part(ctx, ctx->h_surf_index, own_lo, own_hi, own_base);
     unsigned long long sv = (unsigned long long)(own_hi - own_lo);  // surface voxels of the owned planes
     ARVX_HIP(hipMemcpyAsync(ctx->d_stats + 4, &sv, sizeof sv, hipMemcpyHostToDevice, ctx->stream));
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ARVX_SYNC(ctx);
     ctx->color_ready = true;
     return ARVX_OK;
 }
@@ -1514,7 +1571,7 @@ int arvx_color_samples(arvx_ctx *ctx, int64_t n, const int64_t *index, arvx_colo
                            d_idx, d_out);
     ARVX_HIP(hipGetLastError());
     ARVX_HIP(hipMemcpyAsync(out, d_out, total * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ARVX_SYNC(ctx);
     return ARVX_OK;
 }
 
@@ -1538,7 +1595,7 @@ static int surface_fetch(Ctx *ctx, std::vector<float> &rgb, std::vector<float> &
                                 hipMemcpyDeviceToHost, ctx->stream));
         ARVX_HIP(hipMemcpyAsync(depth.data(), ctx->d_surf_depth, depth.size() * sizeof(float),
                                 hipMemcpyDeviceToHost, ctx->stream));
-        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+        ARVX_SYNC(ctx);
     }
     return ARVX_OK;
 }
@@ -1709,7 +1766,7 @@ int arvx_selftest_view_tables(arvx_ctx *ctx, int view, uint32_t *bg_bits, uint16
         ARVX_HIP(hipMemcpyAsync(table, ctx->d_sat + (size_t)view * ctx->satStride,
                                 (size_t)ctx->satStride * sizeof(uint16_t), hipMemcpyDeviceToHost,
                                 ctx->stream));
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ARVX_SYNC(ctx);
     return ARVX_OK;
 }
 
@@ -1730,7 +1787,7 @@ int arvx_selftest_round(arvx_ctx *ctx, int64_t *mismatches) {
     }
     unsigned long long bad = 0;
     ARVX_HIP(hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ARVX_SYNC(ctx);
     *mismatches = (int64_t)bad;
     return ARVX_OK;
 }
@@ -1741,7 +1798,7 @@ extern "C" int arvx_debug_timeline(arvx_ctx *ctx, unsigned long long *out, int64
     ARVX_CHECK_CTX(ctx);
     *n = ctx->timeline_n;
     if (out && ctx->d_timeline) {
-        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+        ARVX_SYNC(ctx);
         ARVX_HIP(hipMemcpy(out, ctx->d_timeline, (size_t)ctx->timeline_n * ctx->timeline_rec,
                            hipMemcpyDeviceToHost));
     }
@@ -1784,7 +1841,7 @@ int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const flo
                            ctx->stream, (const float *)ctx->d_scratch, (long long)n,
                            ctx->d_surf_rgba);
         ARVX_HIP(hipGetLastError());
-        ARVX_HIP(hipStreamSynchronize(ctx->stream));  // (the scratch buffer is reused below)
+        ARVX_SYNC(ctx);  // (the scratch buffer is reused below)
         ARVX_HIP(hipMemsetAsync(ctx->d_surf_depth, 0, (size_t)n * sizeof(float), ctx->stream));
         ARVX_HIP(hipMemsetAsync(ctx->d_surf_has, 1, (size_t)n, ctx->stream));
         // the list's plane + ranks (what arvx_color leaves behind)
@@ -1809,7 +1866,7 @@ int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const flo
         if (int rc = bit_compact_write(ctx, bits, nw, gown, d_off, nullptr,
                                        (arvx::SparseWord *)ctx->pool_col_rank.p))
             return rc;
-        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+        ARVX_SYNC(ctx);
     }
     ctx->color_ready = true;
     return ARVX_OK;
@@ -1919,7 +1976,7 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
         ctx->h_clo_index.resize((size_t)total);
         ARVX_HIP(hipMemcpyAsync(ctx->h_clo_index.data(), ctx->d_clo_index,
                                 (size_t)total * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+        ARVX_SYNC(ctx);
     }
     ctx->closure_ready = true;
     ctx->closure_unseen = apply_unseen ? 1 : 0;
@@ -1948,7 +2005,7 @@ int arvx_closure_download(arvx_ctx *ctx, int64_t *index, float *rgba) {
     if (hi > lo) {
         ARVX_HIP(hipMemcpyAsync(rgba, (const float4 *)ctx->d_clo_rgba + lo,
                                 (hi - lo) * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+        ARVX_SYNC(ctx);
     }
     return ARVX_OK;
 }
@@ -2009,14 +2066,14 @@ int arvx_mc_cells(arvx_ctx *ctx, int64_t *count) {
     long long total = 0;
     ARVX_HIP(hipMemcpyAsync(&total, d_boff + nsb, sizeof total, hipMemcpyDeviceToHost,
                             ctx->stream));
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ARVX_SYNC(ctx);
     if (total > 0) {
         ARVX_HIP(ctx->pool_mc_cells.reserve((size_t)total * sizeof(int4)));
         ctx->d_mc_cells = (void *)ctx->pool_mc_cells.p;
         hipLaunchKernelGGL(arvx::mc_write_kernel, dim3(nblk), dim3(256), 0, ctx->stream, mp, d_off,
                            (int4 *)ctx->d_mc_cells);
         ARVX_HIP(hipGetLastError());
-        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+        ARVX_SYNC(ctx);
     }
     ctx->mc_count = total;
     ctx->mc_ready = true;
@@ -2031,7 +2088,7 @@ int arvx_mc_cells_download(arvx_ctx *ctx, int32_t *cells) {
     if (ctx->mc_count) {
         ARVX_HIP(hipMemcpyAsync(cells, ctx->d_mc_cells, (size_t)ctx->mc_count * sizeof(int4),
                                 hipMemcpyDeviceToHost, ctx->stream));
-        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+        ARVX_SYNC(ctx);
     }
     return ARVX_OK;
 }
@@ -2085,7 +2142,7 @@ int arvx_mc_mesh(arvx_ctx *ctx, int apply_unseen, int64_t *triangles) {
     long long total = 0;
     ARVX_HIP(hipMemcpyAsync(&total, d_boff + nsb, sizeof total, hipMemcpyDeviceToHost,
                             ctx->stream));
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ARVX_SYNC(ctx);
     if (total > 0) {
         ARVX_HIP(ctx->pool_mesh_verts.reserve((size_t)total * 9 * sizeof(float)));
         ARVX_HIP(ctx->pool_mesh_rgb.reserve((size_t)total * 6 * sizeof(unsigned)));  // face records
@@ -2118,7 +2175,7 @@ int arvx_mc_mesh_download(arvx_ctx *ctx, float *verts, uint32_t *face_rgb) {
         // r, g, b of the 24-byte face records
         ARVX_HIP(hipMemcpy2DAsync(face_rgb, 12, (const uint8_t *)ctx->pool_mesh_rgb.p + 12, 24, 12,
                                   (size_t)ctx->mesh_tris, hipMemcpyDeviceToHost, ctx->stream));
-        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+        ARVX_SYNC(ctx);
     }
     return ARVX_OK;
 }
@@ -2131,7 +2188,7 @@ int arvx_mc_mesh_download_faces(arvx_ctx *ctx, float *verts, uint32_t *faces) {
                                 hipMemcpyDeviceToHost, ctx->stream));
         ARVX_HIP(hipMemcpyAsync(faces, ctx->pool_mesh_rgb.p, (size_t)ctx->mesh_tris * 24,
                                 hipMemcpyDeviceToHost, ctx->stream));
-        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+        ARVX_SYNC(ctx);
     }
     return ARVX_OK;
 }
@@ -2148,7 +2205,7 @@ int arvx_closure_download32(arvx_ctx *ctx, int32_t *index, float *rgba) {
         else for (size_t k = lo; k < hi; ++k) index[k - lo] = (int32_t)(ctx->h_clo_index[k] - base);
         ARVX_HIP(hipMemcpyAsync(rgba, (const float4 *)ctx->d_clo_rgba + lo,
                                 (hi - lo) * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+        ARVX_SYNC(ctx);
     }
     return ARVX_OK;
 }
@@ -2255,7 +2312,7 @@ int arvx_fast_carve(arvx_ctx *ctx) {
         }
         ARVX_HIP(hipMemcpyAsync(changed, flags, 8 * sizeof(int), hipMemcpyDeviceToHost,
                                 ctx->stream));
-        ARVX_HIP(hipStreamSynchronize(ctx->stream));
+        ARVX_SYNC(ctx);
         if (!changed[batch - 1]) break;
         if (launched >= max_launches) return fail(ARVX_ERR_HIP, "flood fill did not converge");
         if (round >= 1 && batch < 8) batch *= 2;
@@ -2269,7 +2326,7 @@ int arvx_fast_carve(arvx_ctx *ctx) {
     ctx->fresh_pending = false;  // the records now hold every voxel's state
     ctx->rec_valid = true;
     ctx->lazy = false;
-    ARVX_HIP(hipStreamSynchronize(ctx->stream));
+    ARVX_SYNC(ctx);
     return ARVX_OK;
 }
 

@@ -52,6 +52,15 @@ struct Ctx {
     size_t nvox = 0;      // owned voxels
     size_t nvox_ext = 0;  // voxels in the state buffer (owned + halo)
 
+    // Kernels that wait for other workgroups inside a launch (views_strip_kernel, the streaming
+    // carve) give up after seconds and leave a mark here instead of hanging the device: one word of
+    // page-locked host memory the device writes directly, read by the host after its next
+    // synchronisation (arvx_capi.hip, check_fault).  Never seen set outside fault-injection tests.
+    unsigned *h_fault = nullptr;  // host address
+    unsigned *d_fault = nullptr;  // the same word as the device sees it
+    DevPool pool_vstrip;          // views_strip_kernel: ticket counters + published column counts
+    size_t vstrip_key = 0;        // layout (V, strips, granules) the pool was zeroed for
+
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t xstream = nullptr;  // arvx_ctx_set_exchange_stream: the occupancy hand-off (null: stream)
@@ -156,6 +165,8 @@ struct Ctx {
         pool_mesh_verts.release();
         pool_mesh_rgb.release();
         pool_xscratch.release();
+        pool_vstrip.release();
+        vstrip_key = 0;
         pool_paint.release();
         pool_ccode.release();
         pool_cstate.release();

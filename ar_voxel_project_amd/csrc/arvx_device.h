@@ -146,6 +146,19 @@ __device__ __forceinline__ uint32_t lazy_seen(const CarveParams &p, int code, in
     return code == 3 ? (~row_inmask(p, tx, ty, tz, wave, r) & 0xffffu) : 0xffffu;
 }
 
+// Granules: what crosses workgroups INSIDE a launch (/opt/skills/guides/MI355X_MICROARCH.md, inter-
+// workgroup visibility): one naturally aligned 8-byte word {32-bit payload, 32-bit tag} written by
+// ONE sc1 store and read by sc1 loads (relaxed, agent scope: past the CU's L1).  A granule is valid
+// when its tag is the current launch's: no flag, no fence, no ordering between granules, and
+// nothing to reset between launches.
+__device__ __forceinline__ void granule_store(unsigned long long *p, uint32_t payload, uint32_t tag) {
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | payload, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long granule_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // 4 bits -> bit 0 of 4 bytes, and back
 __device__ __forceinline__ uint32_t nibble_to_bytes(uint32_t nib) {
     return (nib * 0x00204081u) & 0x01010101u;

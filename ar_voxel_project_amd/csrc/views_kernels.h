@@ -263,4 +263,206 @@ __global__ __launch_bounds__(256) void views_table_kernel(const uint32_t *__rest
     }
 }
 
+// ---- everything in ONE launch (one-channel masks, W a multiple of 64, W < 1024) -----------------
+//
+// Round 4.  The three launches above are a chain of dependent grids of a few thousand waves: 22 us
+// for 36 views of 640 x 480 of which most is dispatch, ramp and the small arrays going through
+// memory from one launch to the next.  Here a workgroup owns a STRIP of one view -- tile row I, 64
+// image rows -- with one wave per tile column J (the same tiles and the same row loop as above) and
+// reads the mask bytes itself:
+//   own rows          16 bytes per lane (row 4 (lane / 4) + k, columns 64 J + 16 (lane % 4)), four
+//                     loads; the four lanes of a row OR their 16 flags into the row's 64-bit word,
+//                     and lane r ends up with row r (k = lane % 4 is its own register);
+//   bit plane         the strip's words go through LDS and out as one contiguous run (whole lines);
+//   left of the tile  the waves of the workgroup are the tile columns: per-row counts through LDS;
+//   above the tile    every strip counts the foreground of its OWN rows per column (the flags of
+//                     the bytes it has loaded, added as packed bytes, summed over the 16 row slots)
+//                     and publishes the counts; a strip sums what the strips above it published.
+// That hand-off is the only thing that crosses workgroups.  It follows the guide's granule form
+// (MI355X_MICROARCH.md, inter-workgroup visibility): 8-byte words {two 16-bit counts, 32-bit tag}
+// written by one sc1 store each and polled with sc1 loads -- a word is valid when its tag is this
+// launch's, no flag, no fence, nothing to reset.  Forward progress does not depend on dispatch
+// order or residency: a workgroup takes its strip from a per-view TICKET (64-bit counter, never
+// reset: ticket t = strip t % TI of launch t / TI, which is also the tag), so the strips it waits
+// for (lower tickets of the same launch) belong to workgroups that are already running and that
+// wait for nothing above them.  (First version of this round: no hand-off, every strip counted the
+// rows above it again from the mask bytes -- 287 KB of reads on ONE compute unit for the lowest
+// strip, 11 B/cycle: 17 us, and 32 us when 92 registers left room for one workgroup per unit.)
+// tests/test_carve_gpu.py::test_view_tables_against_numpy compares every entry of plane and table.
+constexpr int kStripMaxWaves = 16;
+
+// 16 mask bytes -> 16 flags, bit i = byte i is not zero
+__device__ __forceinline__ uint32_t nonzero16(const uint4 w) {
+    const uint32_t d[4] = {w.x, w.y, w.z, w.w};
+    uint32_t f = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // bit 7 of a byte of t: the byte is not zero (no carry leaves a byte: 0x7f + 0x7f < 0x100)
+        const uint32_t t = (((d[k] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d[k]) & 0x80808080u;
+        f |= bytes_to_nibble(t >> 7) << (4 * k);
+    }
+    return f;
+}
+// the same as packed bytes: byte i of the result = 1 iff byte i of x is not zero
+__device__ __forceinline__ uint32_t nonzero_bytes(const uint32_t x) {
+    return ((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) >> 7) & 0x01010101u;
+}
+
+// ctr: one 64-bit ticket counter per view (zero when allocated, never reset); gran: the published
+// column counts, [view][strip][W / 2] granules; err: set when a wait gives up (never seen; the
+// host checks it at its next synchronisation)
+__global__ __launch_bounds__(64 * kStripMaxWaves) void views_strip_kernel(
+    const uint8_t *__restrict__ masks, int W, int H, int TI, uint32_t *__restrict__ bg, int bgWords,
+    uint16_t *__restrict__ sat, int satStride, int ld, unsigned long long *__restrict__ ctr,
+    unsigned long long *__restrict__ gran, unsigned *__restrict__ err) {
+    __shared__ unsigned long long s_bits[64 * (kStripMaxWaves - 1)];  // [row][pixel tile column]
+    __shared__ int s_rowcnt[kStripMaxWaves][64];
+    __shared__ uint16_t s_col[kStripMaxWaves][64];
+    __shared__ int s_tot[kStripMaxWaves];
+    __shared__ uint4 s_row[kStripMaxWaves][64];
+    __shared__ unsigned long long s_ticket;
+    const int v = blockIdx.y;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&ctr[v], 1ull);
+    __syncthreads();
+    const unsigned long long ticket = s_ticket;
+    const int I = (int)(ticket % (unsigned long long)TI);
+    const uint32_t tag = (uint32_t)(ticket / (unsigned long long)TI) + 1u;
+    const int J = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int TP = W >> 6;  // tile columns that hold pixels; wave TP writes table column W (+ padding)
+    const int G = W >> 1;   // granules per strip
+    const uint8_t *img = masks + (size_t)v * W * H;
+    const int y0 = I * 64;
+    const int nrows = min(64, H - y0);
+    const int rr = lane >> 2, q = lane & 3;
+
+    // ---- this strip's rows: lane r <- the 64 foreground flags of row y0 + r, columns 64 J ..
+    uint32_t mine_lo = 0, mine_hi = 0;
+    uint32_t acc[4] = {0u, 0u, 0u, 0u};  // columns 64 J + 16 q + 4 d + b: byte b of acc[d]
+    if (J < TP) {
+        uint4 w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = y0 + 4 * rr + k;
+            w[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (y < H) w[k] = *reinterpret_cast<const uint4 *>(img + (size_t)y * W + 64 * J + 16 * q);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t f = nonzero16(w[k]);
+            uint32_t lo = q < 2 ? f << (16 * q) : 0u, hi = q >= 2 ? f << (16 * (q - 2)) : 0u;
+            lo |= __shfl_xor(lo, 1);
+            hi |= __shfl_xor(hi, 1);
+            lo |= __shfl_xor(lo, 2);
+            hi |= __shfl_xor(hi, 2);
+            if (k == q) {  // row 4 rr + q = lane
+                mine_lo = lo;
+                mine_hi = hi;
+            }
+            acc[0] += nonzero_bytes(w[k].x);
+            acc[1] += nonzero_bytes(w[k].y);
+            acc[2] += nonzero_bytes(w[k].z);
+            acc[3] += nonzero_bytes(w[k].w);
+        }
+        // background bits of the row (reference src/VoxelCarving.cpp:49-50: all bytes zero)
+        s_bits[lane * TP + J] = (lane < nrows)
+                                    ? ~(((unsigned long long)mine_hi << 32) | mine_lo)
+                                    : 0ull;
+    }
+    s_rowcnt[J][lane] = __popc(mine_lo) + __popc(mine_hi);
+
+    // ---- the strip's own foreground per column: packed bytes (<= 4 each) -> packed halves, summed
+    // over the 16 row slots (the lanes with the same q), published for the strips below
+    if (J < TP && I + 1 < TI) {
+        uint32_t e[8];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            e[2 * d] = acc[d] & 0x00ff00ffu;             // bytes 0 and 2
+            e[2 * d + 1] = (acc[d] >> 8) & 0x00ff00ffu;  // bytes 1 and 3
+        }
+#pragma unroll
+        for (int m = 4; m < 64; m <<= 1)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) e[i] += __shfl_xor(e[i], m);
+        if (rr == 0) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                uint16_t *o = &s_col[J][16 * q + 4 * d];
+                o[0] = (uint16_t)(e[2 * d] & 0xffffu);
+                o[1] = (uint16_t)(e[2 * d + 1] & 0xffffu);
+                o[2] = (uint16_t)(e[2 * d] >> 16);
+                o[3] = (uint16_t)(e[2 * d + 1] >> 16);
+            }
+        }
+        wave_lds_fence();
+        if (lane < 32) {
+            const uint32_t pay = (uint32_t)s_col[J][2 * lane] | ((uint32_t)s_col[J][2 * lane + 1] << 16);
+            granule_store(gran + ((size_t)v * TI + I) * G + 32 * J + lane, pay, tag);
+        }
+    }
+    __syncthreads();
+
+    // ---- the bit plane: the strip's nrows * TP words are one contiguous run
+    {
+        unsigned long long *dst =
+            reinterpret_cast<unsigned long long *>(bg + (size_t)v * bgWords) + (size_t)y0 * TP;
+        for (int i = threadIdx.x; i < nrows * TP; i += blockDim.x) dst[i] = s_bits[i];
+        if (I == 0 && threadIdx.x == 0) bg[(size_t)v * bgWords + bgWords - 1] = 0u;
+    }
+
+    // ---- foreground of column 64 J + lane in the rows above the strip: the counts the strips
+    // above have published (all loads of a round in flight together)
+    int above = 0;
+    if (J < TP && I > 0) {
+        const unsigned long long *g0 = gran + (size_t)v * TI * G + 32 * J + (lane >> 1);
+        for (unsigned spin = 0;; ++spin) {
+            bool ok = true;
+            int sum = 0;
+            for (int k = 0; k < I; ++k) {
+                const unsigned long long g = granule_load(g0 + (size_t)k * G);
+                ok = ok && (uint32_t)(g >> 32) == tag;
+                sum += (int)(((uint32_t)g >> (16 * (lane & 1))) & 0xffffu);
+            }
+            if (__all(ok)) {
+                above = sum;
+                break;
+            }
+            if (spin > (1u << 20)) {  // (seconds: something is broken; leave a mark and go on)
+                if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    int sc = above;  // ... inclusive along the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(sc, d);
+        if (lane >= d) sc += t;
+    }
+    if (lane == 63) s_tot[J] = sc;
+    __syncthreads();
+
+    // ---- the table, as in views_table_kernel
+    int left = 0, lt = 0;
+    for (int k = 0; k < J; ++k) {
+        left += s_rowcnt[k][lane];
+        lt += s_tot[k];
+    }
+    uint16_t *tab = sat + (size_t)v * satStride;
+    const unsigned off = 64u * (unsigned)J + (unsigned)lane;
+    if (I == 0) tab[off] = 0;
+    uint4 *const rows = s_row[J];
+    rows[lane] = make_uint4(mine_lo, mine_hi, (uint32_t)left, 0u);
+    wave_lds_fence();
+    uint32_t run = (uint32_t)(sc - above + lt);
+    uint16_t *row = tab + (size_t)(y0 + 1) * ld;
+#pragma unroll 4
+    for (int r = 0; r < nrows; ++r) {
+        const uint4 f = rows[r];
+        run = __builtin_amdgcn_mbcnt_hi(f.y, __builtin_amdgcn_mbcnt_lo(f.x, run)) + f.z;
+        row[off] = (uint16_t)run;
+        row += ld;
+    }
+}
+
 }  // namespace arvx
