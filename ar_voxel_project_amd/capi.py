@@ -21,6 +21,12 @@ SEEN = 2
 CARVE_NO_CULL = 1
 CARVE_STATS = 2
 CARVE_FUSED = 8
+CARVE_STREAM = 16
+CARVE_NO_STREAM = 32
+# test plumbing: flags OR-ed into every carve of this process, e.g. ARVX_CARVE_EXTRA_FLAGS=16 runs a
+# whole test module with the streaming carve forced on every fresh model (the library itself reads
+# no environment variable)
+_EXTRA_CARVE_FLAGS = int(os.environ.get("ARVX_CARVE_EXTRA_FLAGS", "0"))
 COLOR_CLOSEST = 0
 COLOR_AVERAGE = 1
 
@@ -454,10 +460,10 @@ class Context:
 
     # -- hot path --
     def carve(self, flags: int = 0) -> None:
-        self._ck(self._lib.arvx_carve(self._h, flags))
+        self._ck(self._lib.arvx_carve(self._h, flags | _EXTRA_CARVE_FLAGS))
 
     def carve_views(self, first: int, count: int, flags: int = 0) -> None:
-        self._ck(self._lib.arvx_carve_views(self._h, first, count, flags))
+        self._ck(self._lib.arvx_carve_views(self._h, first, count, flags | _EXTRA_CARVE_FLAGS))
 
     def fast_carve(self) -> None:
         self._ck(self._lib.arvx_fast_carve(self._h))

@@ -19,6 +19,7 @@
 
 #include "arvx_ctx.h"
 #include "carve_kernels.h"
+#include "carve_stream_kernels.h"
 #include "views_kernels.h"
 #include "state_kernels.h"
 #include "undistort_kernels.h"
@@ -132,6 +133,7 @@ static int check_fault(Ctx *ctx) {
     *ctx->h_fault = 0u;
     ctx->vstrip_key = 0;   // the ticket counters no longer match the launches: start over
     ctx->carve_layout = 0;
+    ctx->stream_layout = 0;
     return fail(ARVX_ERR_HIP, "a kernel gave up waiting for another workgroup (mark %u): the "
                 "results of the calls since the last synchronisation are undefined", what);
 }
@@ -378,6 +380,7 @@ int arvx_ctx_destroy(arvx_ctx *ctx) {
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_coarse) (void)hipFree(ctx->d_coarse);
+    if (ctx->d_stream) (void)hipFree(ctx->d_stream);
     if (ctx->h_fault) (void)hipHostFree(ctx->h_fault);
     if (ctx->own_stream) {
         (void)hipStreamSynchronize(ctx->own_stream);
@@ -1110,6 +1113,86 @@ int arvx_occupancy_expand_striped(arvx_ctx *ctx, const void *dev_packets, int wo
 // ---- carve -------------------------------------------------------------------
 
 // Launches the carve over planes [ze0, ze1) (owned + halo) of the records at `rec`.
+// A fresh model carved by ONE persistent launch (carve_stream_kernels.h).  p: geometry, views and
+// flags filled in by launch_carve.
+static int launch_carve_stream(Ctx *ctx, arvx::CarveParams p, int ncu) {
+    const size_t ncoarse = (size_t)p.coarseX * p.coarseY * p.coarseZ;
+    const unsigned G = (unsigned)ncu * 4u;  // resident workgroups (128 VGPRs: 4 per compute unit)
+    // (the chunks of 64 views are a template parameter of the kernel: 1, or all four)
+    if (p.nchunks > 1) p.nchunks = arvx::kMaxChunks;
+    // a coarse unit (one wave): up to four coarse tiles, so that every wave gets one
+    p.cwA = (int)std::min<size_t>(arvx::kStreamTilesA, std::max<size_t>(1, (ncoarse + 4 * G - 1) / (4 * G)));
+    p.nA = (int)((ncoarse + p.cwA - 1) / p.cwA);
+    // a sub-tile unit (one wave): 16 sub-tiles, a quarter of a coarse tile (half on striped slabs)
+    p.splitLog2 = p.cyShift + p.czShift - 2;
+    p.listStride = 1 + 2 * p.nchunks;
+    p.itemStride = 2 + 4 * p.nchunks;
+    // A unit u appends to list part u % 8: a part gets at most every 8th unit's tiles
+    p.listCap = (p.nA / arvx::kStreamLists + 1) * p.cwA;
+    // sub-tile i (of 4 per tile) goes to list i % 8 of one of eight weight classes: a list never
+    // gets more than every 8th sub-tile
+    p.workCap = (int)(((size_t)p.tilesX * p.tilesY * p.tilesZ * 4 + 7) / 8);
+    const size_t off_list = ((size_t)arvx::kStreamLines * arvx::kCounterStride * sizeof(int) + 255) / 256 * 256;
+    const size_t off_items =
+        off_list + ((size_t)arvx::kStreamLists * p.listCap * p.listStride * 8 + 255) / 256 * 256;
+    const size_t need = off_items + (size_t)arvx::kWorkLists * p.workCap * p.itemStride * 8 + 256;
+    if (ctx->stream_bytes < need) {
+        if (ctx->d_stream) (void)hipFree(ctx->d_stream);
+        ctx->d_stream = nullptr;
+        ctx->stream_bytes = 0;
+        ctx->stream_layout = 0;
+        ARVX_HIP(hipMalloc(&ctx->d_stream, need));
+        ctx->stream_bytes = need;
+        // (stale granules are told by their tag; but the memory must not hold a FUTURE tag)
+        ARVX_HIP(hipMemsetAsync(ctx->d_stream, 0, need, ctx->stream));
+        ctx->carve_epoch = 0;
+    }
+    if (ctx->stream_layout != need) {  // the control block: all zero before a launch
+        ARVX_HIP(hipMemsetAsync(ctx->d_stream, 0, off_list, ctx->stream));
+        ctx->stream_layout = need;
+    }
+    if (++ctx->carve_epoch == 0u) {  // (2^32 launches: start the tags over on clean memory)
+        ARVX_HIP(hipMemsetAsync(ctx->d_stream, 0, need, ctx->stream));
+        ctx->carve_epoch = 1u;
+    }
+    p.sctl = (int *)ctx->d_stream;
+    p.poolNext = p.sctl + (size_t)arvx::kSC_Pool * arvx::kCounterStride;
+    p.listG = (unsigned long long *)((uint8_t *)ctx->d_stream + off_list);
+    p.itemG = (unsigned long long *)((uint8_t *)ctx->d_stream + off_items);
+    p.epoch = ctx->carve_epoch;
+    p.fault = ctx->d_fault;
+    p.nwaves = (int)G * 4;
+    ARVX_HIP(ctx->pool_ccode.reserve(ncoarse + 64));
+    ARVX_HIP(ctx->pool_cstate.reserve(ncoarse + 64));
+    p.coarseCarved = (uint8_t *)ctx->pool_ccode.p;
+    p.cstate = (uint8_t *)ctx->pool_cstate.p;
+    p.flags |= 128u;
+    ctx->cstate_tiles = 0;
+#ifdef ARVX_TIMELINE
+    if (ctx->d_timeline) (void)hipFree(ctx->d_timeline);
+    ctx->d_timeline = nullptr;
+    ctx->timeline_n = (int64_t)G * 4;  // one record per wave
+    ctx->timeline_rec = 128;
+    ARVX_HIP(hipMalloc(&ctx->d_timeline, (size_t)G * 4 * 128));
+    ARVX_HIP(hipMemsetAsync(ctx->d_timeline, 0, (size_t)G * 4 * 128, ctx->stream));
+    p.timeline = (unsigned long long *)ctx->d_timeline;
+#endif
+    // (the chunks of 64 views are a template parameter: up to 64 views, or up to 256)
+    const bool left = ctx->assoc == ARVX_ASSOC_LEFT, one = p.nchunks == 1;
+    if (left && one)
+        hipLaunchKernelGGL((arvx::carve_stream_kernel<true, 1>), dim3(G), dim3(256), 0, ctx->stream, p);
+    else if (left)
+        hipLaunchKernelGGL((arvx::carve_stream_kernel<true, arvx::kMaxChunks>), dim3(G), dim3(256), 0, ctx->stream, p);
+    else if (one)
+        hipLaunchKernelGGL((arvx::carve_stream_kernel<false, 1>), dim3(G), dim3(256), 0, ctx->stream, p);
+    else
+        hipLaunchKernelGGL((arvx::carve_stream_kernel<false, arvx::kMaxChunks>), dim3(G), dim3(256), 0, ctx->stream, p);
+    ARVX_HIP(hipGetLastError());
+    ctx->lazy = true;
+    ctx->cstate_tiles = ncoarse;
+    return ARVX_OK;
+}
+
 // `fresh`: the model is all-occupied/unseen and exists only as that flag: nothing is read,
 // every record of the grid is written.
 static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned flags,
@@ -1149,6 +1232,15 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
     size_t layout_when_done = 0;
     bool lazy = false;
     if (rec == ctx->d_rec) ctx->lazy = false;  // (set again below once the launches are out)
+    // a fresh model, the context's own records, up to 256 views: one persistent launch -- from
+    // 2^26 voxels (below that the three-launch chain shares items between waves, which the
+    // streaming launch does not), or wherever the caller asks for it
+    static const bool no_stream = experiment_flag("ARVX_NO_STREAM");
+    if (fresh && split && rec == ctx->d_rec && !no_stream &&
+        !(flags & (ARVX_CARVE_STATS | ARVX_CARVE_NO_STREAM)) &&
+        ((flags & ARVX_CARVE_STREAM) || (size_t)p.X * p.Y * p.Z >= ((size_t)1 << 26)) &&
+        arvx::rec_count(p) < ((size_t)1 << 30) && p.tilesX < 65536 && p.tilesY < 65536 && p.tilesZ < 65536)
+        return launch_carve_stream(ctx, p, ncu);
     if (cull) {
         const size_t words = ncoarse * p.nchunks;
         // coarse masks | coarse codes | undecided list | two list counters

@@ -86,6 +86,11 @@ struct Ctx {
     int ncu = 0;                 // compute units of the device (cached)
     int carve_seq = 0;           // parity of the undecided-list counters (carve_coarse_kernel)
     size_t carve_layout = 0;     // d_coarse layout those counters were zeroed for
+    // the streaming carve (carve_stream_kernels.h): control block + list entries + item queues
+    void *d_stream = nullptr;
+    size_t stream_bytes = 0;
+    size_t stream_layout = 0;    // layout the control block was zeroed for (0: zero it again)
+    unsigned carve_epoch = 0;    // tag of the latest streaming launch's granules
     void *d_timeline = nullptr;  // ARVX_TIMELINE diagnostic builds only
     int64_t timeline_n = 0;
     int timeline_rec = 32;  // bytes per record

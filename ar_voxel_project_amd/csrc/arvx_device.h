@@ -96,6 +96,17 @@ struct CarveParams {
     int workCap;                    // capacity of one list
     unsigned long long *itemInfo;   // [kWorkLists * workCap] tx | ty<<16 | tz<<32 | wave<<48 | fg<<50
     unsigned long long *itemMasks;  // [..][nchunks][2] mixed views, shared-rcp division ok
+    // the streaming carve (carve_stream_kernels.h): one persistent launch, work handed from
+    // workgroup to workgroup as tagged granules
+    int *sctl;                  // control block: counter k at sctl[k * kCounterStride]
+    unsigned long long *listG;  // [8 parts][listCap][listStride] undecided coarse tiles, as they are found
+    unsigned long long *itemG;  // [kWorkLists][workCap][itemStride] sub-tiles for exact work
+    unsigned epoch;             // tag of this launch's granules (never 0)
+    int listCap;                // entries per list part
+    int listStride, itemStride; // granules per list entry / per item (items: workCap per list)
+    int nA, cwA;                // coarse units: nA of cwA coarse tiles each
+    int splitLog2;              // log2 sub-tile units per listed coarse tile (0: whole, 2: quarters)
+    unsigned *fault;            // Ctx::d_fault
 };
 
 // global z of local plane lz

@@ -72,8 +72,20 @@ __device__ __forceinline__ BoxW make_box(float s, int x0, int x1, int y0, int y1
 // pixels); a larger one is called "mixed" without looking (conservative: the next level of
 // tests, on smaller boxes, decides).  Half the bytes to derive per step and to keep in the caches.
 typedef uint16_t sat_t;
-__device__ inline int classify_box(const float *__restrict__ M, const BoxW b, int W, int H,
-                                   const sat_t *__restrict__ sat, int satW) {
+// The test in two steps, so that a caller can have the table reads of several rectangles in flight
+// together: rect_prepare does the arithmetic up to the pixel rectangle -- an answer that needs no
+// look at the table (code >= 0: outside / mixed) or the four entries to read (code < 0) --,
+// rect_finish turns the entries into the answer.
+struct RectQ {
+    int code;  // >= 0: the answer (kClsOut, or kClsMixed [| kFastDiv]); -1: read the table
+    int fast;  // kFastDiv or 0, to be OR-ed onto a "mixed" answer
+    int base;  // entry (Y0, X0)
+    int dx, dy;  // X1 - X0, Y1 - Y0
+};
+__device__ inline RectQ rect_prepare(const float (&M)[12], const BoxW b, int W, int H, int satW) {
+    RectQ q;
+    q.fast = 0;
+    q.base = q.dx = q.dy = 0;
     const float dy = b.wy1 - b.wy0, dx = b.wx1 - b.wx0, dz = b.wz1 - b.wz0;
     const float ay = fmaxf(fabsf(b.wy0), fabsf(b.wy1));
     const float ax = fmaxf(fabsf(b.wx0), fabsf(b.wx1));
@@ -110,16 +122,19 @@ __device__ inline int classify_box(const float *__restrict__ M, const BoxW b, in
     const float k12 = 2.44140625e-04f;       // 2^-12
     const float eps0 = E[0] * k19, eps1 = E[1] * k19, eps2 = E[2] * k19;
     const float cabs = (cmin > 0.f) ? cmin : ((cmax < 0.f) ? -cmax : 0.f);
-    if (!(cabs > 8.f * eps2 + 1e-30f)) return kClsMixed;  // the denominator may vanish
+    q.code = kClsMixed;
+    if (!(cabs > 8.f * eps2 + 1e-30f)) return q;  // the denominator may vanish
     // every voxel of the box then has |a2| >= cabs - eps2 > 0; kFastDiv: all row values
     // lie in the range where divide2_shared_rcp equals the IEEE quotient (or the
     // difference cannot matter): 2^-59 <= |a2|, and |a_r| <= 2^59
     const int fast = (cabs >= 1.8e-18f && E[0] <= 5.7e17f && E[1] <= 5.7e17f && E[2] <= 5.7e17f)
                          ? kFastDiv
                          : 0;
+    q.fast = fast;
+    q.code = kClsMixed | fast;
     const float Ua = fmaxf(fabsf(umin), fabsf(umax));
     const float Va = fmaxf(fabsf(vmin), fabsf(vmax));
-    if (!(Ua < 1.0e6f && Va < 1.0e6f)) return kClsMixed | fast;  // also NaN
+    if (!(Ua < 1.0e6f && Va < 1.0e6f)) return q;  // also NaN
     const float rden = 1.0001f / (cabs - eps2);
     const float mu = (eps0 + Ua * eps2) * rden + Ua * k20 + k12;
     const float mv = (eps1 + Va * eps2) * rden + Va * k20 + k12;
@@ -127,16 +142,38 @@ __device__ inline int classify_box(const float *__restrict__ M, const BoxW b, in
     const int pxhi = (int)floorf(umax + mu + 0.5f);
     const int pylo = (int)ceilf(vmin - mv - 0.5f);
     const int pyhi = (int)floorf(vmax + mv + 0.5f);
-    if (pxhi < 0 || pxlo >= W || pyhi < 0 || pylo >= H) return kClsOut;
-    if (pxlo < 0 || pxhi >= W || pylo < 0 || pyhi >= H) return kClsMixed | fast;
-    const int X0 = pxlo, X1 = pxhi + 1;
-    const int Y0 = pylo, Y1 = pyhi + 1;
-    const int area = (X1 - X0) * (Y1 - Y0);
-    if (area >= 65536) return kClsMixed | fast;  // (the table's entries are counts modulo 2^16)
-    const int cnt = ((int)sat[Y1 * satW + X1] - (int)sat[Y0 * satW + X1] - (int)sat[Y1 * satW + X0] +
-                     (int)sat[Y0 * satW + X0]) & 0xffff;
+    if (pxhi < 0 || pxlo >= W || pyhi < 0 || pylo >= H) {
+        q.code = kClsOut;
+        return q;
+    }
+    if (pxlo < 0 || pxhi >= W || pylo < 0 || pyhi >= H) return q;
+    q.dx = pxhi + 1 - pxlo;
+    q.dy = pyhi + 1 - pylo;
+    if (q.dx * q.dy >= 65536) return q;  // (the table's entries are counts modulo 2^16)
+    q.base = pylo * satW + pxlo;
+    q.code = -1;
+    return q;
+}
+// s00 .. s11: the table's entries (Y0, X0), (Y0, X1), (Y1, X0), (Y1, X1)
+__device__ __forceinline__ int rect_finish(const RectQ &q, int s00, int s01, int s10, int s11) {
+    const int cnt = (s11 - s01 - s10 + s00) & 0xffff;
     if (cnt == 0) return kClsCarved;  // no foreground in the rectangle
-    return (cnt == area) ? kClsFg : (kClsMixed | fast);
+    return (cnt == q.dx * q.dy) ? kClsFg : (kClsMixed | q.fast);
+}
+__device__ inline int classify_box_m(const float (&M)[12], const BoxW b, int W, int H,
+                                     const sat_t *__restrict__ sat, int satW) {
+    const RectQ q = rect_prepare(M, b, W, H, satW);
+    if (q.code >= 0) return q.code;
+    const sat_t *e = sat + q.base;
+    return rect_finish(q, e[0], e[q.dx], e[q.dy * satW], e[q.dy * satW + q.dx]);
+}
+// ... with the view's matrix in memory
+__device__ inline int classify_box(const float *__restrict__ M, const BoxW b, int W, int H,
+                                   const sat_t *__restrict__ sat, int satW) {
+    float Mr[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Mr[i] = M[i];
+    return classify_box_m(Mr, b, W, H, sat, satW);
 }
 
 // Pre-pass over coarse tiles of 64 x 32 x 32 voxels (64 sub-tiles each; striped
@@ -1153,12 +1190,24 @@ __device__ __forceinline__ bool exact_view(const CarveParams &p, const int view,
 // srank / nstatic: this wave's rank among the nstatic waves that take an item by index
 // (srank < 0: none for this wave).
 template <bool kSplit, class Body>
+__device__ __forceinline__ void for_each_work_item_of(const CarveParams &p, const int lane,
+                                                      const int srank, const int nstatic,
+                                                      int incl, Body body);
+template <bool kSplit, class Body>
 __device__ __forceinline__ void for_each_work_item(const CarveParams &p, const int lane,
                                                    const int srank, const int nstatic,
                                                    Body body) {
+    // the list fill counts, list l in lane l
+    for_each_work_item_of<kSplit>(p, lane, srank, nstatic,
+                                  (lane < kWorkLists) ? p.workCount[lane * kCounterStride] : 0, body);
+}
+// ... with the counts handed in (lane l: list l)
+template <bool kSplit, class Body>
+__device__ __forceinline__ void for_each_work_item_of(const CarveParams &p, const int lane,
+                                                      const int srank, const int nstatic,
+                                                      int incl, Body body) {
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    // inclusive prefix of the list fill counts, list l in lane l
-    int incl = (lane < kWorkLists) ? p.workCount[lane * kCounterStride] : 0;
+    // inclusive prefix of the counts
 #pragma unroll
     for (int d = 1; d < kWorkLists; d <<= 1) {
         const int t = __shfl_up(incl, d);

@@ -57,6 +57,9 @@ enum {
 #define ARVX_CARVE_NO_CULL 1u /* evaluate every voxel in every view (ablation) */
 #define ARVX_CARVE_STATS 2u   /* fill the counters read by arvx_get_stats */
 #define ARVX_CARVE_FUSED 8u   /* one kernel for rectangle tests and per-voxel work (A/B) */
+#define ARVX_CARVE_STREAM 16u    /* a fresh model: the one-launch streaming carve whatever the grid size
+                                    (default: from 2^26 voxels; tests force it on small grids) */
+#define ARVX_CARVE_NO_STREAM 32u /* never the streaming carve: the three-launch chain (A/B) */
 
 /* colour modes: reference -color=1 / -color=2 (src/main.cpp:276-288) */
 #define ARVX_COLOR_CLOSEST 0

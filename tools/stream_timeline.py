@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of the streaming carve from a DIAGNOSTIC build
+(make -C ar_voxel_project_amd/csrc EXTRA=-DARVX_TIMELINE OUT=.../ab_libs/timeline.so):
+    ARVX_LIB_PATH=ab_libs/timeline.so python tools/stream_timeline.py 512"""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from ar_voxel_project_amd import capi, synthetic  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+sc = synthetic.sphere_scene(N, 36)
+lib = capi.load_library()
+with capi.Context(N, N, N, sc.voxel_size) as ctx:
+    ctx.set_views(sc.M, sc.masks)
+    for _ in range(3):
+        ctx.reset()
+        ctx.carve(capi.CARVE_STREAM)
+        ctx.synchronize()
+    n = C.c_int64()
+    lib.arvx_debug_timeline.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    lib.arvx_debug_timeline(ctx._h, None, C.byref(n))
+    buf = np.zeros((n.value, 16), np.uint64)
+    lib.arvx_debug_timeline(ctx._h, buf.ctypes.data_as(C.c_void_p), C.byref(n))
+ok = buf[:, 0] > 0
+b = buf[ok].astype(np.float64)
+t0 = b[:, 0].min()
+us = lambda a: (a - t0) / 100.0
+pct = lambda a: {k: round(float(np.percentile(a, q)), 2) for k, q in
+                 (("p1", 1), ("p10", 10), ("p50", 50), ("p90", 90), ("p99", 99), ("max", 100))}
+items = buf[ok, 5].astype(int)
+got = items > 0
+units = buf[ok, 7]
+print(json.dumps({
+    "grid": N, "waves": int(ok.sum()),
+    "start_us": pct(us(b[:, 0])), "A_end_us": pct(us(b[:, 1])), "B_end_us": pct(us(b[:, 2])),
+    "first_item_in_hand_us": pct(us(b[got, 3])), "end_us": pct(us(b[:, 4])),
+    "items_per_wave": pct(items), "items": int(items.sum()),
+    "take_us_per_wave": pct(b[:, 6] / 100.0),
+    "take_us_per_item_mean": float(b[:, 6].sum() / 100.0 / max(1, items.sum())),
+    "A_units": int((units & np.uint64(0xffffffff)).sum() // 4),
+    "B_units": int((units >> np.uint64(32)).sum() // 4),
+    "first_draw_us(incl. wait for A)": pct(b[:, 8] / 100.0),
+    "later_draws_us_per_wave": pct(b[:, 6] / 100.0),
+    "draws_per_wave": pct(b[:, 10]),
+    "B_unit_us_per_wave": pct(b[:, 9] / 100.0),
+    "B_unit_us_mean": float(b[:, 9].sum() / 100.0 / max(1, (units >> np.uint64(32)).sum())),
+    "B_unit_parts_us_mean(rectangles, records, appends+granules, arrive)":
+        [float(b[:, k].sum() / 100.0 / max(1, (units >> np.uint64(32)).sum())) for k in (11, 12, 13, 14)],
+    "kernel_us": float(us(b[:, 4]).max())}))
