@@ -15,6 +15,19 @@ def _make(directory: str, *targets: str) -> None:
         raise RuntimeError(f"{' '.join(cmd)} failed:\n{res.stdout}")
 
 
+def source_stamp() -> str:
+    """sha256 (16 hex digits) over the kernel sources of libarvx.so: what ties a PMC pass under
+    profiles/ (tools/make_traffic.py) to the build bench.py is running."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ar_voxel_project_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build_library() -> str:
     """hipcc --offload-arch=gfx950 -> ar_voxel_project_amd/lib/libarvx.so"""
     _make("ar_voxel_project_amd/csrc")

@@ -370,10 +370,13 @@ class Context:
     def plane_words(self) -> int:
         return ((self.X + 31) // 32) * self.Y * len(self.planes)
 
-    def download_planes(self):
-        """(occ, seen) bit planes, uint32, rows padded to 32-bit words."""
+    def download_planes(self, occ=None, seen=None):
+        """(occ, seen) bit planes, uint32, rows padded to 32-bit words (into the caller's arrays,
+        e.g. page-locked ones, when given)."""
         n = self.plane_words()
-        occ, seen = np.empty(n, np.uint32), np.empty(n, np.uint32)
+        if occ is None:
+            occ, seen = np.empty(n, np.uint32), np.empty(n, np.uint32)
+        assert occ.size == seen.size == n and occ.dtype == seen.dtype == np.uint32
         self._ck(self._lib.arvx_state_download_planes(self._h, occ.ctypes.data, seen.ctypes.data))
         return occ, seen
 
@@ -497,8 +500,9 @@ class Context:
         (n, V) records r, g, b, valid, depth for n voxels (flat indices over the owned planes)."""
         index = np.ascontiguousarray(index, dtype=np.int64)
         out = np.zeros((len(index), self.V), self.SAMPLE_DTYPE)
-        self._lib.arvx_color_samples.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
-        self._ck(self._lib.arvx_color_samples(self._h, len(index), index.ctypes.data, out.ctypes.data))
+        self._lib.arvx_color_samples.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+        self._ck(self._lib.arvx_color_samples(self._h, len(index), index.ctypes.data, out.shape[1],
+                                              out.ctypes.data))
         return out
 
     def upload_colors(self, index, rgb) -> None:

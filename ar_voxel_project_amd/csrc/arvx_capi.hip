@@ -1232,13 +1232,13 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
     size_t layout_when_done = 0;
     bool lazy = false;
     if (rec == ctx->d_rec) ctx->lazy = false;  // (set again below once the launches are out)
-    // a fresh model, the context's own records, up to 256 views: one persistent launch -- from
-    // 2^26 voxels (below that the three-launch chain shares items between waves, which the
-    // streaming launch does not), or wherever the caller asks for it
-    static const bool no_stream = experiment_flag("ARVX_NO_STREAM");
-    if (fresh && split && rec == ctx->d_rec && !no_stream &&
-        !(flags & (ARVX_CARVE_STATS | ARVX_CARVE_NO_STREAM)) &&
-        ((flags & ARVX_CARVE_STREAM) || (size_t)p.X * p.Y * p.Z >= ((size_t)1 << 26)) &&
+    // a fresh model, the context's own records, up to 256 views: one persistent launch where the
+    // caller asks for it (carve_stream_kernels.h; EXPERIMENTS.md, round 4: its sub-tile phase is
+    // slower inside a launch of 128-register waves than as a launch of its own, so the three
+    // launches below stay the default)
+    static const bool stream_default = experiment_flag("ARVX_STREAM_DEFAULT");
+    if (fresh && split && rec == ctx->d_rec && !(flags & (ARVX_CARVE_STATS | ARVX_CARVE_NO_STREAM)) &&
+        ((flags & ARVX_CARVE_STREAM) || (stream_default && (size_t)p.X * p.Y * p.Z >= ((size_t)1 << 26))) &&
         arvx::rec_count(p) < ((size_t)1 << 30) && p.tilesX < 65536 && p.tilesY < 65536 && p.tilesZ < 65536)
         return launch_carve_stream(ctx, p, ncu);
     if (cull) {
@@ -1623,10 +1623,14 @@ int arvx_color(arvx_ctx *ctx, int mode) {
     return ARVX_OK;
 }
 
-int arvx_color_samples(arvx_ctx *ctx, int64_t n, const int64_t *index, arvx_color_sample *out) {
+int arvx_color_samples(arvx_ctx *ctx, int64_t n, const int64_t *index, int views,
+                       arvx_color_sample *out) {
     ARVX_CHECK_CTX(ctx);
     static_assert(sizeof(arvx_color_sample) == 8, "r, g, b, valid, depth");
     if (!ctx->cameras_ready) return fail(ARVX_ERR_STATE, "arvx_set_views has not been called");
+    if (views != ctx->V)
+        return fail(ARVX_ERR_INVALID, "out holds %d samples per voxel, the context has %d views", views,
+                    ctx->V);
     if (!ctx->images_ready) return fail(ARVX_ERR_STATE, "arvx_set_images has not been called");
     if (!ctx->has_campos) return fail(ARVX_ERR_STATE, "arvx_set_views was given no campos");
     if (n < 0 || (n && (!index || !out))) return fail(ARVX_ERR_INVALID, "null index / out or n < 0");

@@ -1587,6 +1587,82 @@ __device__ __forceinline__ unsigned block_tests(const CarveParams &p, const SubT
     return needLanes;
 }
 
+// The same tests with the views' matrices in LDS (sM: 12 floats per view, view 0 = p.v0) and NB
+// passes per round: the arithmetic of the round's passes first, then their table reads together,
+// then the answers -- one round trip to memory per NB * 4 views instead of two per 4 (the matrix,
+// then the table).  vrel: the chunk's first view, relative to p.v0.  Every view of `views` belongs
+// to this wave.
+template <int NB>
+__device__ __forceinline__ unsigned block_tests_lds(const CarveParams &p, const float *sM,
+                                                    const SubTile &t, int vrel,
+                                                    unsigned long long views, int lane,
+                                                    unsigned &carved, unsigned &seen) {
+    const int blk = lane & 15, q = lane >> 4;
+    const int j = blk & 3, m = blk >> 2, byi = m >> 1, bzi = m & 1;
+    const int x0 = t.sx0 + 4 * j, y0 = t.sy0 + 4 * byi, z0 = t.sz0 + 4 * bzi;
+    const bool inside = x0 < p.X && y0 < p.Y && z0 < p.Z;
+    const BoxW box = make_box(p.s, x0, min(x0 + 3, p.X - 1), y0, min(y0 + 3, p.Y - 1),
+                              global_z(p, z0), global_z(p, min(z0 + 3, p.Z - 1)));
+    unsigned needLanes = 0;  // lane s: blocks to project in the s-th view
+    int slot = 0;
+    while (views) {
+        RectQ rq[NB];
+        int nv[NB], myv[NB];
+        int s00[NB], s01[NB], s10[NB], s11[NB];
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+            int vb[4];
+            nv[g] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // the next four views (scalar)
+                vb[k] = 0;
+                if (views) {
+                    vb[k] = __ffsll((long long)views) - 1;
+                    views &= views - 1;
+                    nv[g] = k + 1;
+                }
+            }
+            myv[g] = vrel + (q == 0 ? vb[0] : (q == 1 ? vb[1] : (q == 2 ? vb[2] : vb[3])));
+            rq[g].code = kClsOut;
+            if (q < nv[g] && inside) {
+                float Mr[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) Mr[i] = sM[12 * myv[g] + i];
+                rq[g] = rect_prepare(Mr, box, p.W, p.H, p.satW);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+            s00[g] = s01[g] = s10[g] = s11[g] = 0;
+            if (rq[g].code < 0) {
+                const sat_t *e = p.sat + (size_t)(p.v0 + myv[g]) * p.satStride + rq[g].base;
+                s00[g] = e[0];
+                s01[g] = e[rq[g].dx];
+                s10[g] = e[rq[g].dy * p.satW];
+                s11[g] = e[rq[g].dy * p.satW + rq[g].dx];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+            if (!nv[g]) continue;  // (scalar)
+            const int cls =
+                (rq[g].code >= 0 ? rq[g].code : rect_finish(rq[g], s00[g], s01[g], s10[g], s11[g])) & 3;
+            const unsigned long long c = __ballot(cls == kClsCarved), f = __ballot(cls == kClsFg),
+                                     x = __ballot(cls == kClsMixed);
+            carved |= (unsigned)((c | (c >> 16) | (c >> 32) | (c >> 48)) & 0xffffu);
+            seen |= (unsigned)((f | (f >> 16) | (f >> 32) | (f >> 48)) & 0xffffu);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nv[g]) {
+                    const unsigned need16 = (unsigned)((x >> (16 * k)) & 0xffffu);
+                    if (lane == slot) needLanes = need16;
+                    ++slot;
+                }
+        }
+    }
+    return needLanes;
+}
+
 template <bool LEFT>
 __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveParams p) {
 #ifdef ARVX_TIMELINE

@@ -490,8 +490,11 @@ __device__ __forceinline__ bool stream_fetch_item(const CarveParams &p, const in
 }
 
 // ---- C: one item (the job of carve_exact_blocks_kernel for one sub-tile) ------------------------
+#ifndef ARVX_BT_BATCH
+#define ARVX_BT_BATCH 2  // passes (of four views) per round of the block tests
+#endif
 template <bool LEFT, int NCH>
-__device__ __forceinline__ void stream_exact_item(const CarveParams &p, const int lane,
+__device__ __forceinline__ void stream_exact_item(const CarveParams &p, const StreamLds &L, const int lane,
                                                   const unsigned pay, const int wclass) {
     const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;  // block map: a voxel per block
     // the launch ends on its longest items: the heavy classes get the SIMD's issue slots first
@@ -539,7 +542,11 @@ __device__ __forceinline__ void stream_exact_item(const CarveParams &p, const in
         const unsigned long long fastdiv = ((unsigned long long)f_hi << 32) | f_lo;
         // block-level rectangle tests first: what they settle is applied at once
         unsigned bcarved = 0, bseen = 0;
+#if ARVX_BT_BATCH > 0
+        const unsigned needLanes = block_tests_lds<ARVX_BT_BATCH>(p, L.M, t, 64 * c, mixed, lane, bcarved, bseen);
+#else
         const unsigned needLanes = block_tests(p, t, p.v0 + 64 * c, mixed, 0, 0, lane, bcarved, bseen);
+#endif
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             uint32_t w = st[m];
@@ -698,7 +705,7 @@ __global__ __launch_bounds__(256, 4) void carve_stream_kernel(const CarveParams 
                                          [&](const size_t it, const int, const int list, const int) {
                 unsigned pay = 0;
                 if (!stream_fetch_item(p, lane, it, pay)) return;
-                stream_exact_item<LEFT, NCH>(p, lane, pay, list >> 3);
+                stream_exact_item<LEFT, NCH>(p, L, lane, pay, list >> 3);
 #ifdef ARVX_TIMELINE
                 ++tl_items;
 #endif

@@ -11,19 +11,16 @@ the 1-bit background planes and the summed-area tables the carve kernels read --
 rebuilt inside every timed step (arvx_set_views_device), then arvx_carve runs.
 `value` / `ms_per_step` are that whole step.
 
-Jobs in flight (--jobs, default 4).  A step is a chain of six kernels of which the first five are
-bound by latency (a few thousand waves each, dependent reads) and the last one by vector issue,
-ending on a tail of long items: one step after the other leaves the chip partly idle most of the
-time.  The K timed steps are therefore dealt to `jobs` contexts, each on its own stream (job k on
-slot k % jobs): every step is still a whole step on a fresh model with its own derived views, all
-K are complete inside the timed region, and the final model of every slot is compared
-(`slots_agree`, `parity_vs_oracle`).  `value` / `ms_per_step` = K steps / wall time of that;
-`latency_ms_per_step` / `sequential_value` = the same step run one job after the other (K / 2
-steps, same timing frame), which is also where `carve_kernel_ms` (the carve alone),
-`views_kernel_ms` (the derivation) and the `roofline` come from: HIP events on the launch stream
-around single launches, recorded on five of those steps (the events themselves cost GPU time
-between dependent kernels).  --jobs 1 gives the sequential run alone (the profiles under
-profiles/ are taken that way: overlapping launches have no duration of their own).
+`value` / `ms_per_step`: the K steps run ONE AFTER THE OTHER on one context and stream (the
+metric is a carve's wall time: reference src/VoxelCarving.cpp:60-72 is one call, one carve), timed
+R = 5 times (`rounds`: every round's figure, median, min, max; `value` is the median round), plus one
+further round with HIP events around single launches for `carve_kernel_ms` / `views_kernel_ms` / the
+`roofline` (the events cost GPU time between dependent kernels: that round is not part of `value`).
+`throughput_jobs_in_flight`: the same K steps dealt to --jobs-in-flight contexts (default 4), each on
+its own stream -- a caller with a stream of frames hides one job's latency-bound kernels behind
+another's issue-bound one; reported beside the headline, never as it.
+`e2e`: what SURVEY 8d asks for beside the resident-input figure: page-locked host masks -> device,
+the step, and the carved model's two bit planes back on the host.
 
 metric  Mvoxel-views/s = voxels x views / carve time  (BASELINE.json)
 N = 1   512^3 grid x 36 views (the configuration the metric is quoted on)
@@ -124,6 +121,17 @@ def block_noise_masks(V, H, W, block, seed=0):
     return (m * 255).astype(np.uint8)
 
 
+def sparse_noise_masks(V, H, W, block, p_bg, seed=0):
+    """Mostly foreground with a fraction p_bg of block x block background squares: no rectangle test
+    settles anything (every rectangle holds both kinds) and nearly every voxel stays occupied through
+    all views -- the regime the culling cannot help and the early-outs do not end."""
+    rng = np.random.default_rng(seed)
+    hb, wb = (H + block - 1) // block, (W + block - 1) // block
+    coarse = rng.random((V, hb, wb)) >= p_bg
+    m = np.repeat(np.repeat(coarse, block, axis=1), block, axis=2)[:, :H, :W]
+    return (m * 255).astype(np.uint8)
+
+
 def run_workloads(capi, synthetic, dev, check):
     """The other configurations behind the headline, each in a few launches: the BASELINE.json
     configurations that fit one GPU, a worst case for the culling, and the north-star target
@@ -136,7 +144,7 @@ def run_workloads(capi, synthetic, dev, check):
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     out = []
 
-    def carve_entry(name, N, M, masks, s, planes=None, post=None):
+    def carve_entry(name, N, M, masks, s, planes=None, post=None, no_cull_too=False):
         V = masks.shape[0]
         e = {"workload": name, "grid": [N, N, N], "views": V}
         with capi.Context(N, N, N, s, device=dev.index) as ctx:
@@ -154,26 +162,50 @@ def run_workloads(capi, synthetic, dev, check):
             e["carve_kernel_ms"] = best
             e["value"] = N ** 3 * V / best / 1e3
             e["unit"] = "Mvoxel-views/s"
+            if no_cull_too:  # the brute-force kernel on the same input, for comparison
+                bf = 1e9
+                for _ in range(3):
+                    ctx.reset()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(stream)
+                    ctx.carve(capi.CARVE_NO_CULL)
+                    b.record(stream)
+                    torch.cuda.synchronize()
+                    bf = min(bf, a.elapsed_time(b))
+                e["no_cull_kernel_ms"] = bf
+                ctx.reset()
+                ctx.carve(0)
             st = ctx.download_state() if (check or post) else None
             if st is not None:
                 e["occupied_fraction"] = float((st & 1).mean())
             if post:  # carve -> colour vote -> handleUnseen -> closure -> mesh, src/main.cpp:262-303
                 ctx.set_images(post["images"])
-                stages = {}
-                for stage, call in (("colour_avg", lambda: ctx.color(capi.COLOR_AVERAGE)),
-                                    ("handle_unseen", ctx.handle_unseen),
-                                    ("closure_3", lambda: ctx.closure(3, True, download=False)),
-                                    ("mc_mesh", lambda: ctx.mc_mesh_count(True))):
-                    ctx.synchronize()
-                    t0 = time.perf_counter()
-                    r = call()
-                    ctx.synchronize()
-                    stages[stage] = (time.perf_counter() - t0) * 1e3
-                    if stage == "mc_mesh":
-                        e["triangles"] = int(r)
-                e["stage_ms"] = stages
+                # the stages after the carve, four rounds of the whole sequence on the same context:
+                # the first pays the first uses (pool allocations), the others are warm
+                per_round = []
+                for rnd in range(4):
+                    if rnd:
+                        ctx.reset()
+                        ctx.carve(0)
+                    stages = {}
+                    for stage, call in (("colour_avg", lambda: ctx.color(capi.COLOR_AVERAGE)),
+                                        ("handle_unseen", ctx.handle_unseen),
+                                        ("closure_3", lambda: ctx.closure(3, True, download=False)),
+                                        ("mc_mesh", lambda: ctx.mc_mesh_count(True))):
+                        ctx.synchronize()
+                        t0 = time.perf_counter()
+                        r = call()
+                        ctx.synchronize()
+                        stages[stage] = (time.perf_counter() - t0) * 1e3
+                        if stage == "mc_mesh":
+                            e["triangles"] = int(r)
+                    per_round.append(stages)
+                e["stage_ms"] = {k: min(pr[k] for pr in per_round[1:]) for k in per_round[0]}
+                e["stage_ms_first_call"] = per_round[0]
                 e["stage_ms_note"] = ("wall time of the C-ABI call with inputs resident, incl. its "
-                                      "own synchronisations; no result copied to the host")
+                                      "own synchronisations; no result copied to the host; "
+                                      "stage_ms = best of 3 warm rounds, stage_ms_first_call = the "
+                                      "cold first round (pool allocations)")
             ctx.reset()
             ctx.carve(capi.CARVE_STATS)
             stt = ctx.stats()
@@ -219,6 +251,14 @@ def run_workloads(capi, synthetic, dev, check):
     guarded(lambda: carve_entry("worst case for the culling: 512^3 x 36 views of 2x2-pixel block noise "
                                 "(no pixel rectangle of a 4x4x4 block is uniform)",
                                 512, sc.M, block_noise_masks(36, sc.H, sc.W, 2), sc.voxel_size))
+    # what neither the rectangles nor the early-outs can help: sparse background
+    for name, blk, pbg in (("2x2-pixel noise, 2 % background", 2, 0.02),
+                           ("2x2-pixel noise, 10 % background", 2, 0.10),
+                           ("all foreground with 0.5 % isolated background pixels", 1, 0.005)):
+        guarded(lambda name=name, blk=blk, pbg=pbg: carve_entry(
+            f"no rectangle settles, voxels stay alive: 512^3 x 36 views, {name}", 512, sc.M,
+            sparse_noise_masks(36, sc.H, sc.W, blk, pbg), sc.voxel_size,
+            planes=np.arange(192, 320), no_cull_too=True))
     sc = synthetic.sphere_scene(1024, 36)
     guarded(lambda: carve_entry("north-star target: sphere, 1024^3 x 36 views", 1024, sc.M, sc.masks,
                                 sc.voxel_size, planes=np.arange(384, 640)))
@@ -240,12 +280,17 @@ def main():
                          "trial fails or a packet overflows), in-place all-gather of contiguous "
                          "slabs, or the north star's all-reduce (SUM over zero-filled planes, "
                          "striped slabs)")
-    ap.add_argument("--jobs", type=int, default=4,
-                    help="jobs in flight per GPU: every job is a whole step (fresh model, views "
-                         "derived, carved); job k runs on context and stream k %% jobs, so that the "
-                         "latency-bound head of one job (view tables, tile classification) runs "
-                         "beside the issue-bound exact kernel of another.  1 = one job after the "
-                         "other (what `latency_ms_per_step` and the kernel times are measured on)")
+    ap.add_argument("--jobs", type=int, default=1,
+                    help="jobs in flight for the HEADLINE (default 1: one step after the other, what "
+                         "the metric means); > 1 deals the steps to that many contexts and streams")
+    ap.add_argument("--jobs-in-flight", type=int, default=4,
+                    help="the `throughput_jobs_in_flight` leg: every job is a whole step (fresh "
+                         "model, views derived, carved); job k runs on context and stream k %% jobs, "
+                         "so that the latency-bound head of one job runs beside the issue-bound "
+                         "exact kernel of another (0 = skip the leg)")
+    ap.add_argument("--rounds", type=int, default=5,
+                    help="the timed region (K steps) is run this many times: median / min / max")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (PCIe-inclusive) leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-ablation", action="store_true",
                     help="skip the NO_CULL ablation leg (keeps a profile to one kernel variant)")
@@ -296,8 +341,9 @@ def main():
     # a sample of the timed steps: five of them (fewer when K < 20), evenly spaced.
     EV = {"none": 0, "carve": 1, "all": 2}[os.environ.get("ARVX_BENCH_EVENTS", "all")]
 
-    def run_config(base, V, steps, warmup, collective, no_cull=False, jobs=1):
+    def run_config(base, V, steps, warmup, collective, no_cull=False, jobs=1, rounds=1):
         jobs = max(1, jobs)
+        rounds = max(1, rounds)
         X, Y, Z = sharding.grid_for(world, base)
         sc = synthetic.sphere_scene(max(X, Y, Z), V)
         sc.X, sc.Y, sc.Z = X, Y, Z
@@ -445,22 +491,30 @@ def main():
                     xs.cap = packet_cap
             else:
                 packet_cap = ex.retune((nstep[0] - 1) % 2)
-        barrier()
-        torch.cuda.synchronize()
+        # `rounds` timed regions of exactly `steps` steps each, bracketed by barrier + synchronize
+        # on both sides, without events; then (one job at a time) one more region WITH the events
+        # for the kernel times -- not part of the round figures
+        dts = []
         try:
-            t0 = time.perf_counter()
-            for i in range(steps):
-                step(i)
-            drain()
-            barrier()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            for rnd in range(rounds + (1 if ev else 0)):
+                with_ev = rnd == rounds
+                barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    step(i if with_ev else None)
+                drain()
+                barrier()
+                torch.cuda.synchronize()
+                if not with_ev:
+                    dts.append(time.perf_counter() - t0)
         finally:
             gc.enable()
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor(dts, dtype=torch.float64, device=dev)
         if world > 1:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)  # per round: the slowest rank
+        dts = [float(x) for x in tmax.tolist()]
+        dt = float(np.median(dts))
         views_ms = (float(np.mean([a.elapsed_time(b) for a, b, _ in ev.values()]))
                     if EV >= 2 and ev else float("nan"))
         kern_ms = (float(np.mean([b.elapsed_time(c) for _, b, c in ev.values()]))
@@ -503,7 +557,7 @@ def main():
                       else ex.total_words * 4 if collective == "allreduce" else ex.my_words * 4)
         kern_ms = None if kern_ms != kern_ms else kern_ms  # (no NaN in the JSON line)
         views_ms = None if views_ms != views_ms else views_ms
-        return dict(X=X, Y=Y, Z=Z, V=V, dt=dt, kern_ms=kern_ms, views_ms=views_ms, sc=sc, occ=occ,
+        return dict(X=X, Y=Y, Z=Z, V=V, dt=dt, dts=dts, kern_ms=kern_ms, views_ms=views_ms, sc=sc, occ=occ,
                     state=st if (world == 1 and rank == 0) else None,
                     nplanes=nplanes, layout=layout, ev_steps=len(ev), nvox=nvox_global, merge_ok=merge_ok[0],
                     jobs=jobs, slots_agree=slots_agree,
@@ -522,12 +576,13 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if not int(flag.item()):
             args.collective = "allgather"
-    def measure(base, V, steps, warmup, collective, jobs):
-        """The throughput run (`jobs` in flight) and, for jobs > 1, a short run of one job after
-        the other in the same frame for what only that can give: a step's latency and the
-        durations of its kernels (HIP events around single launches)."""
-        m = run_config(base, V, steps, warmup, collective, jobs=jobs)
+    def measure(base, V, steps, warmup, collective, jobs, rounds=1):
+        """K steps, `jobs` in flight (1: one after the other), `rounds` times.  With jobs > 1 a launch
+        has no duration of its own: the kernel times then come from a short run of one job after
+        the other in the same frame."""
+        m = run_config(base, V, steps, warmup, collective, jobs=jobs, rounds=rounds)
         m["latency_ms"] = m["dt"] / steps * 1e3
+        m["latency_steps"] = steps
         if jobs > 1 and not m["overflowed"]:
             k = max(8, steps // 2)
             q = run_config(base, V, k, min(warmup, 5), collective, jobs=1)
@@ -535,34 +590,46 @@ def main():
                      latency_ms=q["dt"] / k * 1e3, latency_steps=k)
         return m
 
-    r = measure(args.grid, args.views, args.steps, args.warmup, args.collective, args.jobs)
+    r = measure(args.grid, args.views, args.steps, args.warmup, args.collective, args.jobs, args.rounds)
     if r["overflowed"]:
         # a packet outgrew its size inside the timed region: that run does not count
         args.collective = "allgather"
-        r = measure(args.grid, args.views, args.steps, args.warmup, args.collective, args.jobs)
+        r = measure(args.grid, args.views, args.steps, args.warmup, args.collective, args.jobs, args.rounds)
     vv = r["nvox"] * r["V"]
     value = vv * args.steps / r["dt"] / 1e6
     ms_per_step = r["dt"] / args.steps * 1e3
+    per_round = [d / args.steps * 1e3 for d in r["dts"]]
+    rounds_out = {"n": len(per_round), "ms_per_step": per_round, "median": float(np.median(per_round)),
+                  "min": min(per_round), "max": max(per_round),
+                  "spread": (max(per_round) - min(per_round)) / float(np.median(per_round)),
+                  "note": f"every round = exactly {args.steps} steps one after the other between "
+                          "barrier + synchronize; `value` / `ms_per_step` = the median round"}
 
     # roofline of the carve kernels: SURVEY 8(d) algorithmic bytes, HBM-read side:
     # N*V (one state byte per voxel-view) + V*W*H (one mask byte per pixel), for the
     # voxels THIS rank's launch processes.
     nv_rank = r["X"] * r["Y"] * r["nplanes"]
     alg_bytes = nv_rank * r["V"] + r["V"] * r["sc"].W * r["sc"].H
-    achieved = alg_bytes / (r["kern_ms"] * 1e-3) / 1e9
+    kern_ms = r["kern_ms"]  # None without events (ARVX_BENCH_EVENTS=none)
+    views_ms = r["views_ms"]
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms else None
     traffic = traffic_step = None
     valu = valu_all = valu_views = None
+    profile_note = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and world == 1:
         try:
             tj = json.load(open(tpath))
             key = f"{r['X']}x{r['Y']}x{r['Z']}x{r['V']}" + ("_nocull" if args.no_cull else "")
             ent = tj.get(key, {})
+            stamp = build.source_stamp()
+            if ent and ent.get("source_stamp") != stamp:
+                # the PMC pass was taken on other kernel sources: its counts say nothing about this build
+                profile_note = (f"profiles/traffic.json[{key}] was taken on kernel sources "
+                                f"{ent.get('source_stamp')}, this build is {stamp}: no PMC figures")
+                ent = {}
             traffic = ent.get("bytes_per_launch")
             traffic_step = ent.get("bytes_per_step")
-            # what the dominant kernel is actually bound by: vector-instruction issue.  Peak:
-            # 256 CUs x 4 SIMD-32, one wave64 instruction per 2 cycles at 2.4 GHz (the guide's
-            # FP32 vector peak counted in instructions; fp64 adds / converts issue slower)
             valu_all = ent.get("valu_wave_instructions") or None
             valu_views = ent.get("valu_wave_instructions_views") or None
             ins = ent.get("valu_wave_instructions", {}).get("exact")
@@ -572,11 +639,12 @@ def main():
                 valu = {"kernel": "carve_exact_blocks_kernel", "SQ_INSTS_VALU": ins,
                         "kernel_us_rocprofv3": t_ns / 1e3, "achieved_Ginst_per_s": ins / t_ns,
                         "peak_Ginst_per_s": peak / 1e9, "frac": ins / (t_ns * 1e-9) / peak,
-                        "source": "profiles/traffic.json (PMC pass of the same command)"}
-        except Exception:
+                        "source": "profiles/traffic.json (PMC pass of the same command, same sources)"}
+        except Exception as ex:  # noqa: BLE001
+            profile_note = f"profiles/traffic.json unreadable: {ex}"
             traffic = None
-    phys = (traffic / (r["kern_ms"] * 1e-3) / 1e9) if traffic else None
-    step_kernel_ms = r["kern_ms"] + r["views_ms"]
+    phys = (traffic / (kern_ms * 1e-3) / 1e9) if (traffic and kern_ms) else None
+    step_kernel_ms = (kern_ms + views_ms) if (kern_ms and views_ms) else None
     # What bounds the carve is vector-instruction issue (the exact kernel) and dependent-read
     # latency (the classification), not HBM: the roofline is stated against the issue peak --
     # 256 CUs x 4 SIMDs, one wave64 instruction per 2 cycles at 2.4 GHz (the guide's FP32 vector
@@ -585,21 +653,25 @@ def main():
     # command: profiles/traffic.json -- deterministic for a fixed scene), time = this run's.
     VALU_PEAK = 256 * 4 * 2.4e9 / 2 / 1e9  # G wave-instructions / s
     ins_all = sum(valu_all.values()) if valu_all else None
+    ok_k = bool(ins_all and kern_ms)
     roofline = {"bound": "valu-issue",
-                "achieved": (ins_all / (r["kern_ms"] * 1e-3) / 1e9) if ins_all else None,
+                "achieved": (ins_all / (kern_ms * 1e-3) / 1e9) if ok_k else None,
                 "peak": VALU_PEAK, "unit": "G wave-instructions/s",
-                "frac": (ins_all / (r["kern_ms"] * 1e-3) / 1e9 / VALU_PEAK) if ins_all else None,
+                "frac": (ins_all / (kern_ms * 1e-3) / 1e9 / VALU_PEAK) if ok_k else None,
                 "traffic": traffic,
-                "kernel": "carve_coarse_fill_kernel + carve_classify_kernel + "
-                          "carve_exact_blocks_kernel (one arvx_carve call)",
-                "kernel_ms": r["kern_ms"],
+                "kernel": "carve_coarse_kernel + carve_classify_dense_kernel + "
+                          "carve_exact_blocks_kernel<LEFT> (one arvx_carve call of a fresh model)",
+                "kernel_ms": kern_ms,
                 "valu_wave_instructions": valu_all,
                 "dominant_kernel": valu,
+                "profile_note": profile_note,
                 "measured_here": "kernel_ms (HIP events on the launch stream)",
                 "from_profiles": "valu_wave_instructions, traffic, dominant_kernel: "
-                                 "profiles/traffic.json (rocprofv3 --pmc passes of this command)",
+                                 "profiles/traffic.json (rocprofv3 --pmc passes of this command, tied "
+                                 "to the kernel sources by `source_stamp`)",
                 "hbm_effective": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
+                                  "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                                  "algorithmic_bytes": alg_bytes,
                                   "note": "SURVEY 8d's per-view streaming formulation (N*V + V*W*H "
                                           "read bytes) / kernel time: an EFFECTIVE rate -- the "
                                           "kernels keep 2 bits per voxel, write them once and settle "
@@ -609,22 +681,15 @@ def main():
                                  "frac": (phys / HBM_PEAK_GBS) if phys else None,
                                  "note": "2 x FETCH_SIZE + WRITE_SIZE per the guide's gfx950 "
                                          "correction"},
-                "step_jobs_in_flight": (lambda ins: {
-                    "what": "all vector instructions of a step (the six kernels, "
-                            "profiles/traffic.json) / this run's ms_per_step with "
-                            f"{r['jobs']} jobs in flight",
-                    "valu_wave_instructions": ins, "ms_per_step": ms_per_step,
-                    "achieved": ins / (ms_per_step * 1e-3) / 1e9, "peak": VALU_PEAK,
-                    "unit": "G wave-instructions/s",
-                    "frac": ins / (ms_per_step * 1e-3) / 1e9 / VALU_PEAK} if ins else None)(
-                        (ins_all + sum(valu_views.values())) if (ins_all and valu_views) else None),
-                "step": {"kernels": "views_bits + views_tile_sums + views_table "
-                                    "(arvx_set_views_device) + the three carve kernels",
+                "step": {"kernels": "views_strip_kernel (arvx_set_views_device) + the three carve kernels",
                          "kernel_ms": step_kernel_ms,
-                         "hbm_effective_frac": alg_bytes / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "valu_wave_instructions": ((ins_all + sum(valu_views.values()))
+                                                    if (ins_all and valu_views) else None),
+                         "hbm_effective_frac": (alg_bytes / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                         if step_kernel_ms else None,
                          "traffic": traffic_step,
                          "hbm_physical_frac": (traffic_step / (step_kernel_ms * 1e-3) / 1e9 /
-                                               HBM_PEAK_GBS) if traffic_step else None}}
+                                               HBM_PEAK_GBS) if (traffic_step and step_kernel_ms) else None}}
 
     out = {
         "metric": "Mvoxel-views/s (voxels x views / s) + carve wall-time, 512^3 grid x 36 views",
@@ -634,7 +699,7 @@ def main():
         "config": {"workload": f"synthetic sphere silhouettes, {r['X']}x{r['Y']}x{r['Z']} grid, "
                                f"{r['V']} views 640x480, per step: derive bit planes + summed-area "
                                f"tables from the resident u8 masks, then dense carve of a fresh "
-                               f"model by all views",
+                               f"model by all views; one step after the other",
                    "grid": [r["X"], r["Y"], r["Z"]], "views": r["V"],
                    "jobs_in_flight": r["jobs"],
                    "parallelism": f"z-slab x{world} ({r['layout']})" if world > 1 else "single GPU",
@@ -642,24 +707,33 @@ def main():
                    "merged_plane_holds_rank0_planes": r["merge_ok"],
                    "exchange_bytes_per_rank": r["exchange_bytes_per_rank"],
                    "cull": not args.no_cull},
+        "rounds": rounds_out,
         "latency_ms_per_step": r["latency_ms"],
-        "jobs_in_flight_note": (
-            f"`value` / `ms_per_step`: {args.steps} whole steps, {r['jobs']} in flight (job k on context "
-            f"and stream k % {r['jobs']}; every slot's final model compared: slots_agree); "
-            f"`latency_ms_per_step`, the kernel times and the roofline: "
-            f"{r.get('latency_steps', args.steps)} steps one after the other, same frame"
-            if r["jobs"] > 1 else "one job after the other"),
         "slots_agree": r["slots_agree"],
-        "sequential_value": vv / (r["latency_ms"] * 1e-3) / 1e6,
-        "carve_kernel_ms": r["kern_ms"], "views_kernel_ms": r["views_ms"],
+        "carve_kernel_ms": kern_ms, "views_kernel_ms": views_ms,
         "kernel_ms_from": f"HIP events on the launch stream around {r['ev_steps']} of the "
-                          f"{r.get('latency_steps', args.steps)} steps run one after the other (an "
-                          f"event is a packet between dependent kernels: three per step cost "
-                          f"13.6 us of a 0.146 ms step)",
-        "carve_only_value": vv / (r["kern_ms"] * 1e-3) / 1e6,
+                          f"{r.get('latency_steps', args.steps)} steps of one further round (an "
+                          f"event is a packet between dependent kernels; that round is not part of "
+                          f"`value`)",
+        "carve_only_value": (vv / (kern_ms * 1e-3) / 1e6) if kern_ms else None,
         "occupied_fraction": r["occ"],
         "roofline": roofline,
     }
+
+    if world == 1 and rank == 0 and args.jobs_in_flight > 1 and args.jobs == 1:
+        # the same steps with several jobs in flight: a throughput figure of its own, not the headline
+        try:
+            tj_ = run_config(args.grid, args.views, args.steps, min(args.warmup, 5), "none",
+                             jobs=args.jobs_in_flight, rounds=min(3, args.rounds))
+            out["throughput_jobs_in_flight"] = {
+                "jobs": args.jobs_in_flight, "value": vv * args.steps / tj_["dt"] / 1e6,
+                "unit": "Mvoxel-views/s", "ms_per_step": tj_["dt"] / args.steps * 1e3,
+                "rounds_ms_per_step": [d / args.steps * 1e3 for d in tj_["dts"]],
+                "slots_agree": tj_["slots_agree"],
+                "note": f"{args.steps} whole steps dealt to {args.jobs_in_flight} contexts, each on its "
+                        "own stream (job k on slot k % jobs); every slot's final model compared"}
+        except Exception as ex:  # noqa: BLE001
+            out["throughput_jobs_in_flight"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     if world > 1:
         # One scaling run answers every collective question: the headline above is the default
@@ -729,7 +803,7 @@ def main():
     if rank == 0 and world == 1 and args.extra_grid and args.extra_grid != args.grid:
         try:
             k = max(3, args.steps // 4)
-            e = measure(args.extra_grid, args.views, k, 1, "none", args.jobs)
+            e = measure(args.extra_grid, args.views, k, 1, "none", args.jobs, min(3, args.rounds))
             evv = e["nvox"] * e["V"]
             eb = evv + e["V"] * e["sc"].W * e["sc"].H
             out["extra"] = {
@@ -738,7 +812,8 @@ def main():
                 "unit": "Mvoxel-views/s", "carve_kernel_ms": e["kern_ms"],
                 "views_kernel_ms": e["views_ms"], "ms_per_step": e["dt"] / k * 1e3,
                 "jobs_in_flight": e["jobs"], "latency_ms_per_step": e["latency_ms"],
-                "roofline_frac": eb / (e["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "rounds_ms_per_step": [d / k * 1e3 for d in e["dts"]],
+                "roofline_frac": (eb / (e["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if e["kern_ms"] else None,
                 "occupied_fraction": e["occ"]}
         except Exception as ex:  # e.g. not enough memory on a shared box
             out["extra"] = {"error": str(ex)}
@@ -755,11 +830,55 @@ def main():
             out["ablation_no_cull"] = {
                 "value": b["nvox"] * b["V"] / (b["dt"] / k) / 1e6, "unit": "Mvoxel-views/s",
                 "carve_kernel_ms": b["kern_ms"],
-                "roofline": {"bound": "hbm", "achieved": bb / (b["kern_ms"] * 1e-3) / 1e9,
+                "roofline": {"bound": "hbm",
+                             "achieved": (bb / (b["kern_ms"] * 1e-3) / 1e9) if b["kern_ms"] else None,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": bb / (b["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                             "frac": (bb / (b["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if b["kern_ms"] else None}}
         except Exception as ex:
             out["ablation_no_cull"] = {"error": str(ex)}
+
+    if rank == 0 and world == 1 and not args.no_e2e:
+        # SURVEY 8d's second figure: the step with its inputs coming from and its result going to
+        # the HOST -- page-locked u8 masks -> device (arvx_set_views), carve, the carved model's two
+        # bit planes (N / 4 bytes) back into page-locked memory (arvx_state_download_planes)
+        def e2e_entry(N):
+            sc_ = synthetic.sphere_scene(N, args.views)
+            masks = torch.from_numpy(sc_.masks).pin_memory()
+            words = ((N + 31) // 32) * N * N
+            occ = torch.empty(words, dtype=torch.int32).pin_memory()
+            seen = torch.empty(words, dtype=torch.int32).pin_memory()
+            ms = []
+            with capi.Context(N, N, N, sc_.voxel_size, device=dev.index) as c:
+                mnp = masks.numpy()
+                for _ in range(8):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    c.reset()
+                    c.set_views(sc_.M, mnp)
+                    t1 = time.perf_counter()
+                    c.carve(0)
+                    c.synchronize()
+                    t2 = time.perf_counter()
+                    c.download_planes(occ.numpy().view(np.uint32), seen.numpy().view(np.uint32))
+                    t3 = time.perf_counter()
+                    ms.append(((t3 - t0) * 1e3, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
+            a = np.array(ms[3:])  # (the first rounds pay the first uses: staging buffers, pools)
+            tot = float(np.median(a[:, 0]))
+            return {"grid": [N, N, N], "views": args.views, "ms_total": tot,
+                    "ms_masks_h2d_and_views": float(np.median(a[:, 1])),
+                    "ms_carve": float(np.median(a[:, 2])),
+                    "ms_planes_d2h": float(np.median(a[:, 3])),
+                    "value": N ** 3 * args.views / (tot * 1e-3) / 1e6, "unit": "Mvoxel-views/s",
+                    "bytes_h2d": int(sc_.masks.nbytes), "bytes_d2h": int(2 * words * 4)}
+        try:
+            out["e2e"] = {"what": "page-locked host masks -> arvx_set_views -> arvx_carve -> "
+                                  "arvx_state_download_planes into page-locked memory; median of 5 "
+                                  "rounds after 3 warm ones; never part of `value`",
+                          "runs": [e2e_entry(args.grid)] +
+                                  ([e2e_entry(args.extra_grid)] if args.extra_grid and
+                                   args.extra_grid != args.grid else [])}
+        except Exception as ex:  # noqa: BLE001
+            out["e2e"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"], oracle_plane = cpu_baseline(r["sc"], r["X"], r["Y"], r["Z"])

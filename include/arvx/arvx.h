@@ -57,9 +57,9 @@ enum {
 #define ARVX_CARVE_NO_CULL 1u /* evaluate every voxel in every view (ablation) */
 #define ARVX_CARVE_STATS 2u   /* fill the counters read by arvx_get_stats */
 #define ARVX_CARVE_FUSED 8u   /* one kernel for rectangle tests and per-voxel work (A/B) */
-#define ARVX_CARVE_STREAM 16u    /* a fresh model: the one-launch streaming carve whatever the grid size
-                                    (default: from 2^26 voxels; tests force it on small grids) */
-#define ARVX_CARVE_NO_STREAM 32u /* never the streaming carve: the three-launch chain (A/B) */
+#define ARVX_CARVE_STREAM 16u    /* a fresh model: the one-launch streaming carve (A/B and tests; the
+                                    default is the three-launch chain) */
+#define ARVX_CARVE_NO_STREAM 32u /* never the streaming carve */
 
 /* colour modes: reference -color=1 / -color=2 (src/main.cpp:276-288) */
 #define ARVX_COLOR_CLOSEST 0
@@ -299,7 +299,11 @@ typedef struct arvx_color_sample {
     uint8_t r, g, b, valid;
     float depth;
 } arvx_color_sample;
-int arvx_color_samples(arvx_ctx *ctx, int64_t n, const int64_t *index, arvx_color_sample *out);
+/* views: the samples per voxel `out` has room for -- must be the context's number of views
+ * (ARVX_ERR_INVALID otherwise: a caller that sized its buffer for another set of views is told so
+ * instead of being written past its end). */
+int arvx_color_samples(arvx_ctx *ctx, int64_t n, const int64_t *index, int views,
+                       arvx_color_sample *out);
 
 /* Replace the device-side sparse colours by a caller-supplied list (n voxels,
  * ascending flat index, 3 floats RGB each, w = 1): lets a host Model that was

@@ -27,7 +27,13 @@ namespace detail {
 class HostPool {
    public:
     static constexpr size_t kSmall = 256 * 1024;     // below this: plain malloc
-    static constexpr size_t kKeepBytes = 4ull << 30;  // idle blocks kept, in total
+    // idle blocks kept, in total (page-locked memory stays locked while it idles): 1 GiB unless
+    // the program says otherwise -- HostPool::instance().set_keep_bytes(...)
+    size_t keep_bytes_ = 1ull << 30;
+    void set_keep_bytes(size_t bytes) {
+        std::lock_guard<std::mutex> lock(m_);
+        keep_bytes_ = bytes;
+    }
     static HostPool &instance() {
         static HostPool *pool = new HostPool();  // never destroyed: no HIP calls at exit
         return *pool;
@@ -68,7 +74,7 @@ class HostPool {
         std::lock_guard<std::mutex> lock(m_);
         for (size_t i = 0; i < blocks_.size(); ++i)
             if (blocks_[i].p == p) {
-                if (idle_ + blocks_[i].cap > kKeepBytes) {
+                if (idle_ + blocks_[i].cap > keep_bytes_) {
                     drop(i);
                 } else {
                     blocks_[i].used = false;

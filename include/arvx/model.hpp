@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <fstream>
 #include <iostream>
 #include <memory>
@@ -210,9 +211,17 @@ class Model {
         if (link_ && link_->ctx && !sampled_.empty() &&
             std::binary_search(sampled_.begin(), sampled_.end(), flat)) {
             std::vector<arvx_color_sample> smp((size_t)sample_views_);
-            if (arvx_color_samples(link_->ctx, 1, &flat, smp.data()) == ARVX_OK)
+            const int rc = arvx_color_samples(link_->ctx, 1, &flat, sample_views_, smp.data());
+            if (rc == ARVX_OK) {
                 for (const arvx_color_sample &c : smp)
                     if (c.valid) out.push_back(DCLR{Vec4f((float)c.r, (float)c.g, (float)c.b, 1.f), c.depth});
+            } else {
+                // the context no longer holds that pass's views / images (or another number of
+                // views): say so once, the device part of the list is gone
+                std::fprintf(stderr, "arvx::Model::getColors: the device samples are gone (%s)\n",
+                             arvx_last_error());
+                sampled_.clear();
+            }
         }
         auto it = color_lists_.find((int)flat);
         if (it != color_lists_.end()) out.insert(out.end(), it->second.begin(), it->second.end());
@@ -355,6 +364,8 @@ class Model {
         return link_->ctx;
     }
     // the device context for a stage that only READS the occupancy (marching-cubes cells)
+    // the context if the model has one already (nothing is created or uploaded)
+    arvx_ctx *device_if_any() const { return link_ ? link_->ctx : nullptr; }
     arvx_ctx *device_for_reading(int device_index = 0) {
         mc_only_ = true;
         arvx_ctx *c = device(device_index);
@@ -367,6 +378,7 @@ class Model {
         host_stale_ = true;
         paint_is_unseen_ = false;  // (carving sees voxels; closure adds some)
         colors_on_device_ = false;  // (arvx_carve* drops the context's colour list)
+        sampled_.clear();           // (... and with it what getColors could ask the device for)
     }
     // the closure's result is in the context (filled voxels marked occupied): marching cubes can
     // run on it, but anything else that changes the state has to start from an upload again
@@ -583,7 +595,7 @@ class Model {
     HostVector<Vec4f> fval_;
     std::unordered_map<int, Vec4f> overlay_;  // ... and what single set() calls stored since
     std::unordered_map<int, std::vector<DCLR>> color_lists_;
-    std::vector<int64_t> sampled_;  // voxels the last device colour pass coloured (getColors)
+    mutable std::vector<int64_t> sampled_;  // voxels the last device colour pass coloured (getColors)
     int sample_views_ = 0;
     std::shared_ptr<detail::DeviceLink> link_;
 

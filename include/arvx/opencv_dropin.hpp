@@ -230,11 +230,26 @@ inline void prepare(cv::Mat &cameraMatrix, cv::Mat &distCoeffs, std::vector<cv::
 // ---- the reference's signatures, at global scope like the reference ----
 using Model = arvx::Model;
 
+namespace arvx {
+namespace dropin {
+// arvx_set_projection_assoc (self_pin) only reaches contexts created afterwards: a model whose
+// context exists already -- uploaded, closed or meshed before its first carve here -- gets what
+// cv::gemm showed as well, so that one process never carves with two groupings.
+inline void apply_pin(Model &model) {
+    const PinReport &rep = self_pin();
+    if (rep.assoc >= 0 && model.device_if_any())
+        detail::check(arvx_ctx_set_projection_assoc(model.device_if_any(), rep.assoc),
+                      "arvx_ctx_set_projection_assoc");
+}
+}  // namespace dropin
+}  // namespace arvx
+
 inline void carve(cv::Mat &cameraMatrix, cv::Mat &distCoeffs, Model &model,
                   std::vector<cv::Mat> &images, std::vector<cv::Mat> &masks,
                   bool intermediateMeshes = false) {
     arvx::dropin::Prepared p;
     arvx::dropin::prepare(cameraMatrix, distCoeffs, images, masks, false, p);
+    arvx::dropin::apply_pin(model);
     arvx::carve(p.intr, model, p.views, intermediateMeshes);
 }
 
@@ -242,6 +257,7 @@ inline void fastCarve(cv::Mat &cameraMatrix, cv::Mat &distCoeffs, Model &model,
                       std::vector<cv::Mat> &images, std::vector<cv::Mat> &masks) {
     arvx::dropin::Prepared p;
     arvx::dropin::prepare(cameraMatrix, distCoeffs, images, masks, false, p);
+    arvx::dropin::apply_pin(model);
     arvx::fastCarve(p.intr, model, p.views);
 }
 
@@ -249,6 +265,7 @@ inline void reconstructClosestColor(cv::Mat &cameraMatrix, cv::Mat &distCoeffs, 
                                     std::vector<cv::Mat> &images, std::vector<cv::Mat> &masks) {
     arvx::dropin::Prepared p;
     arvx::dropin::prepare(cameraMatrix, distCoeffs, images, masks, true, p);
+    arvx::dropin::apply_pin(model);
     arvx::reconstructClosestColor(p.intr, model, p.views);
 }
 
@@ -256,6 +273,7 @@ inline void reconstructAvgColor(cv::Mat &cameraMatrix, cv::Mat &distCoeffs, Mode
                                 std::vector<cv::Mat> &images, std::vector<cv::Mat> &masks) {
     arvx::dropin::Prepared p;
     arvx::dropin::prepare(cameraMatrix, distCoeffs, images, masks, true, p);
+    arvx::dropin::apply_pin(model);
     arvx::reconstructAvgColor(p.intr, model, p.views);
 }
 

@@ -30,32 +30,43 @@ def last_json_line(text):
 
 def test_one_gpu_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--grid", "128", "--steps", "9",
-                        "--warmup", "2", "--extra-grid", "0", "--no-workloads", "--no-ablation"],
+                        "--warmup", "2", "--extra-grid", "0", "--no-workloads", "--no-ablation",
+                        "--rounds", "3"],
                        capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json_line(r.stdout)
     for k in CONTRACT:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 9 and d["warmup"] == 2 and d["higher_is_better"] is True
-    assert d["config"]["jobs_in_flight"] == 4 and d["slots_agree"] is True
+    # the headline is one step after the other; several jobs in flight is a figure of its own
+    assert d["config"]["jobs_in_flight"] == 1 and d["slots_agree"] is True
+    assert d["rounds"]["n"] == 3 and len(d["rounds"]["ms_per_step"]) == 3
+    assert d["rounds"]["min"] <= d["ms_per_step"] <= d["rounds"]["max"]
+    t = d["throughput_jobs_in_flight"]
+    assert t["jobs"] == 4 and t["slots_agree"] is True and t["value"] > 0
+    assert d["e2e"]["runs"][0]["ms_total"] > 0 and d["e2e"]["runs"][0]["bytes_h2d"] > 0
     assert d["parity_vs_oracle"] is True
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["latency_ms_per_step"] > 0
     assert d["roofline"]["kernel_ms"] > 0 and d["cpu_baseline"]["value"] > 0
     assert d["vs_baseline"] is None and d["scaling"] == "weak"
 
 
-def test_two_rank_rehearsal_every_collective():
+@pytest.mark.parametrize("jobs", [1, 4])
+def test_two_rank_rehearsal_every_collective(jobs):
+    # jobs = 1: the driver's line (one job after the other, the hand-off on side streams beside the
+    # next job); jobs = 4: every slot hands its job over in its own stream
     env = dict(os.environ, ARVX_BENCH_ONE_GPU="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "128", "--steps", "9",
-                        "--warmup", "2", "--no-mgpu"],
+                        "--warmup", "2", "--no-mgpu", "--rounds", "2", "--jobs", str(jobs)],
                        capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = last_json_line(r.stdout)
     for k in CONTRACT:
         assert k in d, k
-    assert d["n_gpus"] == 2 and d["config"]["jobs_in_flight"] == 4 and d["slots_agree"] is True
+    assert d["n_gpus"] == 2 and d["config"]["jobs_in_flight"] == jobs and d["slots_agree"] is True
+    assert d["rounds"]["n"] == 2
     assert d["config"]["merged_plane_holds_rank0_planes"] is True
     assert set(d["collectives"]) == {"compressed", "allreduce", "allgather"}
     for name, c in d["collectives"].items():

@@ -300,3 +300,85 @@ def test_assoc_kat_tells_the_groupings_apart(oracle):
     assert diff.tolist() == [[tz, ty, tx]]  # the only voxel the grouping decides
     a, _, _ = npr.project_raw(M[0], s, np.array(tx), np.array(ty), np.array(tz), assoc_left=False)
     assert a[0] == np.float32(1.0) + np.float32(2.0 ** -23)
+
+
+# ---- the OpenCV pin (tools/pin_with_opencv.py --emit tests/golden/opencv_pin.json) ------------------
+
+
+def check_pin(doc, oracle):
+    """Holds the C oracle and the numpy twin to what an OpenCV computed on the probes of
+    tests/pin_probes.py.  Returns the grouping the file records."""
+    from tests import np_restate as npr, pin_probes
+    assert doc["grouping"] in ("LEFT", "RIGHT"), f"cv::gemm sums its products in a way the library does not know: {doc}"
+    left = doc["grouping"] == "LEFT"
+    M, s, xyz = pin_probes.projection_probes()
+    want = np.array(doc["projection_rows_bits"], np.uint32).reshape(-1, 3)
+    with oracle.variant("assoc_left" if left else "assoc_right"):
+        # the voxel the grouping decides (random probes differ only once in ~10^8)
+        kat = oracle.project_raw(pin_probes.kat_matrix(), np.float32(1.0), 1, 1, 1)[:1].view(np.uint32)[0]
+        assert int(kat) == doc["kat_row0_bits"], "the known-answer voxel contradicts the recorded grouping"
+        for i, (x, y, z) in enumerate(xyz):
+            got = oracle.project_raw(M, s, x, y, z)[:3].view(np.uint32)
+            assert np.array_equal(got, want[i]), f"oracle rows of probe {i} differ from cv::gemm"
+    a, _, _ = npr.project_raw(M, s, xyz[:, 0], xyz[:, 1], xyz[:, 2], assoc_left=left)
+    assert np.array_equal(np.stack(a, 1).astype(np.float32).view(np.uint32), want), "numpy twin rows"
+    campos, s, xyz = pin_probes.depth_probes()
+    wantd = np.array(doc["depth_bits"], np.uint32)
+    gotd = np.array([oracle.depth(campos, s, x, y, z) for x, y, z in xyz], np.float32).view(np.uint32)
+    assert np.array_equal(gotd, wantd), "oracle depths differ from cv::norm"
+    src, K, dist = pin_probes.undistort_probe()
+    assert np.array_equal(npr.undistort(src, K, dist).reshape(-1),
+                          np.array(doc["undistort_u8"], np.uint8)), "restated undistort differs from cv::undistort"
+    return doc["grouping"]
+
+
+def test_opencv_pin_file(oracle):
+    """When an OpenCV host has committed its answers, the oracle is PINNED to them (DESIGN.md 2);
+    a recorded grouping that is not the library's default fails here and says what to change."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "opencv_pin.json")
+    if not os.path.exists(path):
+        pytest.skip("no tests/golden/opencv_pin.json yet: run tools/pin_with_opencv.py --emit on an OpenCV host")
+    grouping = check_pin(json.load(open(path)), oracle)
+    default_left = oracle.assoc() == 1
+    assert (grouping == "LEFT") == default_left, (
+        f"OpenCV {grouping} but the oracle / library default is {'LEFT' if default_left else 'RIGHT'}: flip "
+        "g_default_assoc (csrc/arvx_capi.hip), ARVX_ORACLE default (oracle/arvx_oracle.c) and np_restate")
+
+
+@pytest.mark.parametrize("left", [True, False])
+def test_opencv_pin_loop_with_a_stand_in(oracle, left):
+    """The emit -> check loop itself, with a stand-in for cv2 that computes the probes with the numpy
+    twin under either grouping (test plumbing: it says nothing about OpenCV, it shows that a pin file
+    of either grouping is read, compared bit for bit and told apart)."""
+    from tests import np_restate as npr, pin_probes
+
+    class FakeCv2:
+        __version__ = "stand-in"
+
+        @staticmethod
+        def gemm(A, B, alpha, C, beta):
+            A64, B64 = A.astype(np.float64), B.astype(np.float64).reshape(4)
+            out = []
+            for r in range(A.shape[0]):
+                p = A64[r] * B64
+                out.append(np.float32(((p[0] + p[1]) + p[2]) + p[3] if left else p[0] + ((p[1] + p[2]) + p[3])))
+            return np.array(out, np.float32).reshape(-1, 1)
+
+        @staticmethod
+        def norm(d):
+            d = d.reshape(-1).astype(np.float64)
+            return np.float32(np.sqrt(((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]))
+
+        @staticmethod
+        def undistort(src, K, dist):
+            return npr.undistort(src, K, dist)
+
+    doc = pin_probes.emit(FakeCv2)
+    assert doc["grouping"] == ("LEFT" if left else "RIGHT")
+    assert check_pin(doc, oracle) == doc["grouping"]
+    # a file of the OTHER grouping must not pass as this one
+    doc2 = dict(doc, grouping="RIGHT" if left else "LEFT")
+    with pytest.raises(AssertionError):
+        check_pin(doc2, oracle)

@@ -1,0 +1,107 @@
+"""The streaming carve (csrc/carve_stream_kernels.h: ONE persistent launch -- coarse units, sub-tile
+units and items handed from workgroup to workgroup as tagged granules) against the oracle and
+against the three-launch chain: the same model, voxel for voxel, whatever the grid, slab, stripe or
+view count; launch after launch on one context (tags, tickets and the control block carry over);
+several contexts at once (launches that share the chip).  Reference: src/VoxelCarving.cpp:60-72."""
+import numpy as np
+import pytest
+
+from tests import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def carve(arvx, X, Y, Z, s, M, masks, flags, **kw):
+    with arvx.Context(X, Y, Z, s, **kw) as ctx:
+        ctx.set_views(M, masks)
+        ctx.carve(flags)
+        return ctx.download_state()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_streaming_equals_oracle_on_random_ragged_grids(arvx, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    X, Y, Z = (int(v) for v in rng.integers(1, 150, size=3))
+    V = int(rng.choice([1, 2, 7, 36, 64, 65, 70, 130]))
+    W, H = (640, 480) if seed % 2 else (320, 240)
+    extent = 0.3
+    s = np.float32(extent / max(X, Y, Z))
+    _, _, M = scenes.random_cameras(V, extent, seed=seed, W=W, H=H, inside=bool(seed % 3 == 0))
+    masks = scenes.noise_masks(V, H, W, block=int(rng.choice([1, 4, 16, 64])), p_bg=float(rng.uniform(0.05, 0.7)),
+                               seed=seed + 7)
+    want = oracle.carve(X, Y, Z, s, M, masks)
+    got = carve(arvx, X, Y, Z, s, M, masks, arvx.CARVE_STREAM)
+    assert np.array_equal(got, want), f"{X}x{Y}x{Z} x {V}: {(got != want).sum()} voxels differ"
+
+
+def test_streaming_on_slabs_and_stripes(arvx, oracle):
+    N, V = 160, 24
+    sc = scenes.small_sphere(N, V, W=640, H=480)
+    want = oracle.carve(N, N, N, sc.voxel_size, sc.M, sc.masks)
+    parts = [carve(arvx, N, N, N, sc.voxel_size, sc.M, sc.masks, arvx.CARVE_STREAM, z_range=r)
+             for r in [(0, 50), (50, 51), (51, 160)]]
+    assert np.array_equal(np.concatenate(parts, axis=0), want), "contiguous slabs"
+    for world in (2, 4):
+        for rank in range(world):
+            with arvx.Context(N, N, N, sc.voxel_size, stripes=(world, rank)) as ctx:
+                ctx.set_views(sc.M, sc.masks)
+                ctx.carve(arvx.CARVE_STREAM)
+                got = ctx.download_state()
+                assert np.array_equal(got, want[ctx.planes]), f"stripes {rank}/{world}"
+
+
+def test_streaming_launch_after_launch(arvx, oracle):
+    """One context, many launches: the granules of earlier launches (other scenes, longer lists)
+    lie in the same memory and must be told from this launch's by their tag; the control block
+    is reset by the last workgroup of every launch; the streaming and the three-launch carve
+    alternate on the same records."""
+    N = 128
+    with arvx.Context(N, N, N, np.float32(0.3 / N)) as ctx:
+        for k in range(24):
+            V = [36, 8, 70, 3][k % 4]
+            _, _, M = scenes.random_cameras(V, 0.3, seed=k, W=320, H=240)
+            masks = scenes.noise_masks(V, 240, 320, block=[2, 32, 8][k % 3], p_bg=0.3 + 0.02 * k, seed=50 + k)
+            ctx.set_views(M, masks)
+            ctx.reset()
+            ctx.carve(arvx.CARVE_STREAM if k % 3 else arvx.CARVE_NO_STREAM)
+            got = ctx.download_state()
+            want = oracle.carve(N, N, N, np.float32(0.3 / N), M, masks)
+            assert np.array_equal(got, want), f"launch {k}"
+            if k % 5 == 4:  # a model that is not fresh takes the three launches; then fresh again
+                ctx.carve(arvx.CARVE_STREAM)
+                assert np.array_equal(ctx.download_state(), want), f"launch {k}, carved twice"
+
+
+def test_streaming_launches_share_the_chip(arvx, oracle):
+    """Several contexts, each on its own stream, all launched before any is waited for: every launch
+    is a full grid of resident workgroups, so they are resident only in part while the others run --
+    nothing may wait for a workgroup that has not started."""
+    N, V = 192, 36
+    sc = scenes.small_sphere(N, V, W=640, H=480)
+    want = oracle.carve(N, N, N, sc.voxel_size, sc.M, sc.masks)
+    ctxs = [arvx.Context(N, N, N, sc.voxel_size) for _ in range(6)]
+    try:
+        for c in ctxs:
+            c.set_views(sc.M, sc.masks)
+        for rep in range(3):
+            for c in ctxs:
+                c.reset()
+                c.carve(arvx.CARVE_STREAM)
+            for k, c in enumerate(ctxs):
+                c.synchronize()  # (raises if a wait inside the launch gave up)
+                assert np.array_equal(c.download_state(), want), f"context {k}, round {rep}"
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_streaming_with_nothing_undecided(arvx, oracle):
+    """All-background and all-foreground masks: every coarse tile is settled by the first phase, the
+    list stays empty, no sub-tile unit and no item exists -- the launch must still end."""
+    N, V = 96, 5
+    sc = scenes.small_sphere(N, V, W=320, H=240)
+    for fill in (0, 255):
+        masks = np.full_like(sc.masks, fill)
+        want = oracle.carve(N, N, N, sc.voxel_size, sc.M, masks)
+        got = carve(arvx, N, N, N, sc.voxel_size, sc.M, masks, arvx.CARVE_STREAM)
+        assert np.array_equal(got, want), f"masks all {fill}"

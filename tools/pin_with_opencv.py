@@ -12,7 +12,15 @@ it (run on any host that has cv2 + numpy; no GPU needed):
 
 Prints the three answers; exit code 0 when OpenCV agrees with the library's defaults, 1 when
 something differs (say which), 2 when cv2 is missing.  The same checks run inside a C++ build
-against OpenCV: include/arvx/opencv_dropin.hpp (dropin::self_pin)."""
+against OpenCV: include/arvx/opencv_dropin.hpp (dropin::self_pin).
+
+    python tools/pin_with_opencv.py --emit tests/golden/opencv_pin.json
+
+writes what this OpenCV computes on the probes of tests/pin_probes.py (its version, the grouping,
+64 projected rows, 64 cv::norm depths, the undistorted ramp).  COMMITTING THAT FILE is what turns
+the repository's parity from "unpinned" to pinned: tests/test_oracle_cpu.py::test_opencv_pin_file
+then holds the C oracle and the numpy twin to it bit for bit, and fails when the recorded grouping
+is not the library's default."""
 import os
 import sys
 
@@ -30,6 +38,15 @@ def main() -> int:
               "opencv-python-headless).")
         return 2
     print("OpenCV", cv2.__version__)
+    if len(sys.argv) >= 3 and sys.argv[1] == "--emit":
+        import json
+        from tests import pin_probes
+        doc = pin_probes.emit(cv2)
+        with open(sys.argv[2], "w") as f:
+            json.dump(doc, f)
+        print(f"wrote {sys.argv[2]}: grouping {doc['grouping']}; commit it (tests/golden/) and run "
+              "python -m pytest tests/test_oracle_cpu.py -k opencv_pin")
+        return 0 if doc["grouping"] in ("LEFT", "RIGHT") else 1
     rc = 0
     # 1. the known-answer voxel of tests/scenes.py::assoc_kat
     M = np.zeros((3, 4), np.float32)
