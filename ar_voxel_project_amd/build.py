@@ -15,16 +15,19 @@ def _make(directory: str, *targets: str) -> None:
         raise RuntimeError(f"{' '.join(cmd)} failed:\n{res.stdout}")
 
 
+STEP_KERNEL_SOURCES = ("arvx_device.h", "carve_kernels.h", "views_kernels.h")
+
+
 def source_stamp() -> str:
-    """sha256 (16 hex digits) over the kernel sources of libarvx.so: what ties a PMC pass under
-    profiles/ (tools/make_traffic.py) to the build bench.py is running."""
-    import glob
+    """sha256 (16 hex digits) over the sources of the kernels of a bench step (view derivation +
+    carve): what ties a PMC pass under profiles/ (tools/make_traffic.py) to the build bench.py
+    is running."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "ar_voxel_project_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip"))):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+    for name in STEP_KERNEL_SOURCES:
+        h.update(name.encode())
+        h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
 

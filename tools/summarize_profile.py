@@ -18,7 +18,7 @@ def kernel_key(name):
         if "carve_" + k in name:
             return k
     # arvx_set_views_device (round 1 names, then csrc/views_kernels.h)
-    for k in ("mask_to_bits", "sat_rows", "sat_cols", "views_bits", "views_tile_sums",
+    for k in ("mask_to_bits", "sat_rows", "sat_cols", "views_strip", "views_bits", "views_tile_sums",
               "views_table", "views_rows", "views_cols"):
         if k in name:
             return k
