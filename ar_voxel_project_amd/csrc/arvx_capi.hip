@@ -1253,7 +1253,7 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         const size_t nitems = cap * arvx::kWorkLists;
         // one persistent workgroup per workgroup slot of the chip (4 per CU at 128 VGPRs)
         static const int exact_wgs = experiment_int("ARVX_EXACT_WGS_PER_CU");  // (A/B builds)
-        const unsigned pgrid = (unsigned)ncu * (exact_wgs > 0 ? (unsigned)exact_wgs : 4u);
+        const unsigned pgrid = (unsigned)ncu * (exact_wgs > 0 ? (unsigned)exact_wgs : (unsigned)ARVX_EXACT_WAVES_PER_SIMD);
         const size_t nwaves = (size_t)pgrid * 4;
         const size_t nctr_pool = (size_t)arvx::kPoolCounters * arvx::kCounterStride;
         const size_t ints = nctr + nctr_pool;  // list fill counters, pool ticket counters
@@ -1395,11 +1395,24 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         p.timeline = (unsigned long long *)ctx->d_timeline;
 #endif
         const bool left = ctx->assoc == ARVX_ASSOC_LEFT;
-        if (blocks && left)
-            hipLaunchKernelGGL(arvx::carve_exact_blocks_kernel<true>, dim3(pgrid), dim3(256), 0,
+        const bool may_split = p.flags & 8u;
+        if (blocks && left && may_split)
+            hipLaunchKernelGGL((arvx::carve_exact_blocks_kernel<true, true>), dim3(pgrid), dim3(256), 0,
+                               ctx->stream, p);
+        else if (blocks && left && fresh)
+            hipLaunchKernelGGL((arvx::carve_exact_blocks_kernel<true, false, true>), dim3(pgrid), dim3(256), 0,
+                               ctx->stream, p);
+        else if (blocks && left)
+            hipLaunchKernelGGL((arvx::carve_exact_blocks_kernel<true, false>), dim3(pgrid), dim3(256), 0,
+                               ctx->stream, p);
+        else if (blocks && may_split)
+            hipLaunchKernelGGL((arvx::carve_exact_blocks_kernel<false, true>), dim3(pgrid), dim3(256), 0,
+                               ctx->stream, p);
+        else if (blocks && fresh)
+            hipLaunchKernelGGL((arvx::carve_exact_blocks_kernel<false, false, true>), dim3(pgrid), dim3(256), 0,
                                ctx->stream, p);
         else if (blocks)
-            hipLaunchKernelGGL(arvx::carve_exact_blocks_kernel<false>, dim3(pgrid), dim3(256), 0,
+            hipLaunchKernelGGL((arvx::carve_exact_blocks_kernel<false, false>), dim3(pgrid), dim3(256), 0,
                                ctx->stream, p);
         else if (left)
             hipLaunchKernelGGL(arvx::carve_exact_kernel<true>, dim3(pgrid), dim3(256), 0,

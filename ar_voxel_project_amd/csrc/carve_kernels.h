@@ -1663,8 +1663,15 @@ __device__ __forceinline__ unsigned block_tests_lds(const CarveParams &p, const 
     return needLanes;
 }
 
-template <bool LEFT>
-__global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveParams p) {
+#ifndef ARVX_EXACT_WAVES_PER_SIMD
+#define ARVX_EXACT_WAVES_PER_SIMD 4  // (A/B builds: 5 -> 102 registers, see EXPERIMENTS.md)
+#endif
+// SPLIT: items may be handed to several waves (flags bit3: small grids and slabs).  The large
+// grids never do: their instantiation carries none of that code (no atomic merge of the parts,
+// fewer registers alive across an item).
+// FRESH: the model is fresh (flags bit2) -- known when the kernel is compiled: no record is read.
+template <bool LEFT, bool SPLIT = true, bool FRESH = false>
+__global__ __launch_bounds__(256, ARVX_EXACT_WAVES_PER_SIMD) void carve_exact_blocks_kernel(const CarveParams p) {
 #ifdef ARVX_TIMELINE
     WaveTimeline wave_timeline(p.timeline);
 #endif
@@ -1674,8 +1681,9 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
     // (Tried and dropped: leaving the pure fill of the decided tiles to a quarter of these
     // workgroups so that it overlaps the exact work -- the fill saturates HBM and the
     // exact waves, which live on memory latency, slow down by more than the fill costs.)
-    for_each_work_item<true>(p, lane, blockIdx.x * 4 + (threadIdx.x >> 6), p.nwaves,
-                          [&](const size_t it, const int part, const int list, const int pshift) {
+    for_each_work_item<SPLIT>(p, lane, blockIdx.x * 4 + (threadIdx.x >> 6), p.nwaves,
+                          [&](const size_t it, const int part, const int list, const int pshift_) {
+            const int pshift = SPLIT ? pshift_ : 0;
             // the kernel ends on its longest items (an item's views run one after the other):
             // the items of the heavy weight classes get the SIMD's issue slots first
             // (512^3: -1.2 %, 1024^3: no change; the waves of a SIMD mostly hold items of
@@ -1711,7 +1719,7 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
                 for (int bzi = 0; bzi < 2; ++bzi) {
                     const int r = (4 * bzi + lz) * 8 + 4 * byi + ly;
                     uint32_t o, sn;
-                    if (p.flags & 4u) {  // fresh model, never written: all occupied, none seen
+                    if (FRESH || (p.flags & 4u)) {  // fresh model, never written: all occupied, none seen
                         o = row_inmask(p, tx, ty, tz, wave, r);
                         sn = ~o & 0xffffu;
                     } else if (pshift) {
@@ -1754,7 +1762,12 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
                     uniform64(c ? p.itemMasks[(it * p.nchunks + c) * 2 + 1] : fast0);
                 // block-level rectangle tests first: what they settle is applied at once
                 unsigned bcarved = 0, bseen = 0;
-                const unsigned needLanes = (p.flags & 32u)
+#ifdef ARVX_EXPERIMENTS  // (flags bit5: the A/B switch of the block tests exists in experiment builds only)
+                const bool no_bt = p.flags & 32u;
+#else
+                constexpr bool no_bt = false;
+#endif
+                const unsigned needLanes = no_bt
                                                ? 0xffffu
                                                : block_tests(p, t, p.v0 + 64 * c, mixed, part, pshift,
                                                              lane, bcarved, bseen);
@@ -1776,7 +1789,7 @@ __global__ __launch_bounds__(256, 4) void carve_exact_blocks_kernel(const CarveP
                     const int b = __ffsll((long long)mixed) - 1;
                     mixed &= mixed - 1;
                     if ((nth & ((1 << pshift) - 1)) != part) continue;  // another part's view
-                    const unsigned need = (p.flags & 32u)
+                    const unsigned need = no_bt
                                               ? 0xffffu
                                               : (unsigned)__builtin_amdgcn_readlane(needLanes, slot);
                     ++slot;
