@@ -51,7 +51,7 @@ SYMBOLS = [
     "arvx_mc_cells", "arvx_mc_cells_download", "arvx_mc_mesh", "arvx_mc_mesh_download",
     "arvx_mc_mesh_download_faces",
     "arvx_occupancy_packet_words", "arvx_occupancy_compress", "arvx_occupancy_expand",
-    "arvx_occupancy_expand_striped",
+    "arvx_occupancy_expand_striped", "arvx_occupancy_pack_compress", "arvx_occupancy_expand_striped_others",
     "arvx_export_model", "arvx_get_stats", "arvx_selftest_divide", "arvx_selftest_round",
 ]
 
@@ -162,6 +162,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
             lib.arvx_occupancy_expand_striped.argtypes = [p, C.c_void_p, C.c_int, C.c_int64,
                                                           C.c_int64, C.c_int64, C.c_void_p,
                                                           C.c_void_p]
+        if hasattr(lib, "arvx_occupancy_pack_compress"):
+            lib.arvx_occupancy_pack_compress.argtypes = [p, C.c_void_p, C.c_int64, C.c_void_p]
+            lib.arvx_occupancy_expand_striped_others.argtypes = [p, C.c_void_p, C.c_int, C.c_int, C.c_int64,
+                                                                 C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     for name in SYMBOLS:
         if ab_build and not hasattr(lib, name):
             continue
@@ -449,6 +453,19 @@ class Context:
         self._ck(self._lib.arvx_occupancy_expand_striped(
             self._h, C.c_void_p(dev_packets_ptr), world, n_words64, cap_words64, words_per_group,
             C.c_void_p(dev_full_ptr), C.c_void_p(dev_overflow_ptr)))
+
+    def occupancy_pack_compress(self, dev_packet_ptr: int, cap_words64: int, dev_full_ptr: int = 0) -> None:
+        """The context's planes -> their packet, straight from the state; with dev_full_ptr the
+        rank's own words also go to their place in the whole grid's plane."""
+        self._ck(self._lib.arvx_occupancy_pack_compress(self._h, C.c_void_p(dev_packet_ptr), cap_words64,
+                                                      C.c_void_p(dev_full_ptr)))
+
+    def occupancy_expand_striped_others(self, dev_packets_ptr: int, world: int, self_rank: int,
+                                        n_words64: int, cap_words64: int, words_per_group: int,
+                                        dev_full_ptr: int, dev_overflow_ptr: int) -> None:
+        self._ck(self._lib.arvx_occupancy_expand_striped_others(
+            self._h, C.c_void_p(dev_packets_ptr), world, self_rank, n_words64, cap_words64,
+            words_per_group, C.c_void_p(dev_full_ptr), C.c_void_p(dev_overflow_ptr)))
 
     def set_stream(self, stream_ptr: int) -> None:
         self._ck(self._lib.arvx_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))

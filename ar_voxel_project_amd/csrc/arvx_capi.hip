@@ -1067,6 +1067,41 @@ int arvx_occupancy_compress(arvx_ctx *ctx, const void *dev_words, int64_t n_word
     return ARVX_OK;
 }
 
+int arvx_occupancy_pack_compress(arvx_ctx *ctx, void *dev_packet, int64_t cap_words64,
+                                 void *dev_full_words) {
+    ARVX_CHECK_CTX(ctx);
+    ExchangeStreamScope exchange_scope(ctx);
+    if (!dev_packet || cap_words64 < 0) return fail(ARVX_ERR_INVALID, "bad argument");
+    if (((uintptr_t)dev_packet | (uintptr_t)dev_full_words) & 7u)
+        return fail(ARVX_ERR_INVALID, "buffers must be 8-byte aligned");
+    const size_t plane = (size_t)ctx->X * ctx->Y;
+    if (ctx->X % 32 || plane % 64)
+        return fail(ARVX_ERR_INVALID, "needs X %% 32 == 0 and X*Y %% 64 == 0 (X=%d, Y=%d)", ctx->X, ctx->Y);
+    if (int mrc = need_rec(ctx, true)) return mrc;
+    arvx::CarveParams g;
+    carve_geometry(ctx, g);
+    g.rec = ctx->d_rec;
+    const int zl0 = ctx->z0 - ctx->ze0, nz = ctx->z1 - ctx->z0;
+    const long long n = (long long)(plane / 64) * nz, nb = (n + 63) / 64;
+    if (2 * n >= (1ll << 32)) return fail(ARVX_ERR_INVALID, "slab too large for the fused packet (%lld words)", n);
+    const int nwg = (int)((nb + arvx::kOccGroupsPerWg - 1) / arvx::kOccGroupsPerWg);
+    arvx::OccGeom og;
+    og.wpr = arvx::fast_div((unsigned)(ctx->X / 32));
+    og.Y = arvx::fast_div((unsigned)ctx->Y);
+    og.P64 = arvx::fast_div((unsigned)(plane / 64));
+    // (a buffer of its own: the call may run on the exchange stream beside the next job's views)
+    ARVX_HIP(ctx->pool_xscratch.reserve((size_t)(nwg + 1) * sizeof(long long) +
+                                        (size_t)nwg * sizeof(int) + 64));
+    int *d_wgsum = (int *)((long long *)ctx->pool_xscratch.p + nwg + 1);
+    hipLaunchKernelGGL(arvx::occ_pack_classify_kernel, dim3(nwg), dim3(256), 0, ctx->stream, g, og, zl0, n,
+                       (unsigned long long *)dev_packet, d_wgsum, (unsigned long long *)dev_full_words);
+    hipLaunchKernelGGL(arvx::occ_pack_write_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0,
+                       ctx->stream, g, og, zl0, n, (long long)cap_words64, d_wgsum, nwg,
+                       (unsigned long long *)dev_packet);
+    ARVX_HIP(hipGetLastError());
+    return ARVX_OK;
+}
+
 int arvx_occupancy_expand(arvx_ctx *ctx, const void *dev_packets, int world, int self_rank,
                           int64_t n_words64, int64_t cap_words64, void *dev_full_words,
                           int *dev_overflow) {
@@ -1091,8 +1126,17 @@ int arvx_occupancy_expand(arvx_ctx *ctx, const void *dev_packets, int world, int
 int arvx_occupancy_expand_striped(arvx_ctx *ctx, const void *dev_packets, int world,
                                   int64_t n_words64, int64_t cap_words64, int64_t words_per_group,
                                   void *dev_full_words, int *dev_overflow) {
+    return arvx_occupancy_expand_striped_others(ctx, dev_packets, world, -1, n_words64, cap_words64,
+                                                words_per_group, dev_full_words, dev_overflow);
+}
+
+int arvx_occupancy_expand_striped_others(arvx_ctx *ctx, const void *dev_packets, int world,
+                                         int self_rank, int64_t n_words64, int64_t cap_words64,
+                                         int64_t words_per_group, void *dev_full_words,
+                                         int *dev_overflow) {
     ARVX_CHECK_CTX(ctx);
     ExchangeStreamScope exchange_scope(ctx);
+    if (self_rank < -1 || self_rank >= world) return fail(ARVX_ERR_INVALID, "self_rank %d of %d", self_rank, world);
     if (!dev_packets || !dev_full_words || !dev_overflow || world < 1 || n_words64 <= 0 ||
         cap_words64 < 0 || words_per_group < 2 || (words_per_group & 1) ||
         n_words64 % words_per_group)
@@ -1103,7 +1147,7 @@ int arvx_occupancy_expand_striped(arvx_ctx *ctx, const void *dev_packets, int wo
     const long long S = arvx::occ_packet_header(n) + cap_words64;
     const long long per = (nb + 2 * arvx::kExpandChunks - 1) / (2 * arvx::kExpandChunks);
     hipLaunchKernelGGL(arvx::occ_expand_kernel, dim3((unsigned)((per * world + 3) / 4)), dim3(256), 0,
-                       ctx->stream, (const unsigned long long *)dev_packets, S, world, -1, n,
+                       ctx->stream, (const unsigned long long *)dev_packets, S, world, self_rank, n,
                        (long long)cap_words64, (unsigned long long *)dev_full_words, dev_overflow,
                        (long long)words_per_group);
     ARVX_HIP(hipGetLastError());

@@ -94,6 +94,165 @@ __global__ __launch_bounds__(256) void occ_write_kernel(const unsigned long long
     }
 }
 
+// ---- records -> packet, without the plain words in between (round 4) ---------------------------
+//
+// The hand-off of a rank was pack (records -> its planes' words), classify, scan, write: four
+// launches and two passes over the words for what the records say directly.  Here the classify
+// kernel reads the records itself (lazy-aware: a settled coarse tile costs no load), the write
+// kernel sums the workgroup totals before it in its own prologue (no scan launch) and takes the
+// mixed words from the records again (only the mixed lanes read).  When the caller hands in the
+// whole grid's plane, the rank's own words are stored at their place there as well, so that the
+// expansion on this rank can skip its own packet.  X % 32 == 0 and X * Y % 64 == 0.
+
+// n / d for 32-bit unsigned n by a multiplication (the kernels below divide word indices by the
+// row length and the plane height per lane and word: the compiler's 64-bit division sequence was
+// most of the first version's 43 us).  d >= 1; exact for every n < 2^32.
+struct FastDiv {
+    unsigned d, m, s;  // q = (mulhi(m, n) + n) >> s, with the 33-bit sum formed as t + ((n - t) >> 1)
+};
+__host__ __device__ inline FastDiv fast_div(unsigned d) {
+    FastDiv f;
+    f.d = d;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    f.s = s;
+    f.m = (unsigned)((((1ull << s) - d) << 32) / d + 1);
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f) {
+    if (f.s == 0) return n;  // d == 1
+    const unsigned t = __umulhi(f.m, n);
+    return (t + ((n - t) >> 1)) >> (f.s - 1);
+}
+struct OccGeom {
+    FastDiv wpr, Y;  // 32-bit words per row, rows per plane
+    FastDiv P64;     // 64-bit words per plane
+};
+
+// 64-bit word i of the rank's planes in local order (planes zl0 .. zl0 + nz - 1); 2 i + 1 < 2^32
+__device__ __forceinline__ unsigned long long occ_word_from_rec(const CarveParams &p, const OccGeom &og,
+                                                                int zl0, unsigned i) {
+    unsigned long long w = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const unsigned j = 2u * i + (unsigned)h;
+        const unsigned row = fdiv(j, og.wpr);     // z * Y + y
+        const unsigned zi = fdiv(row, og.Y);
+        const int k = (int)(j - row * og.wpr.d), y = (int)(row - zi * og.Y.d);
+        const int z = zl0 + (int)zi;
+        const int r = (z & 7) * 8 + (y & 7);
+        const int code = lazy_code(p, k >> 1, y >> 3, z >> 3);
+        uint32_t e;
+        if (code) {
+            e = lazy_occ(p, code, k >> 1, y >> 3, z >> 3, (k & 1) * 2, r) |
+                (lazy_occ(p, code, k >> 1, y >> 3, z >> 3, (k & 1) * 2 + 1, r) << 16);
+        } else {
+            const uint16_t *rec = p.rec + rec_index(p, k >> 1, y >> 3, z >> 3, (k & 1) * 2) * kRecU16;
+            e = (uint32_t)rec[r] | ((uint32_t)rec[kRecU16 + r] << 16);
+        }
+        w |= (unsigned long long)e << (32 * h);
+    }
+    return w;
+}
+// where local word i lies in the whole grid's plane
+__device__ __forceinline__ long long occ_global_index(const CarveParams &p, const OccGeom &og, int zl0,
+                                                      unsigned i) {
+    const unsigned zi = fdiv(i, og.P64);
+    return (long long)global_z(p, zl0 + (int)zi) * og.P64.d + (i - zi * og.P64.d);
+}
+
+// occ_classify_kernel on records (same packet fields), + the rank's own words into `full`
+__global__ __launch_bounds__(256) void occ_pack_classify_kernel(const CarveParams p, const OccGeom og,
+                                                                int zl0, long long n,
+                                                                unsigned long long *__restrict__ out,
+                                                                int *__restrict__ wg_sum,
+                                                                unsigned long long *__restrict__ full) {
+    __shared__ long long wtot[4];
+    const long long nb = (n + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const long long g0 =
+        (long long)blockIdx.x * kOccGroupsPerWg + (threadIdx.x >> 6) * kOccGroupsPerWave;
+    unsigned long long my_ones = 0ull, my_mixed = 0ull;
+#pragma unroll
+    for (int it = 0; it < kOccGroupsPerWave; ++it) {
+        const long long i = (g0 + it) * 64 + lane;
+        unsigned long long w = 0ull;  // (a word past n reads as 0: neither all-one nor mixed)
+        if (i < n) {
+            w = occ_word_from_rec(p, og, zl0, (unsigned)i);
+            if (full) __builtin_nontemporal_store(w, full + occ_global_index(p, og, zl0, (unsigned)i));
+        }
+        const unsigned long long ones = __ballot(w == ~0ull);
+        const unsigned long long mixed = __ballot(w != 0ull && w != ~0ull);
+        if (lane == it) {
+            my_ones = ones;
+            my_mixed = mixed;
+        }
+    }
+    const long long g = g0 + lane;
+    long long total;
+    const long long pre = wg_exclusive_scan((long long)__popcll(my_mixed), wtot, &total);
+    if (lane < kOccGroupsPerWave && g < nb) {
+        out[1 + g] = my_ones;
+        out[1 + nb + g] = my_mixed;
+        reinterpret_cast<unsigned *>(out + 1 + 2 * nb)[g] = (unsigned)pre;  // + its workgroup's offset later
+    }
+    if (threadIdx.x == 0) wg_sum[blockIdx.x] = (int)total;
+}
+
+// occ_write_kernel with the workgroup offsets summed here (four groups per workgroup: one
+// classify workgroup's) and the mixed words taken from the records
+__global__ __launch_bounds__(256) void occ_pack_write_kernel(const CarveParams p, const OccGeom og,
+                                                             int zl0, long long n,
+                                                             long long cap,
+                                                             const int *__restrict__ wg_sum, int nwg,
+                                                             unsigned long long *__restrict__ out) {
+    __shared__ long long s_part[4];
+    __shared__ long long s_off, s_total;
+    const long long nb = (n + 63) / 64;
+    const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    {   // mixed words before this workgroup's groups: the totals of the classify workgroups before
+        const int mine = (int)(((long long)blockIdx.x * 4) / kOccGroupsPerWg);
+        const int upto = blockIdx.x == 0 ? nwg : mine;  // (workgroup 0 also leaves the packet's total)
+        long long a = 0, b = 0;
+        for (int k = threadIdx.x; k < upto; k += 256) {
+            const int v = wg_sum[k];
+            b += v;
+            if (k < mine) a += v;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            a += __shfl_xor(a, d);
+            b += __shfl_xor(b, d);
+        }
+        if (lane == 0) s_part[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) s_off = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        __syncthreads();
+        if (lane == 0) s_part[threadIdx.x >> 6] = b;
+        __syncthreads();
+        if (threadIdx.x == 0) s_total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = (unsigned long long)s_total;
+    if (g >= nb) return;
+    const long long H = occ_packet_header(n);
+    unsigned *goff = reinterpret_cast<unsigned *>(out + 1 + 2 * nb);
+    const unsigned long long mixed = out[1 + nb + g];
+    const long long off = s_off + (long long)goff[g];
+    // (every lane has read goff[g] before lane 0 overwrites it: the wave runs in lockstep and the
+    // store below follows the load in program order)
+    const long long i = g * 64 + lane;
+    unsigned long long w = 0;
+    const bool take = (mixed >> lane) & 1ull;
+    if (take) w = occ_word_from_rec(p, og, zl0, (unsigned)i);
+    if (lane == 0) goff[g] = (unsigned)off;
+    if (take) {
+        const long long at = off + __popcll(mixed & ((1ull << lane) - 1ull));
+        if (at < cap) out[H + at] = w;
+    }
+}
+
 // all packets of one all-gather (world x S words) -> the plain words of every OTHER rank's
 // slab, at slab q's place q * n in `full`.  A wave rebuilds kExpandChunks x 128 words: lane l
 // owns words 2l, 2l+1 of a chunk (one 16-byte store), i.e. bits 2(l%32), 2(l%32)+1 of group
@@ -103,8 +262,9 @@ constexpr int kExpandChunks = 4;
 // wpg = 0: contiguous slabs, rank q's words go to q * n, `self` is skipped (its words are
 // there already).  wpg > 0: striped slabs -- the planes are cut into groups of 8 (wpg words
 // each, even) and rank q owns groups q, q + world, ...: its word i goes to
-// ((i / wpg) * world + q) * wpg + i % wpg, and every rank is expanded, the caller's included
-// (pass self = -1).
+// ((i / wpg) * world + q) * wpg + i % wpg; self = -1 expands every rank, the caller's included,
+// self = the caller's rank skips its packet (its words are in `full` already:
+// occ_pack_classify_kernel).
 __global__ __launch_bounds__(256) void occ_expand_kernel(const unsigned long long *__restrict__ in,
                                                          long long S, int world, int self,
                                                          long long n, long long cap,

@@ -192,6 +192,11 @@ class OccupancyExchange:
                              for _ in range(buffers)]
             self.cap_of = [self.cap] * buffers  # cap the exchange in flight on buffer b used
             self.unexpanded = [False] * buffers
+            # the packet straight from the context's state (Context.occupancy_pack_compress: no
+            # plain words in between, own words written to their place in `full`): where the
+            # library can (X % 32 == 0, whole 64-bit words per plane)
+            self.can_fuse = X % 32 == 0 and plane % 64 == 0 and hasattr(codec, "occupancy_pack_compress")
+            self.fused = [False] * buffers
             self.overflow = torch.zeros(1, dtype=torch.int32, device=device)  # sticky
             self.fallbacks = 0
 
@@ -220,10 +225,13 @@ class OccupancyExchange:
         elif self.mode == "allgather":
             w = dist.all_gather_into_tensor(t, self.my_slice(b), async_op=async_op)
         else:
-            cap = self.cap
+            if self.fused[b]:  # pack() has written the packet
+                cap = self.cap_of[b]
+            else:
+                cap = self.cap
+                src = self.local[b] if self.layout == "striped" else self.my_slice(b)
+                self.codec.occupancy_compress(src.data_ptr(), self.n64, self.packet[b].data_ptr(), cap)
             S = self.header + cap
-            src = self.local[b] if self.layout == "striped" else self.my_slice(b)
-            self.codec.occupancy_compress(src.data_ptr(), self.n64, self.packet[b].data_ptr(), cap)
             w = dist.all_gather_into_tensor(self.gathered[b][:self.world * S],
                                             self.packet[b][:S], async_op=async_op)
             self.cap_of[b] = cap
@@ -232,8 +240,29 @@ class OccupancyExchange:
                 self._expand(b, True)
         self.pending[b] = w if async_op else None
 
+    def pack(self, ctx, b: int) -> None:
+        """ctx's occupancy into buffer b, in the form the collective ships.  compressed: the packet
+        straight from the state where the library can (Context.occupancy_pack_compress: two
+        launches instead of pack + compress's four, the rank's own words stored in full[b] on
+        the way, so that the expansion leaves its own packet out); launch(b) then only starts the
+        all-gather."""
+        if self.mode == "compressed" and self.can_fuse:
+            ctx.occupancy_pack_compress(self.packet[b].data_ptr(), self.cap, self.full[b].data_ptr())
+            self.fused[b] = True
+            self.cap_of[b] = self.cap
+        elif self.mode == "compressed" and self.layout == "striped":
+            ctx.pack_occupancy(self.local[b].data_ptr())
+        elif self.mode == "compressed":
+            ctx.pack_occupancy(self.my_slice(b).data_ptr())
+        else:
+            ctx.pack_occupancy_global(self.full[b].data_ptr())
+
     def _expand(self, b: int, verify: bool) -> None:
-        if self.layout == "striped":
+        if self.layout == "striped" and self.fused[b]:
+            self.codec.occupancy_expand_striped_others(self.gathered[b].data_ptr(), self.world, self.rank,
+                                                       self.n64, self.cap_of[b], self.wpg,
+                                                       self.full[b].data_ptr(), self.overflow.data_ptr())
+        elif self.layout == "striped":
             self.codec.occupancy_expand_striped(self.gathered[b].data_ptr(), self.world, self.n64,
                                                 self.cap_of[b], self.wpg, self.full[b].data_ptr(),
                                                 self.overflow.data_ptr())
@@ -242,6 +271,7 @@ class OccupancyExchange:
                                         self.n64, self.cap_of[b], self.full[b].data_ptr(),
                                         self.overflow.data_ptr())
         self.unexpanded[b] = False
+        was_fused, self.fused[b] = self.fused[b], False
         if verify and self.overflowed():
             # some slab had more mixed words than cap: redo this exchange in plain words.
             # Every rank sees the same packets, so every rank takes this branch.
@@ -251,8 +281,11 @@ class OccupancyExchange:
             if self.layout == "striped":
                 # worst-case packets cannot overflow: the same exchange again at full size
                 S = self.header + self.cap_max
-                self.codec.occupancy_compress(self.local[b].data_ptr(), self.n64,
-                                              self.packet[b].data_ptr(), self.cap_max)
+                if was_fused:  # (from the state again: only a caller that has not carved since)
+                    self.codec.occupancy_pack_compress(self.packet[b].data_ptr(), self.cap_max, 0)
+                else:
+                    self.codec.occupancy_compress(self.local[b].data_ptr(), self.n64,
+                                                  self.packet[b].data_ptr(), self.cap_max)
                 dist.all_gather_into_tensor(self.gathered[b][:self.world * S], self.packet[b][:S])
                 self.codec.occupancy_expand_striped(self.gathered[b].data_ptr(), self.world,
                                                     self.n64, self.cap_max, self.wpg,

@@ -432,10 +432,7 @@ def main():
                 xs = exs[slot]
                 with torch.cuda.stream(stream):  # (the collective is ordered against this stream)
                     xs.prepare(0, verify=False)  # the slot's previous exchange: wait, expand
-                    if collective == "compressed":
-                        ctx.pack_occupancy(xs.local[0].data_ptr())
-                    else:
-                        ctx.pack_occupancy_global(xs.full[0].data_ptr())
+                    xs.pack(ctx, 0)  # compressed: records -> packet (own words into the plane)
                     xs.launch(0, async_op=True)
             elif ex is not None:
                 b = nstep[0] % 2
@@ -447,10 +444,7 @@ def main():
                 with torch.cuda.stream(side):
                     side.wait_event(carved)
                     ex.prepare(b, verify=False)  # compressed: overflow is checked after drain()
-                    if collective == "compressed":  # the rank's planes in local order -> a packet
-                        ctx.pack_occupancy(ex.local[b].data_ptr())
-                    else:
-                        ctx.pack_occupancy_global(ex.full[b].data_ptr())
+                    ex.pack(ctx, b)  # compressed: records -> packet (own words into the plane)
                     packed[slot] = torch.cuda.Event()
                     packed[slot].record(side)
                     ex.launch(b, async_op=True)

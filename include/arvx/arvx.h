@@ -263,6 +263,20 @@ int arvx_occupancy_expand(arvx_ctx *ctx, const void *dev_packets, int world, int
 int arvx_occupancy_expand_striped(arvx_ctx *ctx, const void *dev_packets, int world,
                                   int64_t n_words64, int64_t cap_words64, int64_t words_per_group,
                                   void *dev_full_words, int *dev_overflow);
+/* The rank's own packet straight from the state (no arvx_pack_occupancy in between): the
+ * context's planes in local order -> dev_packet, the same packet arvx_pack_occupancy +
+ * arvx_occupancy_compress produce, in two launches instead of four and one pass over the words
+ * less.  dev_full_words (may be null): the whole grid's word plane -- the rank's own words are
+ * stored at their place there as well (contiguous and striped slabs), so that the expansion of the
+ * gathered packets can leave the caller's out (arvx_occupancy_expand's self_rank /
+ * arvx_occupancy_expand_striped_others).  Needs X % 32 == 0 and X*Y % 64 == 0. */
+int arvx_occupancy_pack_compress(arvx_ctx *ctx, void *dev_packet, int64_t cap_words64,
+                                 void *dev_full_words);
+/* arvx_occupancy_expand_striped that leaves rank self_rank's packet out (-1: none). */
+int arvx_occupancy_expand_striped_others(arvx_ctx *ctx, const void *dev_packets, int world,
+                                         int self_rank, int64_t n_words64, int64_t cap_words64,
+                                         int64_t words_per_group, void *dev_full_words,
+                                         int *dev_overflow);
 
 /* ---- hot path --------------------------------------------------------- */
 

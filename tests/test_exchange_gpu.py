@@ -233,3 +233,81 @@ def test_expand_striped_matches_restatement(ctx, wpg, groups, world):
                 for gl in range(groups):
                     g = gl * world + q
                     assert np.array_equal(want[g * wpg:(g + 1) * wpg], w[gl * wpg:(gl + 1) * wpg])
+
+
+@pytest.mark.parametrize("X,Y,Z,kind", [(128, 96, 64, "whole"), (96, 64, 40, "slab"), (800 // 5, 96, 48, "striped"),
+                                         (256, 128, 48, "striped"), (64, 64, 24, "whole")])
+@pytest.mark.parametrize("state", ["carved", "uploaded"])
+def test_pack_compress_is_pack_then_compress(X, Y, Z, kind, state):
+    """arvx_occupancy_pack_compress (records -> packet, two launches) against arvx_pack_occupancy +
+    arvx_occupancy_compress, bit for bit: the count, both bitmaps, the offsets, the mixed words --
+    on a carved model (lazy coarse codes) and on an uploaded one (every record written); the
+    rank's own words land at their place in the whole grid's plane; and the expansion that leaves
+    the caller's packet out completes that plane."""
+    from ar_voxel_project_amd import capi
+    V, W, H = 6, 320, 240
+    s = np.float32(0.3 / max(X, Y, Z))
+    _, _, M = scenes.random_cameras(V, 0.3, seed=X + Z, W=W, H=H)
+    masks = scenes.noise_masks(V, H, W, block=24, p_bg=0.45, seed=X)
+    world, rank = (3, 1) if kind == "striped" else (1, 0)
+    kw = {"stripes": (world, rank)} if kind == "striped" else ({"z_range": (8, 32)} if kind == "slab" else {})
+    with capi.Context(X, Y, Z, s, **kw) as ctx:
+        ctx.set_views(M, masks)
+        ctx.carve()
+        if state == "uploaded":
+            st = ctx.download_state()
+            rng = np.random.default_rng(5)
+            st = np.where(rng.random(st.shape) < 0.02, st ^ 1, st).astype(np.uint8)
+            ctx.upload_state(st)
+        nz = len(ctx.planes)
+        n = X * Y * nz // 64
+        d_local = torch.zeros(n, dtype=torch.int64, device="cuda")
+        d_full = torch.zeros(X * Y * Z // 64, dtype=torch.int64, device="cuda")
+        _settle()
+        ctx.pack_occupancy(d_local.data_ptr())
+        ctx.synchronize()
+        local = d_local.cpu().numpy().view(np.uint64)
+        nm = int(((local != 0) & (local != occ_codec.ONES)).sum())
+        for cap in (nm + 5, max(0, nm // 2)):
+            S = capi.occupancy_packet_words(n, cap)
+            d_a = torch.zeros(S, dtype=torch.int64, device="cuda")
+            d_b = torch.zeros(S, dtype=torch.int64, device="cuda")
+            d_full.zero_()
+            _settle()
+            ctx.occupancy_compress(d_local.data_ptr(), n, d_a.data_ptr(), cap)
+            ctx.occupancy_pack_compress(d_b.data_ptr(), cap, d_full.data_ptr())
+            ctx.synchronize()
+            a, b = d_a.cpu().numpy().view(np.uint64), d_b.cpu().numpy().view(np.uint64)
+            Hh, nb, k = occ_codec.header_words(n), (n + 63) // 64, min(nm, cap)
+            assert int(b[0]) == nm == int(a[0])
+            assert np.array_equal(b[1:1 + 2 * nb], a[1:1 + 2 * nb]), "bitmaps"
+            assert np.array_equal(b[1 + 2 * nb:Hh].view(np.uint32)[:nb], a[1 + 2 * nb:Hh].view(np.uint32)[:nb]), "offsets"
+            assert np.array_equal(b[Hh:Hh + k], a[Hh:Hh + k]), "mixed words"
+            # the rank's own words at their place in the whole grid's plane, nothing anywhere else
+            full = d_full.cpu().numpy().view(np.uint64).reshape(Z, -1)
+            assert np.array_equal(full[ctx.planes].reshape(-1), local), "own words in the plane"
+            other = np.ones(Z, bool)
+            other[ctx.planes] = False
+            assert not full[other].any()
+        if kind == "striped":  # the other ranks' packets complete the plane; the caller's is skipped
+            cap = nm + 5
+            S = capi.occupancy_packet_words(n, cap)
+            d_pks = torch.zeros(world * S, dtype=torch.int64, device="cuda")
+            d_flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+            d_full.zero_()
+            _settle()
+            for q in range(world):  # (every "rank" ships this rank's planes: only the placement is looked at)
+                ctx.occupancy_compress(d_local.data_ptr(), n, d_pks[q * S:].data_ptr(), cap)
+            # poison the caller's own packet: it must not be read
+            d_pks[rank * S:(rank + 1) * S] = -1
+            ctx.occupancy_pack_compress(d_pks[rank * S:].data_ptr(), cap, d_full.data_ptr())
+            d_pks[rank * S + 1:(rank + 1) * S] = -1
+            _settle()
+            ctx.occupancy_expand_striped_others(d_pks.data_ptr(), world, rank, n, cap, X * Y * 8 // 64,
+                                                d_full.data_ptr(), d_flag.data_ptr())
+            ctx.synchronize()
+            full = d_full.cpu().numpy().view(np.uint64).reshape(Z // 8, 8, -1)
+            assert int(d_flag.item()) == 0
+            for q in range(world):  # group g of rank q = global group g * world + q
+                got = full[q::world].reshape(-1)
+                assert np.array_equal(got, local), f"rank {q}'s stripes"

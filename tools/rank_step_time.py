@@ -58,6 +58,30 @@ for rank in (0, world // 2):
     print(f"world {world} rank {rank}: grid {X}x{Y}x{Z} x {V} views, packet {S * 8 / 1e6:.2f} MB of "
           f"{n64 * 8 / 1e6:.2f} MB | " + " | ".join(f"{n} {b * 1e3:.1f} us" for n, b in zip(names, best))
           + f" | sum {sum(best) * 1e3:.1f} us", flush=True)
+    # round 4: the packet straight from the records (own words into the plane), the expansion
+    # without the rank's own packet
+    names2 = ["views", "carve", "pack+compress", "expand others"]
+    best2 = [1e9] * 4
+    for _ in range(8):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ctx.reset()
+        ev[0].record(stream)
+        ctx.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
+        ev[1].record(stream)
+        ctx.carve()
+        ev[2].record(stream)
+        ctx.occupancy_pack_compress(pks[rank * S:].data_ptr(), cap, full.data_ptr())
+        ev[3].record(stream)
+        ctx.occupancy_expand_striped_others(pks.data_ptr(), world, rank, n64, cap, wpg, full.data_ptr(),
+                                            flag.data_ptr())
+        ev[4].record(stream)
+        torch.cuda.synchronize()
+        for k in range(4):
+            best2[k] = min(best2[k], ev[k].elapsed_time(ev[k + 1]))
+    print(f"world {world} rank {rank}: fused hand-off | "
+          + " | ".join(f"{n} {b * 1e3:.1f} us" for n, b in zip(names2, best2))
+          + f" | hand-off {sum(best2[2:]) * 1e3:.1f} us (was {sum(best[2:]) * 1e3:.1f})", flush=True)
+    FUSED = os.environ.get("ARVX_RANK_STEP_OLD") != "1"
     # the same work as a pipeline: hand-off of step k on a side stream beside step k + 1
     import time
     side = torch.cuda.Stream(device=dev)
@@ -77,13 +101,20 @@ for rank in (0, world // 2):
                 carved = torch.cuda.Event()
                 carved.record(stream)
                 side.wait_event(carved)
-            ctx.pack_occupancy(local.data_ptr())
+            if FUSED:
+                ctx.occupancy_pack_compress(pks[rank * S:].data_ptr(), cap, full.data_ptr())
+            else:
+                ctx.pack_occupancy(local.data_ptr())
             if overlap:
                 packed = torch.cuda.Event()
                 packed.record(side)
-            ctx.occupancy_compress(local.data_ptr(), n64, pks.data_ptr(), cap)
-            ctx.occupancy_expand_striped(pks.data_ptr(), world, n64, cap, wpg, full.data_ptr(),
-                                         flag.data_ptr())
+            if FUSED:
+                ctx.occupancy_expand_striped_others(pks.data_ptr(), world, rank, n64, cap, wpg,
+                                                    full.data_ptr(), flag.data_ptr())
+            else:
+                ctx.occupancy_compress(local.data_ptr(), n64, pks.data_ptr(), cap)
+                ctx.occupancy_expand_striped(pks.data_ptr(), world, n64, cap, wpg, full.data_ptr(),
+                                             flag.data_ptr())
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps * 1e6
 
@@ -134,10 +165,16 @@ for rank in (0, world // 2):
                 else:
                     b = s_
                     c.carve()
-                    c.pack_occupancy(locals_[b].data_ptr())
-                c.occupancy_compress(locals_[b].data_ptr(), n64, pkss[b].data_ptr(), cap)
-                c.occupancy_expand_striped(pkss[b].data_ptr(), world, n64, cap, wpg, fulls[b].data_ptr(),
-                                           flag.data_ptr())
+                    if not FUSED:
+                        c.pack_occupancy(locals_[b].data_ptr())
+                if FUSED and variant != "A":
+                    c.occupancy_pack_compress(pkss[b][rank * S:].data_ptr(), cap, fulls[b].data_ptr())
+                    c.occupancy_expand_striped_others(pkss[b].data_ptr(), world, rank, n64, cap, wpg,
+                                                      fulls[b].data_ptr(), flag.data_ptr())
+                else:
+                    c.occupancy_compress(locals_[b].data_ptr(), n64, pkss[b].data_ptr(), cap)
+                    c.occupancy_expand_striped(pkss[b].data_ptr(), world, n64, cap, wpg, fulls[b].data_ptr(),
+                                               flag.data_ptr())
             torch.cuda.synchronize()
             us = (time.perf_counter() - t0) / steps * 1e6
             best = us if best is None or us < best else best
