@@ -195,6 +195,40 @@ static int bit_compact_count(Ctx *ctx, const unsigned long long *bits, size_t nw
     return ARVX_OK;
 }
 
+// The ordered compaction in ONE launch (bit_compact_kernel): up to `cap` entries of the list go to
+// d_index, every word's SparseWord to d_words; the list's true length is left in device word
+// *d_total_out (for the kernels that follow) and in the page-locked ctx->h_totals[slot], which the
+// caller reads after its synchronisation.
+static int bit_compact(Ctx *ctx, const unsigned long long *bits, size_t nwords, const arvx::BitGrid &g,
+                       long long cap, int *d_index, arvx::SparseWord *d_words, int slot,
+                       const long long **d_total_out) {
+    const size_t nchunks = (nwords + arvx::kBitChunk - 1) / arvx::kBitChunk;
+    const size_t off_status = 128;  // [0] ticket counter, [8 + 8 k] device totals, then the status words
+    const size_t need = off_status + nchunks * sizeof(unsigned long long) + 64;
+    if (ctx->pool_compact.cap < need) {
+        ARVX_HIP(ctx->pool_compact.reserve(need));
+        ARVX_HIP(hipMemsetAsync(ctx->pool_compact.p, 0, ctx->pool_compact.cap, ctx->stream));
+        ctx->compact_tickets = 0;
+        ctx->compact_epoch = 0;
+    }
+    if (++ctx->compact_epoch == 0u) {  // (2^32 launches: start the tags over on clean memory)
+        ARVX_HIP(hipMemsetAsync(ctx->pool_compact.p, 0, ctx->pool_compact.cap, ctx->stream));
+        ctx->compact_tickets = 0;
+        ctx->compact_epoch = 1u;
+    }
+    uint8_t *base = (uint8_t *)ctx->pool_compact.p;
+    long long *d_total = (long long *)(base + 8 + 8 * slot);
+    ctx->h_totals[slot] = -1;
+    hipLaunchKernelGGL(arvx::bit_compact_kernel, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream, bits,
+                       nwords, g, (unsigned long long *)base, ctx->compact_tickets,
+                       (unsigned long long *)(base + off_status), ctx->compact_epoch, cap, d_index, d_words,
+                       d_total, ctx->d_totals_host + slot, ctx->d_fault);
+    ARVX_HIP(hipGetLastError());
+    ctx->compact_tickets += nchunks;
+    if (d_total_out) *d_total_out = d_total;
+    return ARVX_OK;
+}
+
 static int bit_compact_write(Ctx *ctx, const unsigned long long *bits, size_t nwords,
                              const arvx::BitGrid &g, const long long *d_off, int *d_index,
                              arvx::SparseWord *d_words) {
@@ -322,8 +356,10 @@ int arvx_ctx_create_slab_halo(arvx_ctx **out, int device, int X, int Y, int Z, f
     }
     e = hipHostMalloc((void **)&c->h_fault, 64, hipHostMallocMapped);
     if (e == hipSuccess) {
-        *c->h_fault = 0u;
+        memset(c->h_fault, 0, 64);
         e = hipHostGetDevicePointer((void **)&c->d_fault, c->h_fault, 0);
+        c->h_totals = (long long *)(c->h_fault + 2);  // six 8-byte words behind the fault word
+        c->d_totals_host = (long long *)(c->d_fault + 2);
     }
     if (e != hipSuccess) {
         arvx_ctx_destroy(c);
@@ -1514,6 +1550,10 @@ int arvx_carve(arvx_ctx *ctx, unsigned flags) {
     return arvx_carve_views(ctx, 0, ctx->V, flags);
 }
 
+static int surf_host(Ctx *ctx);
+static void owned_part(const Ctx *ctx, const std::vector<int> &idx, size_t &lo, size_t &hi,
+                       long long &base);
+
 int arvx_get_stats(arvx_ctx *ctx, arvx_stats *out) {
     ARVX_CHECK_CTX(ctx);
     if (!out) return fail(ARVX_ERR_INVALID, "null out");
@@ -1525,7 +1565,14 @@ int arvx_get_stats(arvx_ctx *ctx, arvx_stats *out) {
     out->subtiles_carved = h[1];
     out->subtile_views_mixed = h[2];
     out->subtile_views_total = h[3];
-    out->surface_voxels = h[4];
+    out->surface_voxels = 0;
+    if (ctx->color_ready) {  // the owned part of the colour pass's list (arvx_color)
+        if (int rc = surf_host(ctx)) return rc;
+        size_t lo, hi;
+        long long base;
+        owned_part(ctx, ctx->h_surf_index, lo, hi, base);
+        out->surface_voxels = hi - lo;
+    }
     out->reserved[0] = h[5];  // 256-voxel slices evaluated exactly
     out->reserved[1] = h[6];  // voxels among them that were not yet carved+seen
     out->reserved[2] = h[7];  // mixed pairs whose open voxels all got the same answer
@@ -1604,43 +1651,46 @@ int arvx_color(arvx_ctx *ctx, int mode) {
     const arvx::BitGrid gext{ctx->X, ctx->Y, Zext, XW};
     const size_t row_words = (size_t)XW * ctx->Y;
     const size_t nw_ext = row_words * Zext, nw_col = row_words * (size_t)(c_hi - c_lo);
-    const int nblk = (int)((nw_ext + arvx::kBitChunk - 1) / arvx::kBitChunk);
-    if (int rc = ensure_scratch(ctx, nw_ext * sizeof(unsigned long long) +
-                                         (size_t)(nblk + 1) * sizeof(long long) +
-                                         (size_t)nblk * sizeof(int) + 64))
-        return rc;
+    if (int rc = ensure_scratch(ctx, nw_ext * sizeof(unsigned long long) + 64)) return rc;
     // the surface plane stays with the context: with its ranks it is the index of the colour
     // list (closure and mesh look colours up through it)
     ARVX_HIP(ctx->pool_col_bits.reserve(nw_ext * sizeof(unsigned long long)));
     ARVX_HIP(ctx->pool_col_rank.reserve(nw_ext * sizeof(arvx::SparseWord)));
     unsigned long long *d_occ = (unsigned long long *)ctx->d_scratch;
     unsigned long long *d_surf = (unsigned long long *)ctx->pool_col_bits.p;
-    long long *d_off = (long long *)(d_occ + nw_ext);
-    int *d_cnt = (int *)(d_off + nblk + 1);
     if (int rc = launch_bit_pack(ctx, gext, 0, 0, d_occ, nullptr)) return rc;
     if (nw_col != nw_ext) ARVX_HIP(hipMemsetAsync(d_surf, 0, nw_ext * sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(arvx::bit_surface_kernel, dim3((unsigned)((nw_col + 255) / 256)), dim3(256),
                        0, ctx->stream, d_occ, gext, c_lo - ctx->ze0, c_hi - c_lo,
                        d_surf + row_words * (size_t)(c_lo - ctx->ze0));
     ARVX_HIP(hipGetLastError());
+    // The list's length is not known before the compaction has run: the buffers are sized for what
+    // the last pass needed (first call: a surface's share of the voxels), the kernels stop at that
+    // capacity, and the true length is read at the call's ONE synchronisation; a list that outgrew
+    // its buffers is compacted and voted again with room for all of it.
+    long long cap = (long long)(ctx->pool_surf_index.cap / sizeof(int));
+    if (cap <= 0) {
+        const double v = (double)ctx->X * ctx->Y * Zext;
+        cap = (long long)std::min<double>(v, 8.0 * std::cbrt(v) * std::cbrt(v) + 4096.0);
+    }
     long long total = 0;
-    if (int rc = bit_compact_count(ctx, d_surf, nw_ext, d_cnt, d_off, &total)) return rc;
-    ctx->surf_count = total;
-    if (total > 0) {
-        ARVX_HIP(ctx->pool_surf_index.reserve((size_t)total * sizeof(int)));
+    for (int attempt = 0;; ++attempt) {
+        ARVX_HIP(ctx->pool_surf_index.reserve((size_t)cap * sizeof(int)));
         ctx->d_surf_index = (int *)ctx->pool_surf_index.p;
-        ARVX_HIP(ctx->pool_surf_rgb.reserve((size_t)total * sizeof(float4)));
+        ARVX_HIP(ctx->pool_surf_rgb.reserve((size_t)cap * sizeof(float4)));
         ctx->d_surf_rgba = (float4 *)ctx->pool_surf_rgb.p;
-        ARVX_HIP(ctx->pool_surf_depth.reserve((size_t)total * sizeof(float)));
+        ARVX_HIP(ctx->pool_surf_depth.reserve((size_t)cap * sizeof(float)));
         ctx->d_surf_depth = (float *)ctx->pool_surf_depth.p;
-        ARVX_HIP(ctx->pool_surf_has.reserve((size_t)total));
+        ARVX_HIP(ctx->pool_surf_has.reserve((size_t)cap));
         ctx->d_surf_has = (uint8_t *)ctx->pool_surf_has.p;
-        if (int rc = bit_compact_write(ctx, d_surf, nw_ext, gext, d_off, ctx->d_surf_index,
-                                       (arvx::SparseWord *)ctx->pool_col_rank.p))
+        const long long *d_total = nullptr;
+        if (int rc = bit_compact(ctx, d_surf, nw_ext, gext, cap, ctx->d_surf_index,
+                                 (arvx::SparseWord *)ctx->pool_col_rank.p, 0, &d_total))
             return rc;
         arvx::VoteParams vp;
         vp.index = ctx->d_surf_index;
-        vp.n = total;
+        vp.n = cap;
+        vp.n_dev = d_total;
         vp.X = ctx->X;
         vp.Y = ctx->Y;
         vp.zglob0 = ctx->ze0;  // (list indices run over the context's planes)
@@ -1656,27 +1706,28 @@ int arvx_color(arvx_ctx *ctx, int mode) {
         vp.depth = ctx->d_surf_depth;
         vp.has = ctx->d_surf_has;
         if (ctx->assoc == ARVX_ASSOC_LEFT)
-            hipLaunchKernelGGL(arvx::color_vote_kernel<true>, dim3((unsigned)((total + 255) / 256)),
+            hipLaunchKernelGGL(arvx::color_vote_kernel<true>, dim3((unsigned)((cap + 255) / 256)),
                                dim3(256), 0, ctx->stream, vp);
         else
-            hipLaunchKernelGGL(arvx::color_vote_kernel<false>, dim3((unsigned)((total + 255) / 256)),
+            hipLaunchKernelGGL(arvx::color_vote_kernel<false>, dim3((unsigned)((cap + 255) / 256)),
                                dim3(256), 0, ctx->stream, vp);
         ARVX_HIP(hipGetLastError());
-        ctx->h_surf_index.resize((size_t)total);
-        ctx->h_surf_has.resize((size_t)total);
-        ARVX_HIP(hipMemcpyAsync(ctx->h_surf_index.data(), ctx->d_surf_index,
-                                (size_t)total * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        ARVX_HIP(hipMemcpyAsync(ctx->h_surf_has.data(), ctx->d_surf_has, (size_t)total,
-                                hipMemcpyDeviceToHost, ctx->stream));
         ARVX_SYNC(ctx);
+        total = ctx->h_totals[0];
+        if (total < 0) return fail(ARVX_ERR_HIP, "the compaction left no count");
+        if (total <= cap || attempt) break;
+        cap = total + total / 8;  // (once more, with room for all)
     }
-    size_t own_lo, own_hi;
-    long long own_base;
-    owned_part(ctx, ctx->h_surf_index, own_lo, own_hi, own_base);
-    unsigned long long sv = (unsigned long long)(own_hi - own_lo);  // surface voxels of the owned planes
-    ARVX_HIP(hipMemcpyAsync(ctx->d_stats + 4, &sv, sizeof sv, hipMemcpyHostToDevice, ctx->stream));
-    ARVX_SYNC(ctx);
+    ctx->surf_count = total;
+    ctx->surf_host_count = -1;  // the host copies of the list are fetched when somebody asks
+    if (total == 0) {
+        ctx->d_surf_index = nullptr;
+        ctx->d_surf_rgba = nullptr;
+        ctx->d_surf_depth = nullptr;
+        ctx->d_surf_has = nullptr;
+    }
     ctx->color_ready = true;
+    // (arvx_get_stats' surface_voxels: the owned part of the list, counted when it is asked for)
     return ARVX_OK;
 }
 
@@ -1728,9 +1779,29 @@ int arvx_color_samples(arvx_ctx *ctx, int64_t n, const int64_t *index, int views
     return ARVX_OK;
 }
 
+// The colour list's indices and has-flags on the host: fetched when somebody asks (a pipeline
+// that goes on to the closure and the mesh on the device never does).
+static int surf_host(Ctx *ctx) {
+    if (ctx->surf_host_count == ctx->surf_count) return ARVX_OK;
+    const size_t n = (size_t)ctx->surf_count;
+    ctx->h_surf_index.resize(n);
+    ctx->h_surf_has.resize(n);
+    if (n) {
+        ARVX_HIP(hipMemcpyAsync(ctx->h_surf_index.data(), ctx->d_surf_index, n * sizeof(int),
+                                hipMemcpyDeviceToHost, ctx->stream));
+        ARVX_HIP(hipMemcpyAsync(ctx->h_surf_has.data(), ctx->d_surf_has, n, hipMemcpyDeviceToHost,
+                                ctx->stream));
+        ARVX_SYNC(ctx);
+    }
+    ctx->surf_host_count = ctx->surf_count;
+    return ARVX_OK;
+}
+
 int arvx_surface_count(arvx_ctx *ctx, int64_t *count) {
     if (!ctx || !count) return fail(ARVX_ERR_INVALID, "null argument");
     if (!ctx->color_ready) return fail(ARVX_ERR_STATE, "no colour result (call arvx_color)");
+    ARVX_HIP(hipSetDevice(ctx->device));
+    if (int rc = surf_host(ctx)) return rc;
     size_t lo, hi;
     long long base;
     owned_part(ctx, ctx->h_surf_index, lo, hi, base);
@@ -1760,6 +1831,7 @@ int arvx_surface_download(arvx_ctx *ctx, int64_t *index, float *rgb) {
     std::vector<float> hrgb, hdepth;
     int rc = surface_fetch(ctx, hrgb, hdepth);
     if (rc) return rc;
+    if (int rc2 = surf_host(ctx)) return rc2;
     size_t lo, hi;
     long long base;
     owned_part(ctx, ctx->h_surf_index, lo, hi, base);
@@ -1782,6 +1854,7 @@ int arvx_surface_depth_download(arvx_ctx *ctx, float *depth) {
     std::vector<float> hrgb, hdepth;
     int rc = surface_fetch(ctx, hrgb, hdepth);
     if (rc) return rc;
+    if (int rc2 = surf_host(ctx)) return rc2;
     size_t lo, hi;
     long long base;
     owned_part(ctx, ctx->h_surf_index, lo, hi, base);
@@ -1823,6 +1896,7 @@ int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen) {
                    idx.begin();
         };
         if (ctx->color_ready && ctx->surf_count > 0) {
+            if (int rc = surf_host(ctx)) return rc;
             long long first, last;
             list_range(ctx->h_surf_index, first, last);
             if (last > first)
@@ -1973,6 +2047,7 @@ int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const flo
         idx[(size_t)k] = (int)(index[k] + own_base);  // numbered over the context's planes
     }
     ctx->surf_count = n;
+    ctx->surf_host_count = n;
     ctx->h_surf_index = idx;
     ctx->h_surf_has.assign((size_t)n, 1);
     if (n > 0) {

@@ -61,6 +61,15 @@ struct Ctx {
     DevPool pool_vstrip;          // views_strip_kernel: ticket counters + published column counts
     size_t vstrip_key = 0;        // layout (V, strips, granules) the pool was zeroed for
 
+    // bit_compact_kernel (bitplane_kernels.h): ticket counter, device totals, status granules; and
+    // what the host keeps beside it.  h_totals: page-locked words behind the fault word that the
+    // kernels write the lists' lengths to (read at the call's one synchronisation).
+    DevPool pool_compact;
+    unsigned long long compact_tickets = 0;  // tickets all launches so far have taken
+    uint32_t compact_epoch = 0;
+    long long *h_totals = nullptr, *d_totals_host = nullptr;  // 6 slots (host / device address)
+    long long surf_host_count = -1;  // entries of h_surf_index / h_surf_has that are valid (-1: fetch)
+
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t xstream = nullptr;  // arvx_ctx_set_exchange_stream: the occupancy hand-off (null: stream)
@@ -172,6 +181,8 @@ struct Ctx {
         pool_xscratch.release();
         pool_vstrip.release();
         vstrip_key = 0;
+        pool_compact.release();
+        compact_tickets = 0;
         pool_paint.release();
         pool_ccode.release();
         pool_cstate.release();
@@ -214,6 +225,7 @@ struct Ctx {
         d_surf_has = nullptr;
         color_ready = false;
         surf_count = 0;
+        surf_host_count = -1;
         h_surf_index.clear();
         h_surf_has.clear();
     }

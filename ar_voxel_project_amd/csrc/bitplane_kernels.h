@@ -153,6 +153,125 @@ __global__ __launch_bounds__(256) void bit_write_kernel(const unsigned long long
     }
 }
 
+// ---- the same in ONE launch (round 4) -------------------------------------------------------
+//
+// bit_count_kernel -> surface_scan_kernel -> (the host reads the total and sizes the list) ->
+// bit_write_kernel were three launches and a synchronisation in the middle of every call that
+// compacts (colour pass, closure, mesh).  Here a workgroup takes a chunk of kBitChunk words by
+// TICKET, counts it, publishes the count, finds the set bits before its chunk by looking back at
+// the chunks before it (status words: tagged 8-byte granules {aggregate or inclusive prefix, tag};
+// a workgroup waits only for lower tickets, i.e. for workgroups that are running), and writes its
+// part of the list -- up to `cap` entries: the true total goes to *total (device) and to the
+// page-locked word *total_host, which the host reads at the call's ONE synchronisation; a call whose
+// list outgrew the capacity it guessed repeats the launch with room for all.
+// ticket_ctr: 64-bit, never reset; ticket_base: the tickets all earlier launches took.
+constexpr uint32_t kCompactPrefix = 0x80000000u;  // status: the value is an inclusive prefix
+
+__global__ __launch_bounds__(256) void bit_compact_kernel(
+    const unsigned long long *__restrict__ bits, size_t nwords, const BitGrid g,
+    unsigned long long *__restrict__ ticket_ctr, unsigned long long ticket_base,
+    unsigned long long *__restrict__ status, uint32_t tag, long long cap, int *__restrict__ index,
+    SparseWord *__restrict__ words, long long *__restrict__ total, long long *__restrict__ total_host,
+    unsigned *__restrict__ fault) {
+    __shared__ int wtot[4];
+    __shared__ int s_chunk;
+    __shared__ long long s_excl;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_chunk = (int)(atomicAdd(ticket_ctr, 1ull) - ticket_base);
+    __syncthreads();
+    const int c = s_chunk;
+    const int nchunks = (int)((nwords + kBitChunk - 1) / kBitChunk);
+    const size_t base = (size_t)c * kBitChunk;
+    // the chunk's words: word it * 256 + thread (whole lines per wave), kept for the write phase
+    unsigned long long b[kBitChunk / 256];
+    int mine = 0;
+#pragma unroll
+    for (int it = 0; it < kBitChunk / 256; ++it) {
+        const size_t w = base + (size_t)it * 256 + threadIdx.x;
+        b[it] = (w < nwords) ? bits[w] : 0ull;
+        mine += __popcll(b[it]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    if (lane == 0) wtot[wave] = mine;
+    __syncthreads();
+    const int agg = wtot[0] + wtot[1] + wtot[2] + wtot[3];  // (< 2^19)
+    __syncthreads();  // (wtot is used again below)
+    if (wave == 0) {
+        long long excl = 0;
+        if (c > 0) {
+            if (lane == 0) granule_store(status + c, (uint32_t)agg, tag);
+            // look back, 64 chunks at a time: lane l at chunk look - l
+            int look = c - 1;
+            for (unsigned spin = 0;;) {
+                const int k = look - lane;
+                unsigned long long gr = ((unsigned long long)tag << 32) | kCompactPrefix;  // (before chunk 0: prefix 0)
+                if (k >= 0) gr = granule_load(status + k);
+                const bool valid = (uint32_t)(gr >> 32) == tag;
+                const bool pref = valid && ((uint32_t)gr & kCompactPrefix);
+                const unsigned long long vmask = __ballot(valid), pmask = __ballot(pref);
+                const int fp = pmask ? __ffsll((long long)pmask) - 1 : 64;  // nearest chunk with a prefix
+                const unsigned long long need = fp < 63 ? ((2ull << fp) - 1ull) : ~0ull;
+                if ((vmask & need) != need) {  // a chunk in between has not published yet
+                    if (++spin > (1u << 20)) {
+                        if (lane == 0 && fault)
+                            __hip_atomic_store(fault, 6u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                long long v = (lane <= fp) ? (long long)((uint32_t)gr & ~kCompactPrefix) : 0;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+                excl += v;
+                if (fp < 64) break;
+                look -= 64;
+            }
+        }
+        if (lane == 0) {
+            granule_store(status + c, (uint32_t)(excl + agg) | kCompactPrefix, tag);
+            s_excl = excl;
+            if (c == nchunks - 1) {
+                *total = excl + agg;
+                if (total_host)
+                    __hip_atomic_store(total_host, excl + agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    __syncthreads();
+    long long run = s_excl;
+#pragma unroll
+    for (int it = 0; it < kBitChunk / 256; ++it) {
+        const size_t w = base + (size_t)it * 256 + threadIdx.x;
+        unsigned long long bw = b[it];
+        const int n = __popcll(bw);
+        int sc = n;  // inclusive scan inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(sc, d);
+            if (lane >= d) sc += t;
+        }
+        if (lane == 63) wtot[wave] = sc;
+        __syncthreads();
+        long long slot = run + sc - n;
+        for (int v = 0; v < wave; ++v) slot += wtot[v];
+        if (words && w < nwords) words[w] = SparseWord{bw, (int)slot, 0};
+        if (bw && index) {
+            const size_t row = w / g.XW;
+            const int x0 = (int)(w % g.XW) * 64;
+            const int first = (int)(row * g.X) + x0;
+            while (bw) {
+                if (slot < cap) index[slot] = first + (__ffsll((long long)bw) - 1);
+                ++slot;
+                bw &= bw - 1ull;
+            }
+        }
+        run += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+    }
+}
+
 // the plane of a list that came from the host (arvx_colors_upload): bit index[k] set
 __global__ __launch_bounds__(256) void bits_from_index_kernel(const int *__restrict__ index,
                                                               long long n, const BitGrid g,

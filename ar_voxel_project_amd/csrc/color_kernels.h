@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void surface_scan_kernel(const int *__restrict
 
 struct VoteParams {
     const int *index;  // surface voxels, slab-local flat index over owned planes
-    long long n;
+    long long n;       // entries (with n_dev: the list's capacity)
+    const long long *n_dev;  // the list's length as the compaction left it on the device (or null)
     int X, Y;
     int zglob0;  // global z of owned plane 0
     float s;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void color_samples_kernel(const VoteParams p,
 template <bool LEFT>
 __global__ __launch_bounds__(256) void color_vote_kernel(const VoteParams p) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= p.n) return;
+    if (t >= p.n || (p.n_dev && t >= *p.n_dev)) return;
     const int i = p.index[t];
     const int x = i % p.X;
     const int y = (i / p.X) % p.Y;
