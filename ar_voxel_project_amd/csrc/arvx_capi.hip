@@ -195,16 +195,15 @@ static int bit_compact_count(Ctx *ctx, const unsigned long long *bits, size_t nw
     return ARVX_OK;
 }
 
-// The ordered compaction in ONE launch (bit_compact_kernel): up to `cap` entries of the list go to
-// d_index, every word's SparseWord to d_words; the list's true length is left in device word
-// *d_total_out (for the kernels that follow) and in the page-locked ctx->h_totals[slot], which the
-// caller reads after its synchronisation.
-static int bit_compact(Ctx *ctx, const unsigned long long *bits, size_t nwords, const arvx::BitGrid &g,
-                       long long cap, int *d_index, arvx::SparseWord *d_words, int slot,
-                       const long long **d_total_out) {
-    const size_t nchunks = (nwords + arvx::kBitChunk - 1) / arvx::kBitChunk;
+// the control block of the one-launch compaction / scan kernels: ticket counter, device totals,
+// `nchunks` status words; *status: where they start
+static int compact_control(Ctx *ctx, size_t nchunks, uint8_t **base, unsigned long long **status) {
     const size_t off_status = 128;  // [0] ticket counter, [8 + 8 k] device totals, then the status words
-    const size_t need = off_status + nchunks * sizeof(unsigned long long) + 64;
+    // (room for the longest array a context ever compacts or scans -- one entry per voxel, a chunk per
+    // 4096 of them --, so that the block never moves between the launches of a call: the kernels of
+    // a call read each other's totals from it)
+    const size_t most = ctx->nvox_ext / 4096 + 4096;
+    const size_t need = off_status + std::max(nchunks, most) * sizeof(unsigned long long) + 64;
     if (ctx->pool_compact.cap < need) {
         ARVX_HIP(ctx->pool_compact.reserve(need));
         ARVX_HIP(hipMemsetAsync(ctx->pool_compact.p, 0, ctx->pool_compact.cap, ctx->stream));
@@ -216,12 +215,48 @@ static int bit_compact(Ctx *ctx, const unsigned long long *bits, size_t nwords, 
         ctx->compact_tickets = 0;
         ctx->compact_epoch = 1u;
     }
-    uint8_t *base = (uint8_t *)ctx->pool_compact.p;
+    *base = (uint8_t *)ctx->pool_compact.p;
+    *status = (unsigned long long *)(*base + off_status);
+    return ARVX_OK;
+}
+
+// Exclusive scan of n counts src(i) in ONE launch (scan_lookback_kernel): offsets[i]; the sum goes to
+// device word *d_total_out and to ctx->h_totals[slot].  n_dev (may be null): entries at or behind
+// *n_dev count nothing.
+template <class Src>
+static int scan_counts(Ctx *ctx, const Src &src, long long n, const long long *n_dev, long long *d_offsets,
+                       int slot, const long long **d_total_out) {
+    const size_t nchunks = (size_t)((n + arvx::kScanChunk - 1) / arvx::kScanChunk);
+    uint8_t *base = nullptr;
+    unsigned long long *status = nullptr;
+    if (int rc = compact_control(ctx, nchunks, &base, &status)) return rc;
+    long long *d_total = (long long *)(base + 8 + 8 * slot);
+    ctx->h_totals[slot] = -1;
+    hipLaunchKernelGGL(arvx::scan_lookback_kernel<Src>, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream,
+                       src, n, n_dev, d_offsets, (unsigned long long *)base, ctx->compact_tickets, status,
+                       ctx->compact_epoch, d_total, ctx->d_totals_host + slot, ctx->d_fault);
+    ARVX_HIP(hipGetLastError());
+    ctx->compact_tickets += nchunks;
+    if (d_total_out) *d_total_out = d_total;
+    return ARVX_OK;
+}
+
+// The ordered compaction in ONE launch (bit_compact_kernel): up to `cap` entries of the list go to
+// d_index, every word's SparseWord to d_words; the list's true length is left in device word
+// *d_total_out (for the kernels that follow) and in the page-locked ctx->h_totals[slot], which the
+// caller reads after its synchronisation.
+static int bit_compact(Ctx *ctx, const unsigned long long *bits, size_t nwords, const arvx::BitGrid &g,
+                       long long cap, int *d_index, arvx::SparseWord *d_words, int slot,
+                       const long long **d_total_out) {
+    const size_t nchunks = (nwords + arvx::kBitChunk - 1) / arvx::kBitChunk;
+    uint8_t *base = nullptr;
+    unsigned long long *status = nullptr;
+    if (int rc = compact_control(ctx, nchunks, &base, &status)) return rc;
     long long *d_total = (long long *)(base + 8 + 8 * slot);
     ctx->h_totals[slot] = -1;
     hipLaunchKernelGGL(arvx::bit_compact_kernel, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream, bits,
-                       nwords, g, (unsigned long long *)base, ctx->compact_tickets,
-                       (unsigned long long *)(base + off_status), ctx->compact_epoch, cap, d_index, d_words,
+                       nwords, g, (unsigned long long *)base, ctx->compact_tickets, status,
+                       ctx->compact_epoch, cap, d_index, d_words,
                        d_total, ctx->d_totals_host + slot, ctx->d_fault);
     ARVX_HIP(hipGetLastError());
     ctx->compact_tickets += nchunks;
@@ -1551,6 +1586,7 @@ int arvx_carve(arvx_ctx *ctx, unsigned flags) {
 }
 
 static int surf_host(Ctx *ctx);
+static int clo_host(Ctx *ctx);
 static void owned_part(const Ctx *ctx, const std::vector<int> &idx, size_t &lo, size_t &hi,
                        long long &base);
 
@@ -1906,6 +1942,7 @@ int arvx_export_model(arvx_ctx *ctx, float *rgba, int apply_unseen) {
                                    g, zown, paint_plane(ctx), i0, d_out, apply_unseen);
         }
         if (ctx->closure_ready && ctx->clo_count > 0) {
+            if (int rc = clo_host(ctx)) return rc;
             long long first, last;
             list_range(ctx->h_clo_index, first, last);
             if (last > first)
@@ -2136,19 +2173,13 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     const arvx::BitGrid g{ctx->X, ctx->Y, Zext, XW};
     const size_t row_words = (size_t)XW * g.Y;
     const size_t nwords = row_words * g.Z;
-    const int nblk = (int)((nwords + arvx::kBitChunk - 1) / arvx::kBitChunk);
     const bool paints = apply_unseen || ctx->paint_valid;  // somebody is UNSEEN_COLOR
-    if (int rc = ensure_scratch(ctx, 4 * nwords * sizeof(unsigned long long) +
-                                         (size_t)(nblk + 1) * sizeof(long long) +
-                                         (size_t)nblk * sizeof(int) + 64))
-        return rc;
+    if (int rc = ensure_scratch(ctx, 4 * nwords * sizeof(unsigned long long) + 64)) return rc;
     ARVX_HIP(ctx->pool_clo_bits.reserve(nwords * sizeof(unsigned long long)));
     ARVX_HIP(ctx->pool_clo_rank.reserve(nwords * sizeof(arvx::SparseWord)));
     unsigned long long *d_occ = (unsigned long long *)ctx->d_scratch;
     unsigned long long *d_unseen = d_occ + nwords, *d_a = d_unseen + nwords, *d_b = d_a + nwords;
     unsigned long long *d_fill = (unsigned long long *)ctx->pool_clo_bits.p;
-    long long *d_off = (long long *)(d_b + nwords);
-    int *d_cnt = (int *)(d_off + nblk + 1);
     if (int rc = launch_bit_pack(ctx, g, 1, apply_unseen ? 1 : 0, d_occ, paints ? d_unseen : nullptr))
         return rc;
     const unsigned gw = (unsigned)((nwords + 255) / 256);
@@ -2166,16 +2197,26 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     if (f_hi < ctx->ze1)
         ARVX_HIP(hipMemsetAsync(d_fill + row_words * (size_t)(f_hi - ctx->ze0), 0,
                                 row_words * (size_t)(ctx->ze1 - f_hi) * 8, ctx->stream));
+    // The list of the filled voxels: compacted in one launch into buffers sized for what the last
+    // closure needed (first call: a shell's share of the voxels); the true length is read at the
+    // call's ONE synchronisation, and a list that outgrew its buffers is written again.
+    long long cap = (long long)(ctx->pool_clo_index.cap / sizeof(int));
+    if (cap <= 0) {
+        const double v = (double)nwords * 64.0;
+        cap = (long long)std::min<double>(v, 8.0 * std::cbrt(v) * std::cbrt(v) + 4096.0);
+    }
+    arvx::CarveParams rp;
+    carve_geometry(ctx, rp);
+    rp.rec = ctx->d_rec;
     long long total = 0;
-    if (int rc = bit_compact_count(ctx, d_fill, nwords, d_cnt, d_off, &total)) return rc;
-    ctx->clo_count = total;
-    if (total > 0) {
-        ARVX_HIP(ctx->pool_clo_index.reserve((size_t)total * sizeof(int)));
+    for (int attempt = 0;; ++attempt) {
+        ARVX_HIP(ctx->pool_clo_index.reserve((size_t)cap * sizeof(int)));
         ctx->d_clo_index = (int *)ctx->pool_clo_index.p;
-        ARVX_HIP(ctx->pool_clo_rgba.reserve((size_t)total * sizeof(float4)));
+        ARVX_HIP(ctx->pool_clo_rgba.reserve((size_t)cap * sizeof(float4)));
         ctx->d_clo_rgba = (void *)ctx->pool_clo_rgba.p;
-        if (int rc = bit_compact_write(ctx, d_fill, nwords, g, d_off, ctx->d_clo_index,
-                                       (arvx::SparseWord *)ctx->pool_clo_rank.p))
+        const long long *d_total = nullptr;
+        if (int rc = bit_compact(ctx, d_fill, nwords, g, cap, ctx->d_clo_index,
+                                 (arvx::SparseWord *)ctx->pool_clo_rank.p, 1, &d_total))
             return rc;
         arvx::ClosureParams cp;
         cp.g = g;
@@ -2185,26 +2226,33 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
         cp.col = colour_list(ctx);
         cp.col_rgba = ctx->d_surf_rgba;
         if (radius == 1)
-            hipLaunchKernelGGL(arvx::closure_fill_kernel<true>, dim3((unsigned)((total + 255) / 256)),
-                               dim3(256), 0, ctx->stream, cp, ctx->d_clo_index, total,
+            hipLaunchKernelGGL(arvx::closure_fill_kernel<true>, dim3((unsigned)((cap + 255) / 256)),
+                               dim3(256), 0, ctx->stream, cp, ctx->d_clo_index, cap, d_total,
                                (float4 *)ctx->d_clo_rgba);
         else
-            hipLaunchKernelGGL(arvx::closure_fill_kernel<false>, dim3((unsigned)((total + 255) / 256)),
-                               dim3(256), 0, ctx->stream, cp, ctx->d_clo_index, total,
+            hipLaunchKernelGGL(arvx::closure_fill_kernel<false>, dim3((unsigned)((cap + 255) / 256)),
+                               dim3(256), 0, ctx->stream, cp, ctx->d_clo_index, cap, d_total,
                                (float4 *)ctx->d_clo_rgba);
         ARVX_HIP(hipGetLastError());
-        // the filled voxels are occupied from now on (their w is count / count = 1)
-        arvx::CarveParams rp;
-        carve_geometry(ctx, rp);
-        rp.rec = ctx->d_rec;
-        hipLaunchKernelGGL(arvx::rec_or_bitgrid_kernel, dim3(gw), dim3(256), 0, ctx->stream, rp, 0,
-                           g.Z, d_fill);
-        ARVX_HIP(hipGetLastError());
-        state_rewritten(ctx);  // (voxels of tiles an earlier carve emptied may be occupied again)
-        ctx->h_clo_index.resize((size_t)total);
-        ARVX_HIP(hipMemcpyAsync(ctx->h_clo_index.data(), ctx->d_clo_index,
-                                (size_t)total * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        if (attempt == 0) {
+            // the filled voxels are occupied from now on (their w is count / count = 1); the fill
+            // kernel reads the occupancy from the bit planes, not from the records
+            hipLaunchKernelGGL(arvx::rec_or_bitgrid_kernel, dim3(gw), dim3(256), 0, ctx->stream, rp, 0,
+                               g.Z, d_fill);
+            ARVX_HIP(hipGetLastError());
+        }
         ARVX_SYNC(ctx);
+        total = ctx->h_totals[1];
+        if (total < 0) return fail(ARVX_ERR_HIP, "the compaction left no count");
+        if (total <= cap || attempt) break;
+        cap = total + total / 8;  // (once more, with room for all)
+    }
+    if (total > 0) state_rewritten(ctx);  // (voxels of tiles an earlier carve emptied may be occupied again)
+    ctx->clo_count = total;
+    ctx->clo_host_count = -1;  // the list's host copy is fetched when somebody asks
+    if (total == 0) {
+        ctx->d_clo_index = nullptr;
+        ctx->d_clo_rgba = nullptr;
     }
     ctx->closure_ready = true;
     ctx->closure_unseen = apply_unseen ? 1 : 0;
@@ -2212,9 +2260,25 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     return ARVX_OK;
 }
 
+// the closure list's indices on the host: fetched when somebody asks
+static int clo_host(Ctx *ctx) {
+    if (ctx->clo_host_count == ctx->clo_count) return ARVX_OK;
+    const size_t n = (size_t)ctx->clo_count;
+    ctx->h_clo_index.resize(n);
+    if (n) {
+        ARVX_HIP(hipMemcpyAsync(ctx->h_clo_index.data(), ctx->d_clo_index, n * sizeof(int),
+                                hipMemcpyDeviceToHost, ctx->stream));
+        ARVX_SYNC(ctx);
+    }
+    ctx->clo_host_count = ctx->clo_count;
+    return ARVX_OK;
+}
+
 int arvx_closure_count(arvx_ctx *ctx, int64_t *count) {
     if (!ctx || !count) return fail(ARVX_ERR_INVALID, "null argument");
     if (!ctx->closure_ready) return fail(ARVX_ERR_STATE, "no closure result (call arvx_closure)");
+    ARVX_HIP(hipSetDevice(ctx->device));
+    if (int rc = clo_host(ctx)) return rc;
     size_t lo, hi;
     long long base;
     owned_part(ctx, ctx->h_clo_index, lo, hi, base);
@@ -2226,6 +2290,7 @@ int arvx_closure_download(arvx_ctx *ctx, int64_t *index, float *rgba) {
     ARVX_CHECK_CTX(ctx);
     if (!index || !rgba) return fail(ARVX_ERR_INVALID, "null argument");
     if (!ctx->closure_ready) return fail(ARVX_ERR_STATE, "no closure result (call arvx_closure)");
+    if (int rc_h = clo_host(ctx)) return rc_h;
     size_t lo, hi;
     long long base;
     owned_part(ctx, ctx->h_clo_index, lo, hi, base);
@@ -2240,13 +2305,10 @@ int arvx_closure_download(arvx_ctx *ctx, int64_t *index, float *rgba) {
 
 // ---- marching-cubes hand-off ----------------------------------------------------------
 
-int arvx_mc_cells(arvx_ctx *ctx, int64_t *count) {
-    ARVX_CHECK_CTX(ctx);
-    if (!count) return fail(ARVX_ERR_INVALID, "null argument");
+// The cell list, launched without a synchronisation: up to `cap` cells into the context's buffer,
+// the list's true length in device word *d_total (and ctx->h_totals[2] after the next sync).
+static int mc_cells_launch(Ctx *ctx, long long cap, const long long **d_total) {
     if (int mrc = need_rec(ctx)) return mrc;
-    if (ctx->stripe_world > 1)
-        return fail(ARVX_ERR_STATE, "the cell walk needs contiguous slabs (neighbour planes)");
-    ctx->free_mc();
     arvx::McParams mp;
     mp.X = ctx->X;
     mp.Y = ctx->Y;
@@ -2260,16 +2322,13 @@ int arvx_mc_cells(arvx_ctx *ctx, int64_t *count) {
     mp.ZW = (mp.cz1 - mp.cz0 + 1 + 63) / 64;
     const size_t nzw = (size_t)mp.ZW * ctx->X * ctx->Y;  // z-packed occupancy words
     const long long ncol = (long long)(ctx->X + 1) * (ctx->Y + 1);
-    const int nsb = (int)((ncol + arvx::kScanBlock - 1) / arvx::kScanBlock);
     if (int rc = ensure_scratch(ctx, nzw * sizeof(unsigned long long) +
-                                         (size_t)(ncol + nsb + 1) * sizeof(long long) +
-                                         (size_t)(ncol + nsb) * sizeof(int) + 64))
+                                         (size_t)(ncol + 1) * sizeof(long long) +
+                                         (size_t)ncol * sizeof(int) + 64))
         return rc;
     mp.zbits = (unsigned long long *)ctx->d_scratch;
     long long *d_off = (long long *)(mp.zbits + nzw);  // ncol column offsets
-    long long *d_boff = d_off + ncol;                   // nsb + 1 block offsets, last = total
-    int *d_cnt = (int *)(d_boff + nsb + 1);
-    int *d_bsum = d_cnt + ncol;
+    int *d_cnt = (int *)(d_off + ncol + 1);
     {
         arvx::CarveParams g;
         carve_geometry(ctx, g);
@@ -2282,27 +2341,42 @@ int arvx_mc_cells(arvx_ctx *ctx, int64_t *count) {
     const unsigned nblk = (unsigned)((ncol + 255) / 256);
     hipLaunchKernelGGL(arvx::mc_count_kernel, dim3(nblk), dim3(256), 0, ctx->stream, mp, d_cnt);
     ARVX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(arvx::mc_block_sum_kernel, dim3(nsb), dim3(256), 0, ctx->stream, d_cnt,
-                       (int)ncol, d_bsum);
+    // the columns' offsets in the list: one launch (the three-launch block scan before it)
+    if (int rc = scan_counts(ctx, arvx::IntArraySrc{d_cnt}, ncol, nullptr, d_off, 2, d_total)) return rc;
+    ARVX_HIP(ctx->pool_mc_cells.reserve((size_t)cap * sizeof(int4)));
+    ctx->d_mc_cells = (void *)ctx->pool_mc_cells.p;
+    hipLaunchKernelGGL(arvx::mc_write_kernel, dim3(nblk), dim3(256), 0, ctx->stream, mp, d_off, cap,
+                       (int4 *)ctx->d_mc_cells);
     ARVX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(arvx::mc_scan_blocks_kernel, dim3(1), dim3(256), 0, ctx->stream, d_bsum, nsb,
-                       d_boff);
-    ARVX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(arvx::mc_block_scan_kernel, dim3(nsb), dim3(256), 0, ctx->stream, d_cnt,
-                       (int)ncol, d_boff, d_off);
-    ARVX_HIP(hipGetLastError());
-    long long total = 0;
-    ARVX_HIP(hipMemcpyAsync(&total, d_boff + nsb, sizeof total, hipMemcpyDeviceToHost,
-                            ctx->stream));
-    ARVX_SYNC(ctx);
-    if (total > 0) {
-        ARVX_HIP(ctx->pool_mc_cells.reserve((size_t)total * sizeof(int4)));
-        ctx->d_mc_cells = (void *)ctx->pool_mc_cells.p;
-        hipLaunchKernelGGL(arvx::mc_write_kernel, dim3(nblk), dim3(256), 0, ctx->stream, mp, d_off,
-                           (int4 *)ctx->d_mc_cells);
-        ARVX_HIP(hipGetLastError());
-        ARVX_SYNC(ctx);
+    return ARVX_OK;
+}
+// room for the cell list before its length is known: what the last list needed, or a surface's share
+static long long mc_cells_cap(const Ctx *ctx) {
+    long long cap = (long long)(ctx->pool_mc_cells.cap / sizeof(int4));
+    if (cap <= 0) {
+        const double v = (double)ctx->nvox_ext;
+        cap = (long long)std::min<double>(v + 1e6, 8.0 * std::cbrt(v) * std::cbrt(v) + 4096.0);
     }
+    return cap;
+}
+
+int arvx_mc_cells(arvx_ctx *ctx, int64_t *count) {
+    ARVX_CHECK_CTX(ctx);
+    if (!count) return fail(ARVX_ERR_INVALID, "null argument");
+    if (ctx->stripe_world > 1)
+        return fail(ARVX_ERR_STATE, "the cell walk needs contiguous slabs (neighbour planes)");
+    ctx->free_mc();
+    long long cap = mc_cells_cap(ctx), total = 0;
+    for (int attempt = 0;; ++attempt) {  // ONE synchronisation; a second round only if the list outgrew its room
+        const long long *d_total = nullptr;
+        if (int rc = mc_cells_launch(ctx, cap, &d_total)) return rc;
+        ARVX_SYNC(ctx);
+        total = ctx->h_totals[2];
+        if (total < 0) return fail(ARVX_ERR_HIP, "the scan left no count");
+        if (total <= cap || attempt) break;
+        cap = total + total / 8;
+    }
+    if (total == 0) ctx->d_mc_cells = nullptr;
     ctx->mc_count = total;
     ctx->mc_ready = true;
     *count = total;
@@ -2345,35 +2419,28 @@ int arvx_mc_mesh(arvx_ctx *ctx, int apply_unseen, int64_t *triangles) {
                                         "radius %d (it has %d): arvx_ctx_create_slab_halo",
                         ctx->closure_radius + 2, ctx->closure_radius, ctx->halo);
     }
-    int64_t ncells = 0;
-    if (int rc = arvx_mc_cells(ctx, &ncells)) return rc;
+    // cells -> triangles per cell -> triangles, all launched before the call's ONE synchronisation:
+    // the lists' lengths are not known when their buffers are sized (what the last mesh needed, or
+    // a surface's share of the voxels), the kernels stop at the room they have, and a mesh that
+    // outgrew it is built once more with room for all.
+    ctx->free_mc();
     ctx->mesh_tris = 0;
     *triangles = 0;
-    if (ncells == 0) return ARVX_OK;
-    const int n = (int)ncells;
-    const int nsb = (n + arvx::kScanBlock - 1) / arvx::kScanBlock;
-    if (int rc = ensure_scratch(ctx, (size_t)(n + nsb + 1) * sizeof(long long) +
-                                         (size_t)(n + nsb) * sizeof(int) + 64))
-        return rc;
-    long long *d_off = (long long *)ctx->d_scratch, *d_boff = d_off + n;
-    int *d_cnt = (int *)(d_boff + nsb + 1), *d_bsum = d_cnt + n;
-    const unsigned nblk = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(arvx::mc_tri_count_kernel, dim3(nblk), dim3(256), 0, ctx->stream,
-                       (const int4 *)ctx->d_mc_cells, (long long)n, d_cnt);
-    hipLaunchKernelGGL(arvx::mc_block_sum_kernel, dim3(nsb), dim3(256), 0, ctx->stream, d_cnt, n,
-                       d_bsum);
-    hipLaunchKernelGGL(arvx::mc_scan_blocks_kernel, dim3(1), dim3(256), 0, ctx->stream, d_bsum, nsb,
-                       d_boff);
-    hipLaunchKernelGGL(arvx::mc_block_scan_kernel, dim3(nsb), dim3(256), 0, ctx->stream, d_cnt, n,
-                       d_boff, d_off);
-    ARVX_HIP(hipGetLastError());
-    long long total = 0;
-    ARVX_HIP(hipMemcpyAsync(&total, d_boff + nsb, sizeof total, hipMemcpyDeviceToHost,
-                            ctx->stream));
-    ARVX_SYNC(ctx);
-    if (total > 0) {
-        ARVX_HIP(ctx->pool_mesh_verts.reserve((size_t)total * 9 * sizeof(float)));
-        ARVX_HIP(ctx->pool_mesh_rgb.reserve((size_t)total * 6 * sizeof(unsigned)));  // face records
+    long long ccap = mc_cells_cap(ctx);
+    long long tcap = (long long)(ctx->pool_mesh_verts.cap / (9 * sizeof(float)));
+    if (tcap <= 0) tcap = 2 * ccap;
+    long long ncells = 0, total = 0;
+    for (int attempt = 0;; ++attempt) {
+        const long long *d_ncells = nullptr, *d_ntris = nullptr;
+        if (int rc = mc_cells_launch(ctx, ccap, &d_ncells)) return rc;
+        // (the scratch buffer holds mc_cells_launch's arrays: the triangle offsets get their own)
+        ARVX_HIP(ctx->pool_mesh_off.reserve((size_t)(ccap + 1) * sizeof(long long)));
+        long long *d_off = (long long *)ctx->pool_mesh_off.p;
+        if (int rc = scan_counts(ctx, arvx::TriCountSrc{(const int4 *)ctx->d_mc_cells}, ccap, d_ncells, d_off,
+                                 3, &d_ntris))
+            return rc;
+        ARVX_HIP(ctx->pool_mesh_verts.reserve((size_t)tcap * 9 * sizeof(float)));
+        ARVX_HIP(ctx->pool_mesh_rgb.reserve((size_t)tcap * 6 * sizeof(unsigned)));  // face records
         arvx::McMeshParams mp;
         carve_geometry(ctx, mp.g);
         mp.g.rec = ctx->d_rec;
@@ -2383,12 +2450,25 @@ int arvx_mc_mesh(arvx_ctx *ctx, int apply_unseen, int64_t *triangles) {
         mp.col_rgba = ctx->d_surf_rgba;
         mp.clo = closure_list(ctx);
         mp.clo_rgba = (const float4 *)ctx->d_clo_rgba;
-        hipLaunchKernelGGL(arvx::mc_mesh_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                           ctx->stream, mp,
-                           (const int4 *)ctx->d_mc_cells, (long long)n, d_off,
+        hipLaunchKernelGGL(arvx::mc_mesh_kernel, dim3((unsigned)((ccap + 255) / 256)), dim3(256), 0,
+                           ctx->stream, mp, (const int4 *)ctx->d_mc_cells, ccap, d_ncells, tcap, d_off,
                            (float *)ctx->pool_mesh_verts.p, (unsigned *)ctx->pool_mesh_rgb.p);
         ARVX_HIP(hipGetLastError());
+        ARVX_SYNC(ctx);
+        ncells = ctx->h_totals[2];
+        total = ctx->h_totals[3];
+        if (ncells < 0 || total < 0) return fail(ARVX_ERR_HIP, "the scans left no count");
+        if ((ncells <= ccap && total <= tcap) || attempt) break;
+        // (with too few cells the triangle count is of the cells that fitted: five per cell at most)
+        if (ncells > ccap) {
+            tcap = std::max(tcap, total + 5 * (ncells - ccap));
+            ccap = ncells + ncells / 8;
+        }
+        if (total > tcap) tcap = total + total / 8;
     }
+    if (ncells == 0) ctx->d_mc_cells = nullptr;
+    ctx->mc_count = ncells;
+    ctx->mc_ready = true;
     ctx->mesh_tris = total;
     *triangles = total;
     return ARVX_OK;
@@ -2425,6 +2505,7 @@ int arvx_closure_download32(arvx_ctx *ctx, int32_t *index, float *rgba) {
     ARVX_CHECK_CTX(ctx);
     if (!index || !rgba) return fail(ARVX_ERR_INVALID, "null argument");
     if (!ctx->closure_ready) return fail(ARVX_ERR_STATE, "no closure result (call arvx_closure)");
+    if (int rc_h = clo_host(ctx)) return rc_h;
     size_t lo, hi;
     long long base;
     owned_part(ctx, ctx->h_clo_index, lo, hi, base);

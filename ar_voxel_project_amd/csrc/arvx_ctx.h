@@ -69,6 +69,7 @@ struct Ctx {
     uint32_t compact_epoch = 0;
     long long *h_totals = nullptr, *d_totals_host = nullptr;  // 6 slots (host / device address)
     long long surf_host_count = -1;  // entries of h_surf_index / h_surf_has that are valid (-1: fetch)
+    long long clo_host_count = -1;   // ... of h_clo_index
 
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -165,7 +166,7 @@ struct Ctx {
     bool mc_ready = false;
     // storage behind the d_surf_* / d_clo_* / d_mc_cells views (kept until destroy)
     DevPool pool_surf_index, pool_surf_rgb, pool_surf_depth, pool_surf_has, pool_clo_index,
-        pool_clo_rgba, pool_mc_cells, pool_raw_masks, pool_mesh_verts, pool_mesh_rgb;
+        pool_clo_rgba, pool_mc_cells, pool_raw_masks, pool_mesh_verts, pool_mesh_rgb, pool_mesh_off;
     int64_t mesh_tris = 0;  // triangles of the last arvx_mc_mesh
     void release_pools() {
         pool_surf_index.release();
@@ -178,6 +179,7 @@ struct Ctx {
         pool_raw_masks.release();
         pool_mesh_verts.release();
         pool_mesh_rgb.release();
+        pool_mesh_off.release();
         pool_xscratch.release();
         pool_vstrip.release();
         vstrip_key = 0;
@@ -203,6 +205,7 @@ struct Ctx {
         d_clo_rgba = nullptr;
         clo_count = 0;
         closure_ready = false;
+        clo_host_count = -1;
         h_clo_index.clear();
     }
 

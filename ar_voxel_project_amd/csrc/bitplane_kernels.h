@@ -167,6 +167,64 @@ __global__ __launch_bounds__(256) void bit_write_kernel(const unsigned long long
 // ticket_ctr: 64-bit, never reset; ticket_base: the tickets all earlier launches took.
 constexpr uint32_t kCompactPrefix = 0x80000000u;  // status: the value is an inclusive prefix
 
+// one value per thread across the 256-thread workgroup: returns the exclusive prefix, *total the sum
+__device__ __forceinline__ long long wg_scan_exclusive(long long mine, long long *wtot, long long *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long sc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long t = __shfl_up(sc, d);
+        if (lane >= d) sc += t;
+    }
+    if (lane == 63) wtot[wave] = sc;
+    __syncthreads();
+    long long pre = sc - mine;
+    for (int w = 0; w < wave; ++w) pre += wtot[w];
+    *total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    return pre;
+}
+
+// The set bits (or counts) before chunk c: wave 0 of the workgroup publishes the chunk's aggregate
+// and looks back over the chunks before it, 64 at a time, until it meets one that has published
+// its inclusive prefix; then it publishes its own.  Returns the exclusive prefix (in every lane of
+// the wave).  A chunk only waits for lower tickets: workgroups that are running.
+__device__ __forceinline__ long long lookback_exclusive(unsigned long long *__restrict__ status, int c,
+                                                        long long agg, uint32_t tag,
+                                                        unsigned *__restrict__ fault, int lane) {
+    long long excl = 0;
+    if (c > 0) {
+        if (lane == 0) granule_store(status + c, (uint32_t)agg, tag);
+        int look = c - 1;  // lane l looks at chunk look - l
+        for (unsigned spin = 0;;) {
+            const int k = look - lane;
+            unsigned long long gr = ((unsigned long long)tag << 32) | kCompactPrefix;  // (before chunk 0: prefix 0)
+            if (k >= 0) gr = granule_load(status + k);
+            const bool valid = (uint32_t)(gr >> 32) == tag;
+            const bool pref = valid && ((uint32_t)gr & kCompactPrefix);
+            const unsigned long long vmask = __ballot(valid), pmask = __ballot(pref);
+            const int fp = pmask ? __ffsll((long long)pmask) - 1 : 64;  // nearest chunk with a prefix
+            const unsigned long long need = fp < 63 ? ((2ull << fp) - 1ull) : ~0ull;
+            if ((vmask & need) != need) {  // a chunk in between has not published yet
+                if (++spin > (1u << 20)) {
+                    if (lane == 0 && fault)
+                        __hip_atomic_store(fault, 6u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            long long v = (lane <= fp) ? (long long)((uint32_t)gr & ~kCompactPrefix) : 0;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+            excl += v;
+            if (fp < 64) break;
+            look -= 64;
+        }
+    }
+    if (lane == 0) granule_store(status + c, (uint32_t)(excl + agg) | kCompactPrefix, tag);
+    return excl;
+}
+
 __global__ __launch_bounds__(256) void bit_compact_kernel(
     const unsigned long long *__restrict__ bits, size_t nwords, const BitGrid g,
     unsigned long long *__restrict__ ticket_ctr, unsigned long long ticket_base,
@@ -198,39 +256,8 @@ __global__ __launch_bounds__(256) void bit_compact_kernel(
     const int agg = wtot[0] + wtot[1] + wtot[2] + wtot[3];  // (< 2^19)
     __syncthreads();  // (wtot is used again below)
     if (wave == 0) {
-        long long excl = 0;
-        if (c > 0) {
-            if (lane == 0) granule_store(status + c, (uint32_t)agg, tag);
-            // look back, 64 chunks at a time: lane l at chunk look - l
-            int look = c - 1;
-            for (unsigned spin = 0;;) {
-                const int k = look - lane;
-                unsigned long long gr = ((unsigned long long)tag << 32) | kCompactPrefix;  // (before chunk 0: prefix 0)
-                if (k >= 0) gr = granule_load(status + k);
-                const bool valid = (uint32_t)(gr >> 32) == tag;
-                const bool pref = valid && ((uint32_t)gr & kCompactPrefix);
-                const unsigned long long vmask = __ballot(valid), pmask = __ballot(pref);
-                const int fp = pmask ? __ffsll((long long)pmask) - 1 : 64;  // nearest chunk with a prefix
-                const unsigned long long need = fp < 63 ? ((2ull << fp) - 1ull) : ~0ull;
-                if ((vmask & need) != need) {  // a chunk in between has not published yet
-                    if (++spin > (1u << 20)) {
-                        if (lane == 0 && fault)
-                            __hip_atomic_store(fault, 6u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                    continue;
-                }
-                long long v = (lane <= fp) ? (long long)((uint32_t)gr & ~kCompactPrefix) : 0;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-                excl += v;
-                if (fp < 64) break;
-                look -= 64;
-            }
-        }
+        const long long excl = lookback_exclusive(status, c, agg, tag, fault, lane);
         if (lane == 0) {
-            granule_store(status + c, (uint32_t)(excl + agg) | kCompactPrefix, tag);
             s_excl = excl;
             if (c == nchunks - 1) {
                 *total = excl + agg;
@@ -269,6 +296,55 @@ __global__ __launch_bounds__(256) void bit_compact_kernel(
         }
         run += wtot[0] + wtot[1] + wtot[2] + wtot[3];
         __syncthreads();
+    }
+}
+
+// Exclusive scan of one small count per entry in ONE launch, the same way: a chunk of kScanChunk
+// entries per workgroup and ticket.  src(i): entry i's count (>= 0); entries at or behind *n_dev
+// (when given) count nothing.  offsets[i] for i < n; the sum goes to *total and *total_host.
+constexpr int kScanChunk = 4096;
+template <class Src>
+__global__ __launch_bounds__(256) void scan_lookback_kernel(
+    const Src src, long long n, const long long *__restrict__ n_dev, long long *__restrict__ offsets,
+    unsigned long long *__restrict__ ticket_ctr, unsigned long long ticket_base,
+    unsigned long long *__restrict__ status, uint32_t tag, long long *__restrict__ total,
+    long long *__restrict__ total_host, unsigned *__restrict__ fault) {
+    __shared__ long long wtot[4];
+    __shared__ int s_chunk;
+    __shared__ long long s_excl;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_chunk = (int)(atomicAdd(ticket_ctr, 1ull) - ticket_base);
+    __syncthreads();
+    const int c = s_chunk;
+    const int nchunks = (int)((n + kScanChunk - 1) / kScanChunk);
+    const long long n_eff = n_dev ? (*n_dev < n ? *n_dev : n) : n;
+    const long long i0 = (long long)c * kScanChunk + (long long)threadIdx.x * (kScanChunk / 256);
+    int v[kScanChunk / 256];
+    long long mine = 0;
+#pragma unroll
+    for (int k = 0; k < kScanChunk / 256; ++k) {
+        v[k] = (i0 + k < n_eff) ? src(i0 + k) : 0;
+        mine += v[k];
+    }
+    long long agg;
+    long long pre = wg_scan_exclusive(mine, wtot, &agg);
+    if (wave == 0) {
+        const long long excl = lookback_exclusive(status, c, agg, tag, fault, lane);
+        if (lane == 0) {
+            s_excl = excl;
+            if (c == nchunks - 1) {
+                *total = excl + agg;
+                if (total_host)
+                    __hip_atomic_store(total_host, excl + agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    __syncthreads();
+    pre += s_excl;
+#pragma unroll
+    for (int k = 0; k < kScanChunk / 256; ++k) {
+        if (i0 + k < n) offsets[i0 + k] = pre;
+        pre += v[k];
     }
 }
 

@@ -145,9 +145,11 @@ template <bool BOX3>
 __global__ __launch_bounds__(256) void closure_fill_kernel(const ClosureParams p,
                                                            const int *__restrict__ index,
                                                            long long n,
+                                                           const long long *__restrict__ n_dev,
                                                            float4 *__restrict__ rgba) {
+    // n: the list's capacity; n_dev: its length as the compaction left it on the device
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
+    if (e >= n || e >= *n_dev) return;
     float4 sum;
     const int count = BOX3 ? cl_gather3(p, (size_t)index[e], sum) : cl_gather(p, (size_t)index[e], sum);
     const float fc = (float)count;  // Eigen `sum /= count`, src/Postprocessing3d.cpp:49-51

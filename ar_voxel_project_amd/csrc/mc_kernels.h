@@ -240,14 +240,24 @@ __global__ __launch_bounds__(256) void mc_block_scan_kernel(const int *__restric
     }
 }
 
+// cap: room in `cells` (the list's length is not known when the buffers are sized: the caller
+// reads the true total at its synchronisation and repeats the launch if it was larger)
 __global__ __launch_bounds__(256) void mc_write_kernel(const McParams p,
                                                        const long long *__restrict__ offsets,
-                                                       int4 *__restrict__ cells) {
+                                                       long long cap, int4 *__restrict__ cells) {
     int cx, cy;
     if (!mc_column_of_thread(p, cx, cy)) return;
     long long at = offsets[(size_t)(cx + 1) * (p.Y + 1) + (cy + 1)];
-    mc_walk(p, cx, cy,
-            [&](int cz, unsigned idx) { cells[at++] = make_int4(cx, cy, cz, (int)idx); });
+    mc_walk(p, cx, cy, [&](int cz, unsigned idx) {
+        if (at < cap) cells[at] = make_int4(cx, cy, cz, (int)idx);
+        ++at;
+    });
 }
+
+// a plain array of counts as the source of scan_lookback_kernel (bitplane_kernels.h)
+struct IntArraySrc {
+    const int *p;
+    __device__ __forceinline__ int operator()(long long i) const { return p[i]; }
+};
 
 }  // namespace arvx

@@ -76,6 +76,11 @@ __global__ __launch_bounds__(256) void mc_tri_count_kernel(const int4 *__restric
     const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
     if (c < n) counts[c] = kMcTri.n[cells[c].w & 255];
 }
+// the triangles of cell i, as the source of scan_lookback_kernel (bitplane_kernels.h)
+struct TriCountSrc {
+    const int4 *cells;
+    __device__ __forceinline__ int operator()(long long i) const { return kMcTri.n[cells[i].w & 255]; }
+};
 
 __device__ __forceinline__ unsigned mc_mean3(float a, float b, float c) {
     const float s = (a + b) + c;
@@ -98,14 +103,17 @@ constexpr int kMeshMaxTris = 5;  // Bourke's table: at most five triangles per c
 //          the C++ layer's Triangle (include/arvx/marching_cubes.hpp), reference
 //          src/MarchingCubes.h:19-31
 // Only the first two corners' colours are ever used (col[2] = col[1], :506).
+// n_cap: room in `cells`; n_dev: the cell list's length on the device; tri_cap: room for triangles
 __global__ __launch_bounds__(256) void mc_mesh_kernel(const McMeshParams p,
-                                                      const int4 *__restrict__ cells, long long n,
+                                                      const int4 *__restrict__ cells, long long n_cap,
+                                                      const long long *__restrict__ n_dev, long long tri_cap,
                                                       const long long *__restrict__ tri_offset,
                                                       float *__restrict__ verts,
                                                       unsigned *__restrict__ faces) {
     // per wave and triangle: {x + 1 | (y + 1) << 16, z + 1 | offset bits << 16, r, g, b}
     __shared__ uint32_t s_tri[4][64 * kMeshMaxTris][5];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long n = *n_dev < n_cap ? *n_dev : n_cap;
     const long long c0 = ((long long)blockIdx.x * 4 + wave) * 64;
     if (c0 >= n) return;  // (no workgroup-wide barrier below: a wave only touches its own part)
     const long long c = c0 + lane;
@@ -161,6 +169,7 @@ __global__ __launch_bounds__(256) void mc_mesh_kernel(const McMeshParams p,
     float *vo = verts + 9 * base;  // ---- C
     for (int i = lane; i < 9 * ntri; i += 64) {
         const int t = i / 9, comp = i - 9 * t, axis = comp % 3;
+        if (base + t >= tri_cap) continue;  // (no room: the caller repeats the launch with more)
         const uint32_t w0 = mine[t][0], w1 = mine[t][1];
         const int origin = axis == 0 ? (int)(w0 & 0xffffu) : axis == 1 ? (int)(w0 >> 16)
                                                                         : (int)(w1 & 0xffffu);
@@ -169,6 +178,7 @@ __global__ __launch_bounds__(256) void mc_mesh_kernel(const McMeshParams p,
     unsigned *fo = faces + 6 * base;
     for (int i = lane; i < 6 * ntri; i += 64) {
         const int t = i / 6, f = i - 6 * t;
+        if (base + t >= tri_cap) continue;
         fo[i] = f < 3 ? (unsigned)(3 * (base + t) + f) : mine[t][f - 1];
     }
 }
