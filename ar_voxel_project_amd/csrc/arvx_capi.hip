@@ -2174,19 +2174,17 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     const size_t row_words = (size_t)XW * g.Y;
     const size_t nwords = row_words * g.Z;
     const bool paints = apply_unseen || ctx->paint_valid;  // somebody is UNSEEN_COLOR
-    if (int rc = ensure_scratch(ctx, 4 * nwords * sizeof(unsigned long long) + 64)) return rc;
+    if (int rc = ensure_scratch(ctx, 3 * nwords * sizeof(unsigned long long) + 64)) return rc;
     ARVX_HIP(ctx->pool_clo_bits.reserve(nwords * sizeof(unsigned long long)));
     ARVX_HIP(ctx->pool_clo_rank.reserve(nwords * sizeof(arvx::SparseWord)));
     unsigned long long *d_occ = (unsigned long long *)ctx->d_scratch;
-    unsigned long long *d_unseen = d_occ + nwords, *d_a = d_unseen + nwords, *d_b = d_a + nwords;
+    unsigned long long *d_unseen = d_occ + nwords, *d_b = d_unseen + nwords;
     unsigned long long *d_fill = (unsigned long long *)ctx->pool_clo_bits.p;
     if (int rc = launch_bit_pack(ctx, g, 1, apply_unseen ? 1 : 0, d_occ, paints ? d_unseen : nullptr))
         return rc;
     const unsigned gw = (unsigned)((nwords + 255) / 256);
-    hipLaunchKernelGGL(arvx::bit_dilate_x_kernel, dim3(gw), dim3(256), 0, ctx->stream, d_occ, g,
-                       radius, d_a);
-    hipLaunchKernelGGL(arvx::bit_dilate_yz_kernel, dim3(gw), dim3(256), 0, ctx->stream, d_a, g,
-                       radius, 1, (const unsigned long long *)nullptr, d_b);
+    hipLaunchKernelGGL(arvx::bit_dilate_xy_kernel, dim3(gw), dim3(256), 0, ctx->stream, d_occ, g,
+                       radius, d_b);
     hipLaunchKernelGGL(arvx::bit_dilate_yz_kernel, dim3(gw), dim3(256), 0, ctx->stream, d_b, g,
                        radius, 2, (const unsigned long long *)d_occ, d_fill);
     ARVX_HIP(hipGetLastError());

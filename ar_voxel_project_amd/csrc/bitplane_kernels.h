@@ -53,17 +53,23 @@ __global__ __launch_bounds__(256) void bit_surface_kernel(const unsigned long lo
     out[w] = c & ~inner;
 }
 
-// box dilation, one axis per launch (r = radius, 1..4)
-__global__ __launch_bounds__(256) void bit_dilate_x_kernel(const unsigned long long *__restrict__ in,
-                                                           const BitGrid g, int r,
-                                                           unsigned long long *__restrict__ out) {
+// box dilation (r = radius, 1..4).  x and y in one launch: the rows y-r..y+r, each dilated along x on the way (round 4: one launch and
+// one pass over the plane less than bit_dilate_x_kernel + the y pass)
+__global__ __launch_bounds__(256) void bit_dilate_xy_kernel(const unsigned long long *__restrict__ in,
+                                                            const BitGrid g, int r,
+                                                            unsigned long long *__restrict__ out) {
     const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (w >= (size_t)g.XW * g.Y * g.Z) return;
     const int xw = (int)(w % g.XW);
-    const unsigned long long c = in[w];
-    const unsigned long long L = xw > 0 ? in[w - 1] : 0ull, R = xw + 1 < g.XW ? in[w + 1] : 0ull;
-    unsigned long long acc = c;
-    for (int k = 1; k <= r; ++k) acc |= (c << k) | (c >> k) | (L >> (64 - k)) | (R << (64 - k));
+    const size_t row = w / g.XW;
+    const int y = (int)(row % g.Y), z = (int)(row / g.Y);
+    unsigned long long acc = 0ull;
+    for (int dy = -r; dy <= r; ++dy) {
+        const unsigned long long c = bit_word(in, g, xw, y + dy, z);
+        const unsigned long long L = bit_word(in, g, xw - 1, y + dy, z), R = bit_word(in, g, xw + 1, y + dy, z);
+        acc |= c;
+        for (int k = 1; k <= r; ++k) acc |= (c << k) | (c >> k) | (L >> (64 - k)) | (R << (64 - k));
+    }
     const int nbits = min(64, g.X - xw * 64);  // keep the padding clear
     if (nbits < 64) acc &= (1ull << nbits) - 1ull;
     out[w] = acc;
@@ -312,18 +318,27 @@ __global__ __launch_bounds__(256) void scan_lookback_kernel(
     __shared__ long long wtot[4];
     __shared__ int s_chunk;
     __shared__ long long s_excl;
+    __shared__ int s_val[kScanChunk];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_chunk = (int)(atomicAdd(ticket_ctr, 1ull) - ticket_base);
     __syncthreads();
     const int c = s_chunk;
     const int nchunks = (int)((n + kScanChunk - 1) / kScanChunk);
     const long long n_eff = n_dev ? (*n_dev < n ? *n_dev : n) : n;
+    // the chunk's counts: read with neighbouring threads at neighbouring entries (whole lines),
+    // handed to the threads that scan 16 consecutive ones each through LDS
+#pragma unroll
+    for (int it = 0; it < kScanChunk / 256; ++it) {
+        const long long i = (long long)c * kScanChunk + it * 256 + threadIdx.x;
+        s_val[it * 256 + threadIdx.x] = (i < n_eff) ? src(i) : 0;
+    }
+    __syncthreads();
     const long long i0 = (long long)c * kScanChunk + (long long)threadIdx.x * (kScanChunk / 256);
     int v[kScanChunk / 256];
     long long mine = 0;
 #pragma unroll
     for (int k = 0; k < kScanChunk / 256; ++k) {
-        v[k] = (i0 + k < n_eff) ? src(i0 + k) : 0;
+        v[k] = s_val[threadIdx.x * (kScanChunk / 256) + k];
         mine += v[k];
     }
     long long agg;
