@@ -224,7 +224,7 @@ static int compact_control(Ctx *ctx, size_t nchunks, uint8_t **base, unsigned lo
 // device word *d_total_out and to ctx->h_totals[slot].  n_dev (may be null): entries at or behind
 // *n_dev count nothing.
 template <class Src>
-static int scan_counts(Ctx *ctx, const Src &src, long long n, const long long *n_dev, long long *d_offsets,
+static int scan_counts(Ctx *ctx, const Src &src, long long n, const long long *n_dev, int *d_offsets,
                        int slot, const long long **d_total_out) {
     const size_t nchunks = (size_t)((n + arvx::kScanChunk - 1) / arvx::kScanChunk);
     uint8_t *base = nullptr;
@@ -233,7 +233,7 @@ static int scan_counts(Ctx *ctx, const Src &src, long long n, const long long *n
     long long *d_total = (long long *)(base + 8 + 8 * slot);
     ctx->h_totals[slot] = -1;
     hipLaunchKernelGGL(arvx::scan_lookback_kernel<Src>, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream,
-                       src, n, n_dev, d_offsets, (unsigned long long *)base, ctx->compact_tickets, status,
+                       src, n, n_dev, d_offsets, (unsigned *)base, (unsigned)ctx->compact_tickets, status,
                        ctx->compact_epoch, d_total, ctx->d_totals_host + slot, ctx->d_fault);
     ARVX_HIP(hipGetLastError());
     ctx->compact_tickets += nchunks;
@@ -255,7 +255,7 @@ static int bit_compact(Ctx *ctx, const unsigned long long *bits, size_t nwords, 
     long long *d_total = (long long *)(base + 8 + 8 * slot);
     ctx->h_totals[slot] = -1;
     hipLaunchKernelGGL(arvx::bit_compact_kernel, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream, bits,
-                       nwords, g, (unsigned long long *)base, ctx->compact_tickets, status,
+                       nwords, g, (unsigned *)base, (unsigned)ctx->compact_tickets, status,
                        ctx->compact_epoch, cap, d_index, d_words,
                        d_total, ctx->d_totals_host + slot, ctx->d_fault);
     ARVX_HIP(hipGetLastError());
@@ -2325,8 +2325,8 @@ static int mc_cells_launch(Ctx *ctx, long long cap, const long long **d_total) {
                                          (size_t)ncol * sizeof(int) + 64))
         return rc;
     mp.zbits = (unsigned long long *)ctx->d_scratch;
-    long long *d_off = (long long *)(mp.zbits + nzw);  // ncol column offsets
-    int *d_cnt = (int *)(d_off + ncol + 1);
+    int *d_off = (int *)(mp.zbits + nzw);  // ncol column offsets
+    int *d_cnt = d_off + ncol + 1;
     {
         arvx::CarveParams g;
         carve_geometry(ctx, g);
@@ -2432,8 +2432,8 @@ int arvx_mc_mesh(arvx_ctx *ctx, int apply_unseen, int64_t *triangles) {
         const long long *d_ncells = nullptr, *d_ntris = nullptr;
         if (int rc = mc_cells_launch(ctx, ccap, &d_ncells)) return rc;
         // (the scratch buffer holds mc_cells_launch's arrays: the triangle offsets get their own)
-        ARVX_HIP(ctx->pool_mesh_off.reserve((size_t)(ccap + 1) * sizeof(long long)));
-        long long *d_off = (long long *)ctx->pool_mesh_off.p;
+        ARVX_HIP(ctx->pool_mesh_off.reserve((size_t)(ccap + 1) * sizeof(int)));
+        int *d_off = (int *)ctx->pool_mesh_off.p;
         if (int rc = scan_counts(ctx, arvx::TriCountSrc{(const int4 *)ctx->d_mc_cells}, ccap, d_ncells, d_off,
                                  3, &d_ntris))
             return rc;

@@ -170,7 +170,8 @@ __global__ __launch_bounds__(256) void bit_write_kernel(const unsigned long long
 // part of the list -- up to `cap` entries: the true total goes to *total (device) and to the
 // page-locked word *total_host, which the host reads at the call's ONE synchronisation; a call whose
 // list outgrew the capacity it guessed repeats the launch with room for all.
-// ticket_ctr: 64-bit, never reset; ticket_base: the tickets all earlier launches took.
+// ticket_ctr: 32-bit (a 64-bit returning atomic on one word paced the launch), never reset, wraps;
+// ticket_base: the tickets all earlier launches took (modulo 2^32).
 constexpr uint32_t kCompactPrefix = 0x80000000u;  // status: the value is an inclusive prefix
 
 // one value per thread across the 256-thread workgroup: returns the exclusive prefix, *total the sum
@@ -200,31 +201,49 @@ __device__ __forceinline__ long long lookback_exclusive(unsigned long long *__re
     long long excl = 0;
     if (c > 0) {
         if (lane == 0) granule_store(status + c, (uint32_t)agg, tag);
-        int look = c - 1;  // lane l looks at chunk look - l
-        for (unsigned spin = 0;;) {
-            const int k = look - lane;
-            unsigned long long gr = ((unsigned long long)tag << 32) | kCompactPrefix;  // (before chunk 0: prefix 0)
-            if (k >= 0) gr = granule_load(status + k);
-            const bool valid = (uint32_t)(gr >> 32) == tag;
-            const bool pref = valid && ((uint32_t)gr & kCompactPrefix);
-            const unsigned long long vmask = __ballot(valid), pmask = __ballot(pref);
-            const int fp = pmask ? __ffsll((long long)pmask) - 1 : 64;  // nearest chunk with a prefix
-            const unsigned long long need = fp < 63 ? ((2ull << fp) - 1ull) : ~0ull;
-            if ((vmask & need) != need) {  // a chunk in between has not published yet
+        // Eight windows of 64 chunks are requested together (one round trip for 512 chunks: the
+        // workgroups of a launch start together, so by the time one looks back nearly every chunk
+        // before it has published its aggregate -- walking window by window, every 64 chunks cost a
+        // round trip of their own) and consumed nearest first, until one holds an inclusive prefix.
+        constexpr int K = 8;
+        int look = c - 1;  // lane l of window j looks at chunk look - 64 j - l
+        bool done = false;
+        for (unsigned spin = 0; !done;) {
+            unsigned long long gr[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int k = look - 64 * j - lane;
+                gr[j] = ((unsigned long long)tag << 32) | kCompactPrefix;  // (before chunk 0: prefix 0)
+                if (k >= 0) gr[j] = granule_load(status + k);
+            }
+            bool stalled = false;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                if (done || stalled) continue;
+                const bool valid = (uint32_t)(gr[j] >> 32) == tag;
+                const bool pref = valid && ((uint32_t)gr[j] & kCompactPrefix);
+                const unsigned long long vmask = __ballot(valid), pmask = __ballot(pref);
+                const int fp = pmask ? __ffsll((long long)pmask) - 1 : 64;  // nearest chunk with a prefix
+                const unsigned long long need = fp < 63 ? ((2ull << fp) - 1ull) : ~0ull;
+                if ((vmask & need) != need) {  // a chunk in between has not published yet
+                    stalled = true;
+                    continue;
+                }
+                long long v = (lane <= fp) ? (long long)((uint32_t)gr[j] & ~kCompactPrefix) : 0;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+                excl += v;
+                if (fp < 64) done = true;
+                else look -= 64;
+            }
+            if (stalled) {
                 if (++spin > (1u << 20)) {
                     if (lane == 0 && fault)
                         __hip_atomic_store(fault, 6u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
-                continue;
             }
-            long long v = (lane <= fp) ? (long long)((uint32_t)gr & ~kCompactPrefix) : 0;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-            excl += v;
-            if (fp < 64) break;
-            look -= 64;
         }
     }
     if (lane == 0) granule_store(status + c, (uint32_t)(excl + agg) | kCompactPrefix, tag);
@@ -233,7 +252,7 @@ __device__ __forceinline__ long long lookback_exclusive(unsigned long long *__re
 
 __global__ __launch_bounds__(256) void bit_compact_kernel(
     const unsigned long long *__restrict__ bits, size_t nwords, const BitGrid g,
-    unsigned long long *__restrict__ ticket_ctr, unsigned long long ticket_base,
+    unsigned *__restrict__ ticket_ctr, unsigned ticket_base,
     unsigned long long *__restrict__ status, uint32_t tag, long long cap, int *__restrict__ index,
     SparseWord *__restrict__ words, long long *__restrict__ total, long long *__restrict__ total_host,
     unsigned *__restrict__ fault) {
@@ -241,7 +260,7 @@ __global__ __launch_bounds__(256) void bit_compact_kernel(
     __shared__ int s_chunk;
     __shared__ long long s_excl;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_chunk = (int)(atomicAdd(ticket_ctr, 1ull) - ticket_base);
+    if (threadIdx.x == 0) s_chunk = (int)(atomicAdd(ticket_ctr, 1u) - ticket_base);
     __syncthreads();
     const int c = s_chunk;
     const int nchunks = (int)((nwords + kBitChunk - 1) / kBitChunk);
@@ -307,12 +326,13 @@ __global__ __launch_bounds__(256) void bit_compact_kernel(
 
 // Exclusive scan of one small count per entry in ONE launch, the same way: a chunk of kScanChunk
 // entries per workgroup and ticket.  src(i): entry i's count (>= 0); entries at or behind *n_dev
-// (when given) count nothing.  offsets[i] for i < n; the sum goes to *total and *total_host.
+// (when given) count nothing.  offsets[i] (32 bits) for the entries in front of the end; the sum goes
+// to *total and *total_host.
 constexpr int kScanChunk = 4096;
 template <class Src>
 __global__ __launch_bounds__(256) void scan_lookback_kernel(
-    const Src src, long long n, const long long *__restrict__ n_dev, long long *__restrict__ offsets,
-    unsigned long long *__restrict__ ticket_ctr, unsigned long long ticket_base,
+    const Src src, long long n, const long long *__restrict__ n_dev, int *__restrict__ offsets,
+    unsigned *__restrict__ ticket_ctr, unsigned ticket_base,
     unsigned long long *__restrict__ status, uint32_t tag, long long *__restrict__ total,
     long long *__restrict__ total_host, unsigned *__restrict__ fault) {
     __shared__ long long wtot[4];
@@ -320,7 +340,7 @@ __global__ __launch_bounds__(256) void scan_lookback_kernel(
     __shared__ long long s_excl;
     __shared__ int s_val[kScanChunk];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_chunk = (int)(atomicAdd(ticket_ctr, 1ull) - ticket_base);
+    if (threadIdx.x == 0) s_chunk = (int)(atomicAdd(ticket_ctr, 1u) - ticket_base);
     __syncthreads();
     const int c = s_chunk;
     const int nchunks = (int)((n + kScanChunk - 1) / kScanChunk);
@@ -333,7 +353,6 @@ __global__ __launch_bounds__(256) void scan_lookback_kernel(
         s_val[it * 256 + threadIdx.x] = (i < n_eff) ? src(i) : 0;
     }
     __syncthreads();
-    const long long i0 = (long long)c * kScanChunk + (long long)threadIdx.x * (kScanChunk / 256);
     int v[kScanChunk / 256];
     long long mine = 0;
 #pragma unroll
@@ -356,10 +375,18 @@ __global__ __launch_bounds__(256) void scan_lookback_kernel(
     }
     __syncthreads();
     pre += s_excl;
+    // (the sums fit 31 bits: the status words carry them) back through LDS, so that the offsets
+    // leave as whole lines too; entries behind the list's end are not written
 #pragma unroll
     for (int k = 0; k < kScanChunk / 256; ++k) {
-        if (i0 + k < n) offsets[i0 + k] = pre;
+        s_val[threadIdx.x * (kScanChunk / 256) + k] = (int)pre;
         pre += v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kScanChunk / 256; ++it) {
+        const long long i = (long long)c * kScanChunk + it * 256 + threadIdx.x;
+        if (i < n_eff) offsets[i] = s_val[it * 256 + threadIdx.x];
     }
 }
 

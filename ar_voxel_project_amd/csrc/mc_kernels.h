@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void mc_block_scan_kernel(const int *__restric
 // cap: room in `cells` (the list's length is not known when the buffers are sized: the caller
 // reads the true total at its synchronisation and repeats the launch if it was larger)
 __global__ __launch_bounds__(256) void mc_write_kernel(const McParams p,
-                                                       const long long *__restrict__ offsets,
+                                                       const int *__restrict__ offsets,
                                                        long long cap, int4 *__restrict__ cells) {
     int cx, cy;
     if (!mc_column_of_thread(p, cx, cy)) return;

@@ -107,7 +107,7 @@ constexpr int kMeshMaxTris = 5;  // Bourke's table: at most five triangles per c
 __global__ __launch_bounds__(256) void mc_mesh_kernel(const McMeshParams p,
                                                       const int4 *__restrict__ cells, long long n_cap,
                                                       const long long *__restrict__ n_dev, long long tri_cap,
-                                                      const long long *__restrict__ tri_offset,
+                                                      const int *__restrict__ tri_offset,
                                                       float *__restrict__ verts,
                                                       unsigned *__restrict__ faces) {
     // per wave and triangle: {x + 1 | (y + 1) << 16, z + 1 | offset bits << 16, r, g, b}
