@@ -264,6 +264,19 @@ static int bit_compact(Ctx *ctx, const unsigned long long *bits, size_t nwords, 
     return ARVX_OK;
 }
 
+// The total a one-launch compaction / scan left for the host (after the call's synchronisation).  The
+// kernel stores it into the page-locked word; should the host not see that store, the device's own
+// copy of the word is fetched instead (-1: neither holds a count).
+static long long host_total(Ctx *ctx, int slot) {
+    const long long t = ctx->h_totals[slot];
+    if (t >= 0 || !ctx->pool_compact.p) return t;
+    long long dev = -1;
+    if (hipMemcpy(&dev, (const uint8_t *)ctx->pool_compact.p + 8 + 8 * slot, sizeof dev,
+                  hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    return dev;
+}
+
 static int bit_compact_write(Ctx *ctx, const unsigned long long *bits, size_t nwords,
                              const arvx::BitGrid &g, const long long *d_off, int *d_index,
                              arvx::SparseWord *d_words) {
@@ -389,7 +402,10 @@ int arvx_ctx_create_slab_halo(arvx_ctx **out, int device, int X, int Y, int Z, f
         arvx_ctx_destroy(c);
         return arvx::fail_hip(e, "hipMalloc(stats)", __FILE__, __LINE__);
     }
-    e = hipHostMalloc((void **)&c->h_fault, 64, hipHostMallocMapped);
+    // Coherent: without the flag a mapped allocation is non-coherent host memory -- the device's stores
+    // to it need not be seen by a host that has the line in its cache (the totals' words are reset by
+    // the host before every launch: a call then read its own -1 back, once in a few hundred calls)
+    e = hipHostMalloc((void **)&c->h_fault, 64, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) {
         memset(c->h_fault, 0, 64);
         e = hipHostGetDevicePointer((void **)&c->d_fault, c->h_fault, 0);
@@ -1589,6 +1605,8 @@ static int surf_host(Ctx *ctx);
 static int clo_host(Ctx *ctx);
 static void owned_part(const Ctx *ctx, const std::vector<int> &idx, size_t &lo, size_t &hi,
                        long long &base);
+// a context without halo planes owns every entry of its lists: their lengths need no host copy
+static bool owns_all_planes(const Ctx *ctx) { return ctx->z0 == ctx->ze0 && ctx->z1 == ctx->ze1; }
 
 int arvx_get_stats(arvx_ctx *ctx, arvx_stats *out) {
     ARVX_CHECK_CTX(ctx);
@@ -1602,7 +1620,9 @@ int arvx_get_stats(arvx_ctx *ctx, arvx_stats *out) {
     out->subtile_views_mixed = h[2];
     out->subtile_views_total = h[3];
     out->surface_voxels = 0;
-    if (ctx->color_ready) {  // the owned part of the colour pass's list (arvx_color)
+    if (ctx->color_ready && owns_all_planes(ctx)) {
+        out->surface_voxels = (unsigned long long)ctx->surf_count;
+    } else if (ctx->color_ready) {  // the owned part of the colour pass's list (arvx_color)
         if (int rc = surf_host(ctx)) return rc;
         size_t lo, hi;
         long long base;
@@ -1749,7 +1769,7 @@ int arvx_color(arvx_ctx *ctx, int mode) {
                                dim3(256), 0, ctx->stream, vp);
         ARVX_HIP(hipGetLastError());
         ARVX_SYNC(ctx);
-        total = ctx->h_totals[0];
+        total = host_total(ctx, 0);
         if (total < 0) return fail(ARVX_ERR_HIP, "the compaction left no count");
         if (total <= cap || attempt) break;
         cap = total + total / 8;  // (once more, with room for all)
@@ -2240,7 +2260,7 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
             ARVX_HIP(hipGetLastError());
         }
         ARVX_SYNC(ctx);
-        total = ctx->h_totals[1];
+        total = host_total(ctx, 1);
         if (total < 0) return fail(ARVX_ERR_HIP, "the compaction left no count");
         if (total <= cap || attempt) break;
         cap = total + total / 8;  // (once more, with room for all)
@@ -2276,6 +2296,10 @@ int arvx_closure_count(arvx_ctx *ctx, int64_t *count) {
     if (!ctx || !count) return fail(ARVX_ERR_INVALID, "null argument");
     if (!ctx->closure_ready) return fail(ARVX_ERR_STATE, "no closure result (call arvx_closure)");
     ARVX_HIP(hipSetDevice(ctx->device));
+    if (owns_all_planes(ctx)) {  // (the list itself stays on the device until somebody asks for it)
+        *count = (int64_t)ctx->clo_count;
+        return ARVX_OK;
+    }
     if (int rc = clo_host(ctx)) return rc;
     size_t lo, hi;
     long long base;
@@ -2369,7 +2393,7 @@ int arvx_mc_cells(arvx_ctx *ctx, int64_t *count) {
         const long long *d_total = nullptr;
         if (int rc = mc_cells_launch(ctx, cap, &d_total)) return rc;
         ARVX_SYNC(ctx);
-        total = ctx->h_totals[2];
+        total = host_total(ctx, 2);
         if (total < 0) return fail(ARVX_ERR_HIP, "the scan left no count");
         if (total <= cap || attempt) break;
         cap = total + total / 8;
@@ -2453,8 +2477,8 @@ int arvx_mc_mesh(arvx_ctx *ctx, int apply_unseen, int64_t *triangles) {
                            (float *)ctx->pool_mesh_verts.p, (unsigned *)ctx->pool_mesh_rgb.p);
         ARVX_HIP(hipGetLastError());
         ARVX_SYNC(ctx);
-        ncells = ctx->h_totals[2];
-        total = ctx->h_totals[3];
+        ncells = host_total(ctx, 2);
+        total = host_total(ctx, 3);
         if (ncells < 0 || total < 0) return fail(ARVX_ERR_HIP, "the scans left no count");
         if ((ncells <= ccap && total <= tcap) || attempt) break;
         // (with too few cells the triangle count is of the cells that fitted: five per cell at most)
