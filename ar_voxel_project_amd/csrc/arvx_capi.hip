@@ -220,21 +220,31 @@ static int compact_control(Ctx *ctx, size_t nchunks, uint8_t **base, unsigned lo
     return ARVX_OK;
 }
 
-// Exclusive scan of n counts src(i) in ONE launch (scan_lookback_kernel): offsets[i]; the sum goes to
-// device word *d_total_out and to ctx->h_totals[slot].  n_dev (may be null): entries at or behind
-// *n_dev count nothing.
-template <class Src>
-static int scan_counts(Ctx *ctx, const Src &src, long long n, const long long *n_dev, int *d_offsets,
-                       int slot, const long long **d_total_out) {
+// Exclusive scan of n counts in ONE launch (scan_lookback_kernel): offsets[i]; the sum goes to device
+// word *d_total_out and to ctx->h_totals[slot].  cells: the counts are the triangles of the
+// marching-cubes cells of that list (n: its capacity, *n_dev: its length), not an array.
+static int scan_counts(Ctx *ctx, const int *counts, const int4 *cells, long long n, const long long *n_dev,
+                       int *d_offsets, int slot, const long long **d_total_out) {
     const size_t nchunks = (size_t)((n + arvx::kScanChunk - 1) / arvx::kScanChunk);
     uint8_t *base = nullptr;
     unsigned long long *status = nullptr;
     if (int rc = compact_control(ctx, nchunks, &base, &status)) return rc;
     long long *d_total = (long long *)(base + 8 + 8 * slot);
     ctx->h_totals[slot] = -1;
-    hipLaunchKernelGGL(arvx::scan_lookback_kernel<Src>, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream,
-                       src, n, n_dev, d_offsets, (unsigned *)base, (unsigned)ctx->compact_tickets, status,
-                       ctx->compact_epoch, d_total, ctx->d_totals_host + slot, ctx->d_fault);
+    if (cells) {
+        const int8_t *table = nullptr;  // (the triangle counts of Bourke's table, on the device)
+        ARVX_HIP(hipGetSymbolAddress((void **)&table, HIP_SYMBOL(arvx::kMcTri)));
+        table += offsetof(arvx::McTriTable, n);
+        hipLaunchKernelGGL(arvx::scan_lookback_kernel<true>, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream,
+                           (const int *)cells, table, n, n_dev, d_offsets, (unsigned *)base,
+                           (unsigned)ctx->compact_tickets, status, ctx->compact_epoch, d_total,
+                           ctx->d_totals_host + slot, ctx->d_fault);
+    } else {
+        hipLaunchKernelGGL(arvx::scan_lookback_kernel<false>, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream,
+                           counts, (const int8_t *)nullptr, n, (const long long *)nullptr, d_offsets,
+                           (unsigned *)base, (unsigned)ctx->compact_tickets, status, ctx->compact_epoch,
+                           d_total, ctx->d_totals_host + slot, ctx->d_fault);
+    }
     ARVX_HIP(hipGetLastError());
     ctx->compact_tickets += nchunks;
     if (d_total_out) *d_total_out = d_total;
@@ -2345,8 +2355,7 @@ static int mc_cells_launch(Ctx *ctx, long long cap, const long long **d_total) {
     const size_t nzw = (size_t)mp.ZW * ctx->X * ctx->Y;  // z-packed occupancy words
     const long long ncol = (long long)(ctx->X + 1) * (ctx->Y + 1);
     if (int rc = ensure_scratch(ctx, nzw * sizeof(unsigned long long) +
-                                         (size_t)(ncol + 1) * sizeof(long long) +
-                                         (size_t)ncol * sizeof(int) + 64))
+                                         2 * (size_t)(ncol + 1) * sizeof(int) + 64))
         return rc;
     mp.zbits = (unsigned long long *)ctx->d_scratch;
     int *d_off = (int *)(mp.zbits + nzw);  // ncol column offsets
@@ -2363,8 +2372,8 @@ static int mc_cells_launch(Ctx *ctx, long long cap, const long long **d_total) {
     const unsigned nblk = (unsigned)((ncol + 255) / 256);
     hipLaunchKernelGGL(arvx::mc_count_kernel, dim3(nblk), dim3(256), 0, ctx->stream, mp, d_cnt);
     ARVX_HIP(hipGetLastError());
-    // the columns' offsets in the list: one launch (the three-launch block scan before it)
-    if (int rc = scan_counts(ctx, arvx::IntArraySrc{d_cnt}, ncol, nullptr, d_off, 2, d_total)) return rc;
+    // the columns' offsets in the list: one launch
+    if (int rc = scan_counts(ctx, d_cnt, nullptr, ncol, nullptr, d_off, 2, d_total)) return rc;
     ARVX_HIP(ctx->pool_mc_cells.reserve((size_t)cap * sizeof(int4)));
     ctx->d_mc_cells = (void *)ctx->pool_mc_cells.p;
     hipLaunchKernelGGL(arvx::mc_write_kernel, dim3(nblk), dim3(256), 0, ctx->stream, mp, d_off, cap,
@@ -2453,14 +2462,8 @@ int arvx_mc_mesh(arvx_ctx *ctx, int apply_unseen, int64_t *triangles) {
     if (tcap <= 0) tcap = 2 * ccap;
     long long ncells = 0, total = 0;
     for (int attempt = 0;; ++attempt) {
-        const long long *d_ncells = nullptr, *d_ntris = nullptr;
+        const long long *d_ncells = nullptr;
         if (int rc = mc_cells_launch(ctx, ccap, &d_ncells)) return rc;
-        // (the scratch buffer holds mc_cells_launch's arrays: the triangle offsets get their own)
-        ARVX_HIP(ctx->pool_mesh_off.reserve((size_t)(ccap + 1) * sizeof(int)));
-        int *d_off = (int *)ctx->pool_mesh_off.p;
-        if (int rc = scan_counts(ctx, arvx::TriCountSrc{(const int4 *)ctx->d_mc_cells}, ccap, d_ncells, d_off,
-                                 3, &d_ntris))
-            return rc;
         ARVX_HIP(ctx->pool_mesh_verts.reserve((size_t)tcap * 9 * sizeof(float)));
         ARVX_HIP(ctx->pool_mesh_rgb.reserve((size_t)tcap * 6 * sizeof(unsigned)));  // face records
         arvx::McMeshParams mp;
@@ -2472,6 +2475,12 @@ int arvx_mc_mesh(arvx_ctx *ctx, int apply_unseen, int64_t *triangles) {
         mp.col_rgba = ctx->d_surf_rgba;
         mp.clo = closure_list(ctx);
         mp.clo_rgba = (const float4 *)ctx->d_clo_rgba;
+        // (the scratch buffer holds mc_cells_launch's arrays: the triangle offsets get their own)
+        ARVX_HIP(ctx->pool_mesh_off.reserve((size_t)(ccap + 1) * sizeof(int)));
+        int *d_off = (int *)ctx->pool_mesh_off.p;
+        const long long *d_ntris = nullptr;
+        if (int rc = scan_counts(ctx, nullptr, (const int4 *)ctx->d_mc_cells, ccap, d_ncells, d_off, 3, &d_ntris))
+            return rc;
         hipLaunchKernelGGL(arvx::mc_mesh_kernel, dim3((unsigned)((ccap + 255) / 256)), dim3(256), 0,
                            ctx->stream, mp, (const int4 *)ctx->d_mc_cells, ccap, d_ncells, tcap, d_off,
                            (float *)ctx->pool_mesh_verts.p, (unsigned *)ctx->pool_mesh_rgb.p);

@@ -256,7 +256,10 @@ __global__ __launch_bounds__(256) void bit_compact_kernel(
     unsigned long long *__restrict__ status, uint32_t tag, long long cap, int *__restrict__ index,
     SparseWord *__restrict__ words, long long *__restrict__ total, long long *__restrict__ total_host,
     unsigned *__restrict__ fault) {
+    constexpr int kIt = kBitChunk / 256;  // words per thread: word it * 256 + thread (whole lines per wave)
+    static_assert(kIt * 4 == 64, "one lane per (iteration, wave) pair below");
     __shared__ int wtot[4];
+    __shared__ int s_itw[kIt * 4];  // set bits of iteration it in wave w, at it * 4 + w
     __shared__ int s_chunk;
     __shared__ long long s_excl;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -265,11 +268,10 @@ __global__ __launch_bounds__(256) void bit_compact_kernel(
     const int c = s_chunk;
     const int nchunks = (int)((nwords + kBitChunk - 1) / kBitChunk);
     const size_t base = (size_t)c * kBitChunk;
-    // the chunk's words: word it * 256 + thread (whole lines per wave), kept for the write phase
-    unsigned long long b[kBitChunk / 256];
+    unsigned long long b[kIt];
     int mine = 0;
 #pragma unroll
-    for (int it = 0; it < kBitChunk / 256; ++it) {
+    for (int it = 0; it < kIt; ++it) {
         const size_t w = base + (size_t)it * 256 + threadIdx.x;
         b[it] = (w < nwords) ? bits[w] : 0ull;
         mine += __popcll(b[it]);
@@ -279,7 +281,23 @@ __global__ __launch_bounds__(256) void bit_compact_kernel(
     if (lane == 0) wtot[wave] = mine;
     __syncthreads();
     const int agg = wtot[0] + wtot[1] + wtot[2] + wtot[3];  // (< 2^19)
-    __syncthreads();  // (wtot is used again below)
+    // Wave 0 looks back for the set bits before the chunk; meanwhile every wave ranks its own words:
+    // the words of one iteration are 256 consecutive ones, so a word's rank inside the chunk is the
+    // bits of the earlier iterations + those of the lower waves in its iteration + the wave's scan.
+    // (One scan per iteration across the workgroup -- two barriers each -- took most of the kernel.)
+    int before[kIt];  // set bits of the wave's lower lanes in iteration it
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int n = __popcll(b[it]);
+        int sc = n;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(sc, d);
+            if (lane >= d) sc += t;
+        }
+        before[it] = sc - n;
+        if (lane == 63) s_itw[it * 4 + wave] = sc;
+    }
     if (wave == 0) {
         const long long excl = lookback_exclusive(status, c, agg, tag, fault, lane);
         if (lane == 0) {
@@ -292,46 +310,65 @@ __global__ __launch_bounds__(256) void bit_compact_kernel(
         }
     }
     __syncthreads();
-    long long run = s_excl;
-#pragma unroll
-    for (int it = 0; it < kBitChunk / 256; ++it) {
-        const size_t w = base + (size_t)it * 256 + threadIdx.x;
-        unsigned long long bw = b[it];
-        const int n = __popcll(bw);
-        int sc = n;  // inclusive scan inside the wave
+    int pre = s_itw[lane];  // lane q = (iteration q >> 2, wave q & 3): exclusive scan in that order
+    {
+        const int n = pre;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(sc, d);
-            if (lane >= d) sc += t;
+            const int t = __shfl_up(pre, d);
+            if (lane >= d) pre += t;
         }
-        if (lane == 63) wtot[wave] = sc;
-        __syncthreads();
-        long long slot = run + sc - n;
-        for (int v = 0; v < wave; ++v) slot += wtot[v];
-        if (words && w < nwords) words[w] = SparseWord{bw, (int)slot, 0};
-        if (bw && index) {
-            const size_t row = w / g.XW;
-            const int x0 = (int)(w % g.XW) * 64;
-            const int first = (int)(row * g.X) + x0;
+        pre -= n;
+    }
+    const long long excl = s_excl;
+    // The list entries.  A lane that writes its word's entries one after the other takes as many
+    // rounds as the fullest word of the wave has bits, and every round is 64 stores to 64 different
+    // lines: words with more than kLightBits entries (faces of the model that run along x) are
+    // written by the whole wave instead -- lane j takes bit j, the entries leave as one run.
+    constexpr int kLightBits = 4;
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const size_t w = base + (size_t)it * 256 + threadIdx.x;
+        unsigned long long bw = b[it];
+        int slot = (int)(excl + __builtin_amdgcn_readlane(pre, it * 4 + wave) + before[it]);  // (< 2^31)
+        if (words && w < nwords) words[w] = SparseWord{bw, slot, 0};
+        if (!index) continue;
+        const size_t row = w / g.XW;
+        const int first = (int)(row * g.X) + (int)(w % g.XW) * 64;
+        const bool heavy = __popcll(bw) > kLightBits;
+        unsigned long long hm = __ballot(heavy);
+        while (hm) {
+            const int L = __ffsll((long long)hm) - 1;
+            hm &= hm - 1ull;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bw, L),
+                           hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(bw >> 32), L);
+            const int s0 = __builtin_amdgcn_readlane(slot, L), f0 = __builtin_amdgcn_readlane(first, L);
+            const bool set = ((lane < 32 ? lo >> lane : hi >> (lane - 32)) & 1u) != 0u;
+            const int at = s0 + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+            if (set && at < cap) index[at] = f0 + lane;
+        }
+        if (!heavy) {
             while (bw) {
                 if (slot < cap) index[slot] = first + (__ffsll((long long)bw) - 1);
                 ++slot;
                 bw &= bw - 1ull;
             }
         }
-        run += wtot[0] + wtot[1] + wtot[2] + wtot[3];
-        __syncthreads();
     }
 }
 
-// Exclusive scan of one small count per entry in ONE launch, the same way: a chunk of kScanChunk
-// entries per workgroup and ticket.  src(i): entry i's count (>= 0); entries at or behind *n_dev
-// (when given) count nothing.  offsets[i] (32 bits) for the entries in front of the end; the sum goes
-// to *total and *total_host.
+// The scans in ONE launch, the same way: a chunk of kScanChunk entries per workgroup and ticket.
 constexpr int kScanChunk = 4096;
-template <class Src>
+
+// Exclusive scan of one small count per entry (counts[i] >= 0): offsets[i] (32 bits); the sum goes to
+// *total and *total_host.  kLookup: the count of entry i is table[keys[4 i + 3] & 255] (the triangles of
+// marching-cubes cell i from its cube index: `keys` is the cell list, `table` 256 bytes, copied to
+// LDS first -- read from constant memory with a different index in every lane it was a second round
+// trip per entry), and entries at or behind *n_dev count nothing.
+template <bool kLookup>
 __global__ __launch_bounds__(256) void scan_lookback_kernel(
-    const Src src, long long n, const long long *__restrict__ n_dev, int *__restrict__ offsets,
+    const int *__restrict__ counts, const int8_t *__restrict__ table, long long n,
+    const long long *__restrict__ n_dev, int *__restrict__ offsets,
     unsigned *__restrict__ ticket_ctr, unsigned ticket_base,
     unsigned long long *__restrict__ status, uint32_t tag, long long *__restrict__ total,
     long long *__restrict__ total_host, unsigned *__restrict__ fault) {
@@ -342,15 +379,30 @@ __global__ __launch_bounds__(256) void scan_lookback_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_chunk = (int)(atomicAdd(ticket_ctr, 1u) - ticket_base);
     __syncthreads();
+    __shared__ int8_t s_table[256];
+    if (kLookup) s_table[threadIdx.x] = table[threadIdx.x];
     const int c = s_chunk;
     const int nchunks = (int)((n + kScanChunk - 1) / kScanChunk);
-    const long long n_eff = n_dev ? (*n_dev < n ? *n_dev : n) : n;
+    const long long n_eff = (kLookup && n_dev) ? (*n_dev < n ? *n_dev : n) : n;
     // the chunk's counts: read with neighbouring threads at neighbouring entries (whole lines),
     // handed to the threads that scan 16 consecutive ones each through LDS
+    if (kLookup) {
+        int key[kScanChunk / 256];
 #pragma unroll
-    for (int it = 0; it < kScanChunk / 256; ++it) {
-        const long long i = (long long)c * kScanChunk + it * 256 + threadIdx.x;
-        s_val[it * 256 + threadIdx.x] = (i < n_eff) ? src(i) : 0;
+        for (int it = 0; it < kScanChunk / 256; ++it) {
+            const long long i = (long long)c * kScanChunk + it * 256 + threadIdx.x;
+            key[it] = (i < n_eff) ? (counts[4 * i + 3] & 255) : -1;
+        }
+        __syncthreads();  // (the table)
+#pragma unroll
+        for (int it = 0; it < kScanChunk / 256; ++it)
+            s_val[it * 256 + threadIdx.x] = key[it] >= 0 ? (int)s_table[key[it]] : 0;
+    } else {
+#pragma unroll
+        for (int it = 0; it < kScanChunk / 256; ++it) {
+            const long long i = (long long)c * kScanChunk + it * 256 + threadIdx.x;
+            s_val[it * 256 + threadIdx.x] = (i < n) ? counts[i] : 0;
+        }
     }
     __syncthreads();
     int v[kScanChunk / 256];
@@ -376,7 +428,7 @@ __global__ __launch_bounds__(256) void scan_lookback_kernel(
     __syncthreads();
     pre += s_excl;
     // (the sums fit 31 bits: the status words carry them) back through LDS, so that the offsets
-    // leave as whole lines too; entries behind the list's end are not written
+    // leave as whole lines too
 #pragma unroll
     for (int k = 0; k < kScanChunk / 256; ++k) {
         s_val[threadIdx.x * (kScanChunk / 256) + k] = (int)pre;

@@ -85,39 +85,50 @@ __device__ inline int cl_gather3(const ClosureParams &p, size_t i, float4 &sum) 
     const size_t t = i / X;
     const int y = (int)(t % Y), z = (int)(t / Y);
     const int xw = x >> 6, xb = x & 63;
-    // 3-bit windows of the rows (y + b, z + c): bit a + 1 = voxel x + a
-    unsigned occ3[9], uns3[9];
-    SparseWord colw[9];  // the colour list's word of the row
-    auto window = [&](const unsigned long long *plane, size_t at, bool row_ok) -> unsigned {
-        if (!plane || !row_ok) return 0u;
+    // 3-bit windows of the nine rows (y + b, z + c), row r = 3 (b + 1) + (c + 1) at bits 3 r .. 3 r + 2,
+    // bit a = voxel x + a - 1: occupancy, UNSEEN paint, membership in the colour list (the bits of
+    // the voxel's own word; a neighbour in the next / previous word is looked up on its own below).
+    // Packed, and with ONE rank per row (of the window's first voxel), so that the kernel stays
+    // within 64 registers: eight waves per SIMD hide what is a chain of dependent gathers.
+    unsigned occ = 0, uns = 0, col = 0;
+    int kbase[9];
+    auto window = [&](const unsigned long long *plane, size_t at) -> unsigned {
         const unsigned long long w = plane[at];
         unsigned v = xb ? (unsigned)((w >> (xb - 1)) & 7ull) : (unsigned)((w << 1) & 7ull);
         if (xb == 0 && xw > 0) v |= (unsigned)(plane[at - 1] >> 63);
         if (xb == 63 && xw + 1 < XW) v |= (unsigned)(plane[at + 1] & 1ull) << 2;
         return v;
     };
+    const int lo = xb ? xb - 1 : 0;  // first bit of the window inside the word
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
-        const int yn = y + r / 3 - 1, zn = z + r % 3 - 1;  // r = 3 * (b + 1) + (c + 1)
-        const bool ok = yn >= 0 && yn < Y && zn >= 0 && zn < Z;
-        const size_t at = ok ? ((size_t)zn * Y + yn) * XW + xw : 0;
-        occ3[r] = window(p.occ, at, ok);
-        uns3[r] = window(p.unseen, at, ok);
-        colw[r] = (p.col.w && ok) ? sparse_word(p.col, at) : SparseWord{0ull, 0, 0};
+        const int yn = y + r / 3 - 1, zn = z + r % 3 - 1;
+        kbase[r] = 0;
+        if (yn < 0 || yn >= Y || zn < 0 || zn >= Z) continue;
+        const size_t at = ((size_t)zn * Y + yn) * XW + xw;
+        occ |= window(p.occ, at) << (3 * r);
+        if (p.unseen) uns |= window(p.unseen, at) << (3 * r);
+        if (p.col.w) {
+            const SparseWord e = sparse_word(p.col, at);
+            col |= (xb ? (unsigned)((e.bits >> (xb - 1)) & 7ull) : (unsigned)((e.bits << 1) & 7ull)) << (3 * r);
+            kbase[r] = e.rank + __popcll(e.bits & ((1ull << lo) - 1ull));
+        }
     }
     int count = 0;
     sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {  // x offset a - 1
         const int xn = x + a - 1;
+        const bool other_word = (xn >> 6) != xw;  // (xb = 0, a = 0 or xb = 63, a = 2)
         float4 rgb[9];  // w = has-sample flag; (0, 0, 0, 0): not in the list
 #pragma unroll
         for (int r = 0; r < 9; ++r) {  // the nine lookups of this x offset, all in flight
             int k = -1;
-            if (p.col.w && ((occ3[r] >> a) & 1u)) {
-                if (xn >> 6 == xw) {
-                    k = sparse_rank(colw[r], xn & 63);
-                } else if (xn >= 0 && xn < X) {  // the next / previous word of the row
+            if ((occ >> (3 * r + a)) & 1u) {
+                if (!other_word) {
+                    const unsigned w3 = (col >> (3 * r)) & 7u;
+                    if ((w3 >> a) & 1u) k = kbase[r] + __popc(w3 & ((1u << a) - 1u));
+                } else if (p.col.w && xn >= 0 && xn < X) {
                     const int yn = y + r / 3 - 1, zn = z + r % 3 - 1;
                     k = sparse_find(p.col, XW, xn, (size_t)zn * Y + yn);
                 }
@@ -126,11 +137,11 @@ __device__ inline int cl_gather3(const ClosureParams &p, size_t i, float4 &sum) 
         }
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            if (!((occ3[r] >> a) & 1u)) continue;
+            if (!((occ >> (3 * r + a)) & 1u)) continue;
             ++count;
             float4 v = make_float4(50.f, 168.f, 141.f, 1.f);
             if (rgb[r].w != 0.f) v = make_float4(rgb[r].x, rgb[r].y, rgb[r].z, 1.f);
-            if ((uns3[r] >> a) & 1u) v = make_float4(204.f, 0.f, 0.f, 1.f);
+            if ((uns >> (3 * r + a)) & 1u) v = make_float4(204.f, 0.f, 0.f, 1.f);
             sum.x = sum.x + v.x;
             sum.y = sum.y + v.y;
             sum.z = sum.z + v.z;

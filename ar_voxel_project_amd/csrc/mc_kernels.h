@@ -20,9 +20,30 @@
 // in the reference's emission order without a sort.
 #pragma once
 
+#include "arvx/mc_tables.hpp"
 #include "arvx_device.h"
 
 namespace arvx {
+
+// Bourke's triangle table as the kernels read it
+struct McTriTable {
+    alignas(16) int8_t e[256][16];  // edge numbers, three per triangle, -1 terminated
+    int8_t n[256];      // triangles per cube index
+};
+
+constexpr McTriTable make_mc_tri_table() {
+    McTriTable t{};
+    for (int i = 0; i < 256; ++i) {
+        int k = 0;
+        for (const char *s = mc::kTriangles[i]; *s; ++s) t.e[i][k++] = (int8_t)mc::hex_digit(*s);
+        t.n[i] = (int8_t)(k / 3);
+        for (; k < 16; ++k) t.e[i][k] = -1;
+    }
+    return t;
+}
+
+__constant__ McTriTable kMcTri = make_mc_tri_table();
+
 
 struct McParams {
     int X, Y, Z;
@@ -112,8 +133,10 @@ __device__ __forceinline__ bool mc_column_of_thread(const McParams &p, int &cx, 
 // walks the column and calls emit(cz, cubeIndex) for every cell that triangulates,
 // cz ascending.  Corner order of the reference (src/MarchingCubes.h:537-552):
 // (cx+1,cy) (cx,cy) (cx,cy+1) (cx+1,cy+1) on plane cz, then the same on plane cz+1.
-template <class Emit>
-__device__ __forceinline__ void mc_walk(const McParams &p, int cx, int cy, Emit emit) {
+// word by word: visit(w, act, lo, hi) -- bit b of act = cell p.cz0 + 64 w + b triangulates; lo[c] /
+// hi[c]: corner column c on the cell's lower / upper plane
+template <class Visit>
+__device__ __forceinline__ void mc_walk_words(const McParams &p, int cx, int cy, Visit visit) {
     const bool x0 = cx >= 0, x1 = cx + 1 < p.X, y0 = cy >= 0, y1 = cy + 1 < p.Y;
     const bool in[4] = {x1 && y0, x0 && y0, x0 && y1, x1 && y1};
     const int dx[4] = {1, 0, 0, 1}, dy[4] = {0, 0, 1, 1};
@@ -140,6 +163,15 @@ __device__ __forceinline__ void mc_walk(const McParams &p, int cx, int cy, Emit 
         unsigned long long act = any & ~all;
         const int left = ncell - w * 64;
         if (left < 64) act &= (1ull << left) - 1ull;
+        visit(w, act, lo, hi);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
+    }
+}
+template <class Emit>
+__device__ __forceinline__ void mc_walk(const McParams &p, int cx, int cy, Emit emit) {
+    mc_walk_words(p, cx, cy, [&](int w, unsigned long long act, const unsigned long long *lo,
+                                 const unsigned long long *hi) {
         while (act) {
             const int b = __ffsll((long long)act) - 1;
             act &= act - 1ull;
@@ -151,25 +183,22 @@ __device__ __forceinline__ void mc_walk(const McParams &p, int cx, int cy, Emit 
             }
             emit(p.cz0 + w * 64 + b, idx);
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
-    }
+    });
 }
 
+// the cells of a column that triangulate: the walk of mc_walk without visiting the cells
 __global__ __launch_bounds__(256) void mc_count_kernel(const McParams p, int *__restrict__ counts) {
     int cx, cy;
     if (!mc_column_of_thread(p, cx, cy)) return;
     int n = 0;
-    mc_walk(p, cx, cy, [&](int, unsigned) { ++n; });
+    mc_walk_words(p, cx, cy, [&](int, unsigned long long act, const unsigned long long *, const unsigned long long *) {
+        n += __popcll(act);
+    });
     counts[(size_t)(cx + 1) * (p.Y + 1) + (cy + 1)] = n;
 }
 
-// Exclusive scan of the column counts in three launches: every workgroup sums its
-// kScanBlock entries; one workgroup scans those sums (block_off[nb] = total); every
-// workgroup scans its own entries on top of its block offset.
-constexpr int kScanPerThread = 16;
-constexpr int kScanBlock = 256 * kScanPerThread;
-
+// (The columns' counts are scanned by scan2_lookback_kernel, bitplane_kernels.h; what follows serves
+// the occupancy compression of exchange_kernels.h.)
 // inclusive scan of one value per thread across the 256-thread workgroup;
 // returns the exclusive prefix, *total gets the workgroup sum
 __device__ __forceinline__ long long wg_exclusive_scan(long long mine, long long *wtot,
@@ -187,18 +216,6 @@ __device__ __forceinline__ long long wg_exclusive_scan(long long mine, long long
     for (int w = 0; w < wave; ++w) pre += wtot[w];
     *total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
     return pre;
-}
-
-__global__ __launch_bounds__(256) void mc_block_sum_kernel(const int *__restrict__ counts, int n,
-                                                           int *__restrict__ block_sum) {
-    __shared__ long long wtot[4];
-    const int i0 = blockIdx.x * kScanBlock + threadIdx.x * kScanPerThread;
-    long long mine = 0;
-#pragma unroll
-    for (int k = 0; k < kScanPerThread; ++k) mine += (i0 + k < n) ? counts[i0 + k] : 0;
-    long long total;
-    (void)wg_exclusive_scan(mine, wtot, &total);
-    if (threadIdx.x == 0) block_sum[blockIdx.x] = (int)total;  // <= kScanBlock * (Z+1)
 }
 
 // scans nb <= 2^31 block sums with ONE workgroup; block_off[nb] = total
@@ -219,27 +236,6 @@ __global__ __launch_bounds__(256) void mc_scan_blocks_kernel(const int *__restri
     if (threadIdx.x == 0) block_off[nb] = carry;
 }
 
-__global__ __launch_bounds__(256) void mc_block_scan_kernel(const int *__restrict__ counts, int n,
-                                                            const long long *__restrict__ block_off,
-                                                            long long *__restrict__ offsets) {
-    __shared__ long long wtot[4];
-    const int i0 = blockIdx.x * kScanBlock + threadIdx.x * kScanPerThread;
-    int v[kScanPerThread];
-    long long mine = 0;
-#pragma unroll
-    for (int k = 0; k < kScanPerThread; ++k) {
-        v[k] = (i0 + k < n) ? counts[i0 + k] : 0;
-        mine += v[k];
-    }
-    long long total;
-    long long pre = block_off[blockIdx.x] + wg_exclusive_scan(mine, wtot, &total);
-#pragma unroll
-    for (int k = 0; k < kScanPerThread; ++k) {
-        if (i0 + k < n) offsets[i0 + k] = pre;
-        pre += v[k];
-    }
-}
-
 // cap: room in `cells` (the list's length is not known when the buffers are sized: the caller
 // reads the true total at its synchronisation and repeats the launch if it was larger)
 __global__ __launch_bounds__(256) void mc_write_kernel(const McParams p,
@@ -253,11 +249,5 @@ __global__ __launch_bounds__(256) void mc_write_kernel(const McParams p,
         ++at;
     });
 }
-
-// a plain array of counts as the source of scan_lookback_kernel (bitplane_kernels.h)
-struct IntArraySrc {
-    const int *p;
-    __device__ __forceinline__ int operator()(long long i) const { return p[i]; }
-};
 
 }  // namespace arvx

@@ -21,27 +21,10 @@
 #include "arvx/mc_tables.hpp"
 #include "arvx_device.h"
 #include "bitplane_kernels.h"
+#include "mc_kernels.h"  // kMcTri
 #include "state_kernels.h"
 
 namespace arvx {
-
-struct McTriTable {
-    alignas(16) int8_t e[256][16];  // edge numbers, three per triangle, -1 terminated
-    int8_t n[256];      // triangles per cube index
-};
-
-constexpr McTriTable make_mc_tri_table() {
-    McTriTable t{};
-    for (int i = 0; i < 256; ++i) {
-        int k = 0;
-        for (const char *s = mc::kTriangles[i]; *s; ++s) t.e[i][k++] = (int8_t)mc::hex_digit(*s);
-        t.n[i] = (int8_t)(k / 3);
-        for (; k < 16; ++k) t.e[i][k] = -1;
-    }
-    return t;
-}
-
-__constant__ McTriTable kMcTri = make_mc_tri_table();
 
 struct McMeshParams {
     CarveParams g;         // the state records (whole grid, or slab + halo)
@@ -70,17 +53,6 @@ __device__ inline float3 mc_voxel_rgb(const McMeshParams &p, int x, int y, int z
     }
     return make_float3(50.f, 168.f, 141.f);
 }
-
-__global__ __launch_bounds__(256) void mc_tri_count_kernel(const int4 *__restrict__ cells,
-                                                           long long n, int *__restrict__ counts) {
-    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (c < n) counts[c] = kMcTri.n[cells[c].w & 255];
-}
-// the triangles of cell i, as the source of scan_lookback_kernel (bitplane_kernels.h)
-struct TriCountSrc {
-    const int4 *cells;
-    __device__ __forceinline__ int operator()(long long i) const { return kMcTri.n[cells[i].w & 255]; }
-};
 
 __device__ __forceinline__ unsigned mc_mean3(float a, float b, float c) {
     const float s = (a + b) + c;
