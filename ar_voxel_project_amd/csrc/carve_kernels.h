@@ -1,30 +1,32 @@
 // carve_kernels.h -- dense silhouette carve for gfx950 (MI355X).
 //
 // Replaces the voxel loop of the reference's carve(): src/VoxelCarving.cpp:38-55
-// (one view) and :60-72 (all views).  One launch covers all requested views:
-// the state plane is read once, every view is applied in registers, and the
-// plane is written once.
+// (one view) and :60-72 (all views).  One arvx_carve call applies all requested views; a voxel's
+// state (2 bits, records of 16 x 8 x 8 voxels: arvx_device.h) is touched at most once.
 //
-// Work decomposition
-//   workgroup (256 threads) = tile of 64 x 8 x 8 voxels (x fastest in memory)
-//   wave                    = sub-tile of 16 x 8 x 8 voxels
-//   lane                    = 4 consecutive x (one dword of state) at one y,
-//                             for 4 consecutive z: 16 voxels in 4 registers
-// so the four waves of a workgroup together touch whole 64-byte runs.
-//
-// Per sub-tile, before any voxel is projected, lane i classifies view i: the
-// eight corners of the sub-tile's world box are projected, a rigorous error
-// margin is added, and the resulting pixel rectangle is looked up in the view's
-// summed-area table of foreground pixels (a pre-pass does the same for coarse
-// 64x32x32 tiles first, so most sub-tiles inherit their answer):
-//   rectangle outside the image            -> no voxel is seen by this view
-//   inside, no foreground pixel            -> every voxel is carved: sub-tile done
+// Three launches, each settling what it can from RECTANGLES and handing the rest on
+// (classify_box: the eight corners of a voxel box are projected, a rigorous error margin is added,
+// and the pixel rectangle is looked up in the view's summed-area table of foreground pixels):
+//   rectangle outside the image            -> no voxel of the box is seen by this view
+//   inside, no foreground pixel            -> every voxel is carved: the box is finished
+//                                             (carved implies seen, src/VoxelCarving.cpp:50-54)
 //   inside, only foreground pixels         -> every voxel is seen, none carved
-//   anything else                          -> evaluate the 1024 voxels exactly
-// A wave ballot over the lanes turns this into three 64-bit view masks; the
-// "carved" mask ends the sub-tile at once (carved implies seen, reference
-// src/VoxelCarving.cpp:50-54), the "mixed" mask drives the exact per-voxel
-// loop, which itself stops as soon as a ballot finds all 1024 voxels carved.
+//   anything else                          -> "mixed": look closer
+//   carve_coarse_kernel          coarse tiles of 64 x 32 x 32 voxels, a lane per (tile, view) pair; a
+//                                fresh model's decided tiles are not even written (their code is
+//                                their state), the undecided ones are listed
+//   carve_classify_dense_kernel  the 64 sub-tiles (16 x 8 x 8) of a listed coarse tile against its
+//                                mixed views, lane = (sub-tile, view slot); settled records are
+//                                written, mixed sub-tiles queued as items in eight weight classes
+//                                (carve_classify_kernel: a wave per sub-tile, for small grids / stats)
+//   carve_exact_blocks_kernel    persistent waves take the items; per item block-level rectangle
+//                                tests (4 x 4 x 4 voxels) first, then the blocks still mixed are
+//                                projected voxel by voxel, one voxel of each block per lane, in the
+//                                reference's own arithmetic (arvx_device.h: row sums, division,
+//                                rounding), until a ballot finds all 1024 voxels carved and seen
+// carve_fused_kernel is the brute-force form (every voxel in every view: ARVX_CARVE_NO_CULL, > 256
+// views) and the yardstick of tests/test_carve_gpu.py; carve_coarse_fill_kernel / carve_fill_kernel
+// write whole coarse tiles for models that are not fresh and for the stages that need every record.
 #pragma once
 
 #include "arvx_device.h"
