@@ -587,10 +587,10 @@ static int views_common(Ctx *ctx, int V, const float *M, const float *campos, in
 static int views_preprocess(Ctx *ctx, const uint8_t *d_masks, int C) {
     const int npix = ctx->W * ctx->H;
     ARVX_HIP(hipGetLastError());  // anything stale would be blamed on the launches below
-    // one-channel masks with rows of whole 64-pixel tiles: ONE launch, a workgroup per strip of
-    // 64 rows (views_kernels.h, views_strip_kernel); every other format: the three launches below
+    // one- or three-channel masks with rows of whole 64-pixel tiles: ONE launch, a workgroup per strip
+    // of 64 rows (views_kernels.h, views_strip_kernel); every other format: the three launches below
     static const bool three_launches = experiment_flag("ARVX_VIEWS_THREE_LAUNCHES");
-    if (C == 1 && ctx->W % 64 == 0 && ctx->W / 64 + 1 <= arvx::kStripMaxWaves && ctx->H <= 4096 &&
+    if ((C == 1 || C == 3) && ctx->W % 64 == 0 && ctx->W / 64 + 1 <= arvx::kStripMaxWaves && ctx->H <= 4096 &&
         ((uintptr_t)d_masks & 15u) == 0 && !three_launches) {
         const int TIs = (ctx->H + 63) / 64;
         // ticket counters (one per view, never reset) + the strips' published column counts;
@@ -606,9 +606,14 @@ static int views_preprocess(Ctx *ctx, const uint8_t *d_masks, int C) {
         }
         unsigned long long *ctr = (unsigned long long *)ctx->pool_vstrip.p;
         unsigned long long *gran = (unsigned long long *)((uint8_t *)ctx->pool_vstrip.p + off_gran);
-        hipLaunchKernelGGL(arvx::views_strip_kernel, dim3(TIs, ctx->V), dim3(64 * (ctx->W / 64 + 1)),
-                           0, ctx->stream, d_masks, ctx->W, ctx->H, TIs, ctx->d_bg, ctx->bgWords,
-                           ctx->d_sat, ctx->satStride, ctx->satW, ctr, gran, ctx->d_fault);
+        if (C == 1)
+            hipLaunchKernelGGL(arvx::views_strip_kernel<1>, dim3(TIs, ctx->V), dim3(64 * (ctx->W / 64 + 1)),
+                               0, ctx->stream, d_masks, ctx->W, ctx->H, TIs, ctx->d_bg, ctx->bgWords,
+                               ctx->d_sat, ctx->satStride, ctx->satW, ctr, gran, ctx->d_fault);
+        else
+            hipLaunchKernelGGL(arvx::views_strip_kernel<3>, dim3(TIs, ctx->V), dim3(64 * (ctx->W / 64 + 1)),
+                               0, ctx->stream, d_masks, ctx->W, ctx->H, TIs, ctx->d_bg, ctx->bgWords,
+                               ctx->d_sat, ctx->satStride, ctx->satW, ctr, gran, ctx->d_fault);
         ARVX_HIP(hipGetLastError());
         ctx->views_ready = true;
         ctx->cameras_ready = true;

@@ -308,9 +308,34 @@ __device__ __forceinline__ uint32_t nonzero_bytes(const uint32_t x) {
     return ((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) >> 7) & 0x01010101u;
 }
 
+// 16 three-channel pixels (48 bytes) -> 16 flags, bit i = some byte of pixel i is not zero (the
+// reference's masks are three-channel images: background = all channel bytes zero,
+// src/VoxelCarving.cpp:49-50)
+__device__ __forceinline__ uint32_t nonzero16x3(const uint4 a, const uint4 b, const uint4 c) {
+    const uint32_t d[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+    // bit i of m[h] = byte 24 h + i of the run is not zero
+    uint32_t m[2] = {0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const uint32_t t = (((d[k] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d[k]) & 0x80808080u;
+        m[k / 6] |= bytes_to_nibble(t >> 7) << (4 * (k % 6));
+    }
+    uint32_t f = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // eight pixels per 24 byte flags: OR the triples, keep every third bit
+        uint32_t x = (m[h] | (m[h] >> 1) | (m[h] >> 2)) & 0x249249u;
+        x = (x | (x >> 2)) & 0x0C30C3u;
+        x = (x | (x >> 4)) & 0x00F00Fu;
+        x = (x | (x >> 8)) & 0xFFu;
+        f |= x << (8 * h);
+    }
+    return f;
+}
+
 // ctr: one 64-bit ticket counter per view (zero when allocated, never reset); gran: the published
 // column counts, [view][strip][W / 2] granules; err: set when a wait gives up (never seen; the
-// host checks it at its next synchronisation)
+// host checks it at its next synchronisation).  C: channel bytes per pixel, 1 or 3.
+template <int C>
 __global__ __launch_bounds__(64 * kStripMaxWaves) void views_strip_kernel(
     const uint8_t *__restrict__ masks, int W, int H, int TI, uint32_t *__restrict__ bg, int bgWords,
     uint16_t *__restrict__ sat, int satStride, int ld, unsigned long long *__restrict__ ctr,
@@ -330,7 +355,7 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void views_strip_kernel(
     const int J = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int TP = W >> 6;  // tile columns that hold pixels; wave TP writes table column W (+ padding)
     const int G = W >> 1;   // granules per strip
-    const uint8_t *img = masks + (size_t)v * W * H;
+    const uint8_t *img = masks + (size_t)v * W * H * C;
     const int y0 = I * 64;
     const int nrows = min(64, H - y0);
     const int rr = lane >> 2, q = lane & 3;
@@ -339,16 +364,21 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void views_strip_kernel(
     uint32_t mine_lo = 0, mine_hi = 0;
     uint32_t acc[4] = {0u, 0u, 0u, 0u};  // columns 64 J + 16 q + 4 d + b: byte b of acc[d]
     if (J < TP) {
-        uint4 w[4];
+        uint4 w[4][C];  // rows 4 rr + k, pixels 64 J + 16 q .. + 15: 16 C bytes
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int y = y0 + 4 * rr + k;
-            w[k] = make_uint4(0u, 0u, 0u, 0u);
-            if (y < H) w[k] = *reinterpret_cast<const uint4 *>(img + (size_t)y * W + 64 * J + 16 * q);
+            const uint4 *src = reinterpret_cast<const uint4 *>(img + ((size_t)y * W + 64 * J + 16 * q) * C);
+#pragma unroll
+            for (int c = 0; c < C; ++c) w[k][c] = (y < H) ? src[c] : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t f = nonzero16(w[k]);
+            uint32_t f;
+            if constexpr (C == 1)
+                f = nonzero16(w[k][0]);
+            else
+                f = nonzero16x3(w[k][0], w[k][1], w[k][2]);
             uint32_t lo = q < 2 ? f << (16 * q) : 0u, hi = q >= 2 ? f << (16 * (q - 2)) : 0u;
             lo |= __shfl_xor(lo, 1);
             hi |= __shfl_xor(hi, 1);
@@ -358,10 +388,15 @@ __global__ __launch_bounds__(64 * kStripMaxWaves) void views_strip_kernel(
                 mine_lo = lo;
                 mine_hi = hi;
             }
-            acc[0] += nonzero_bytes(w[k].x);
-            acc[1] += nonzero_bytes(w[k].y);
-            acc[2] += nonzero_bytes(w[k].z);
-            acc[3] += nonzero_bytes(w[k].w);
+            if constexpr (C == 1) {
+                acc[0] += nonzero_bytes(w[k][0].x);
+                acc[1] += nonzero_bytes(w[k][0].y);
+                acc[2] += nonzero_bytes(w[k][0].z);
+                acc[3] += nonzero_bytes(w[k][0].w);
+            } else {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) acc[d] += nibble_to_bytes((f >> (4 * d)) & 15u);
+            }
         }
         // background bits of the row (reference src/VoxelCarving.cpp:49-50: all bytes zero)
         s_bits[lane * TP + J] = (lane < nrows)
