@@ -146,8 +146,24 @@ __global__ __launch_bounds__(256) void color_samples_kernel(const VoteParams p,
     out[t] = o;
 }
 
+// One thread per surface voxel, all views.  What a (voxel, view) pair costs is vector instructions
+// (36 exact projections per voxel), so the loop is kept lean:
+//  * the views' matrices are widened to fp64 ONCE per workgroup, into LDS (twelve conversions per
+//    view and lane otherwise; up to kVoteLdsViews views, more take the plain loop);
+//  * both quotients share one reciprocal where divide2_shared_rcp is the IEEE quotient (arvx_device.h:
+//    2^-60 <= |a2| <= 2^60, |a0|, |a1| <= 2^60 in every lane of the wave), `/` otherwise;
+//  * the square root of a sample's depth is taken only when its fp64 sum of squares is below the
+//    smallest so far: depth = (float)sqrt(sum) is monotone in the sum, so a sample with a sum that
+//    is not smaller cannot be strictly closer (and the first view wins ties, .cpp:33-40).
+constexpr int kVoteLdsViews = 256;
 template <bool LEFT>
 __global__ __launch_bounds__(256) void color_vote_kernel(const VoteParams p) {
+    __shared__ double s_M[kVoteLdsViews * 12];
+    const bool lds = p.V <= kVoteLdsViews;  // (uniform)
+    if (lds) {
+        for (int k = threadIdx.x; k < p.V * 12; k += 256) s_M[k] = (double)p.M[k];
+        __syncthreads();
+    }
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= p.n || (p.n_dev && t >= *p.n_dev)) return;
     const int i = p.index[t];
@@ -157,29 +173,53 @@ __global__ __launch_bounds__(256) void color_vote_kernel(const VoteParams p) {
     // Model::toWord, reference src/Model.h:134-140
     const float w0 = (float)y * p.s, w1 = (float)x * p.s, w2 = (float)(-z) * p.s;
     const double d0w = (double)w0, d1w = (double)w1, d2w = (double)w2;
+    const float wlim = (float)p.W - 0.5f, hlim = (float)p.H - 0.5f;
     unsigned sr = 0, sg = 0, sb = 0, n = 0;
     float best = 0.f, br = 0.f, bgc = 0.f, bb = 0.f;
+    double best_sum = 0.0;
     for (int v = 0; v < p.V; ++v) {
-        const float *__restrict__ Mv = p.M + 12 * v;
         float a[3];
+        if (lds) {
+            const double *Md = s_M + 12 * v;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const double p0 = (double)Mv[4 * r] * d0w;
-            const double p1 = (double)Mv[4 * r + 1] * d1w;
-            const double p2 = (double)Mv[4 * r + 2] * d2w;
-            const double p3 = (double)Mv[4 * r + 3];
-            a[r] = row_sum<LEFT>(p0, p1, p2, p3);
+            for (int r = 0; r < 3; ++r)
+                a[r] = row_sum<LEFT>(Md[4 * r] * d0w, Md[4 * r + 1] * d1w, Md[4 * r + 2] * d2w, Md[4 * r + 3]);
+        } else {
+            const float *__restrict__ Mv = p.M + 12 * v;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                a[r] = row_sum<LEFT>((double)Mv[4 * r] * d0w, (double)Mv[4 * r + 1] * d1w,
+                                     (double)Mv[4 * r + 2] * d2w, (double)Mv[4 * r + 3]);
+        }
+        float qu, qv;
+        const bool tame = fabsf(a[2]) >= 0x1p-60f && fabsf(a[2]) <= 0x1p60f && fabsf(a[0]) <= 0x1p60f &&
+                          fabsf(a[1]) <= 0x1p60f;
+        if (__all(tame)) {
+            divide2_shared_rcp(a[0], a[1], a[2], qu, qv);
+        } else {
+            qu = a[0] / a[2];
+            qv = a[1] / a[2];
         }
         int pix;
-        if (!pixel_of(a[0], a[1], a[2], p.W, p.H, pix)) continue;  // ColorReconstruction.h:54-57
+        if (!pixel_from_quotients(qu, qv, p.W, wlim, hlim, pix)) continue;  // ColorReconstruction.h:54-57
         const uint8_t *q = p.images + ((size_t)v * p.W * p.H + pix) * 3;
         const unsigned b = q[0], g = q[1], r = q[2];  // Vec3b is BGR; colour = (R,G,B,1), :59
-        const float depth = sample_depth(p.campos + 3 * v, w0, w1, w2);
-        if (n == 0 || depth < best) {  // strict <: the first view wins ties, .cpp:33-40
-            best = depth;
-            br = (float)r;
-            bgc = (float)g;
-            bb = (float)b;
+        // (float)cv::norm(cameras[v] - word_coord): sample_depth, with the root taken when it matters
+        const float *__restrict__ c = p.campos + 3 * v;
+        const double e0 = (double)(c[0] - w0), e1 = (double)(c[1] - w1), e2 = (double)(c[2] - w2);
+        const double e3 = (double)(1.f - 1.f);
+        const double sum = ((e0 * e0 + e1 * e1) + e2 * e2) + e3 * e3;
+        if (n == 0 || sum < best_sum) {
+            const float depth = (float)sqrt(sum);
+            if (n == 0 || depth < best) {  // strict <: the first view wins ties, .cpp:33-40
+                best = depth;
+                br = (float)r;
+                bgc = (float)g;
+                bb = (float)b;
+            }
+            // (a smaller sum with the same rounded depth: later samples are compared with the
+            // smaller sum, whose depth is the same or smaller -- still exact)
+            best_sum = sum;
         }
         sr += r;
         sg += g;
