@@ -201,11 +201,15 @@ __device__ __forceinline__ long long lookback_exclusive(unsigned long long *__re
     long long excl = 0;
     if (c > 0) {
         if (lane == 0) granule_store(status + c, (uint32_t)agg, tag);
-        // Eight windows of 64 chunks are requested together (one round trip for 512 chunks: the
-        // workgroups of a launch start together, so by the time one looks back nearly every chunk
-        // before it has published its aggregate -- walking window by window, every 64 chunks cost a
-        // round trip of their own) and consumed nearest first, until one holds an inclusive prefix.
-        constexpr int K = 8;
+        // K windows of 64 chunks are requested together and consumed nearest first, until one holds
+        // an inclusive prefix.  (K = 8 -- one round trip for 512 chunks, the workgroups of a launch
+        // start together -- against K = 1, the classic walk: 36.5 / 24.8 us against 34.8 / 22.0 for the
+        // compaction and the 250-chunk scan of EXPERIMENTS.md round 4, no difference at 1024^3: the
+        // polls all go to the same few lines, fewer of them is at least not worse.)
+#ifndef ARVX_LOOKBACK_WINDOWS
+#define ARVX_LOOKBACK_WINDOWS 1
+#endif
+        constexpr int K = ARVX_LOOKBACK_WINDOWS;
         int look = c - 1;  // lane l of window j looks at chunk look - 64 j - l
         bool done = false;
         for (unsigned spin = 0; !done;) {
