@@ -1341,8 +1341,11 @@ static int launch_carve_stream(Ctx *ctx, arvx::CarveParams p, int ncu) {
 
 // `fresh`: the model is all-occupied/unseen and exists only as that flag: nothing is read,
 // every record of the grid is written.
+// `foreign_code` (records that are not the context's own, fresh): the decided coarse tiles are not
+// written there either -- their codes go to that array (ncoarse bytes) and its reader takes them
+// from it (arvx_fast_carve).
 static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned flags,
-                        bool fresh) {
+                        bool fresh, uint8_t *foreign_code = nullptr) {
     arvx::CarveParams p;
     carve_geometry(ctx, p);
     p.rec = rec;
@@ -1421,11 +1424,14 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         // context, is their state (arvx_device.h; need_rec writes them out for the stages that
         // want records).
 #ifndef ARVX_NO_LAZY  // (A/B builds: always write the decided tiles)
-        lazy = fresh && split && rec == ctx->d_rec;
+        lazy = fresh && split && (rec == ctx->d_rec || foreign_code);
 #endif
-        if (lazy) {
+        if (lazy && rec == ctx->d_rec) {
             ARVX_HIP(ctx->pool_ccode.reserve(ncoarse + 64));
             p.coarseCarved = (uint8_t *)ctx->pool_ccode.p;
+            p.flags |= 128u;
+        } else if (lazy) {
+            p.coarseCarved = foreign_code;
             p.flags |= 128u;
         }
         // the model's own records: what this and earlier carves settle for whole coarse tiles
@@ -1569,7 +1575,7 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         ARVX_HIP(hipGetLastError());
         ctx->carve_layout = layout_when_done;
         ++ctx->carve_seq;
-        if (lazy) ctx->lazy = true;
+        if (lazy && rec == ctx->d_rec) ctx->lazy = true;
         if (p.cstate) ctx->cstate_tiles = ncoarse;
         return ARVX_OK;
     }
@@ -2610,17 +2616,22 @@ int arvx_fast_carve(arvx_ctx *ctx) {
 
     // carvable = what the dense carve clears on a fresh model: carved into records of its own
     if (int rc = ensure_records(ctx, &ctx->d_flood_rec, &ctx->flood_rec_bytes)) return rc;
-    if (int rc = launch_carve(ctx, (uint16_t *)ctx->d_flood_rec, 0, ctx->V, 0, true)) return rc;
     arvx::CarveParams g;
     carve_geometry(ctx, g);
     g.rec = ctx->d_rec;
+    // (the coarse tiles that carve settles as a whole exist only as their codes, as in the model's
+    // own lazy state: no N / 4 bytes of constants written here and read back by the conversion)
+    const size_t ncoarse_f = (size_t)g.coarseX * g.coarseY * g.coarseZ;
+    ARVX_HIP(ctx->pool_flood_code.reserve(ncoarse_f + 64));
+    uint8_t *d_carv_code = (uint8_t *)ctx->pool_flood_code.p;
+    if (int rc = launch_carve(ctx, (uint16_t *)ctx->d_flood_rec, 0, ctx->V, 0, true, d_carv_code)) return rc;
     // (both conversions: one workgroup per row of tiles, 64 rows x (tiles along x + 1) words
     // of LDS, twice that for the way back)
     const int chunk = std::min(arvx::kFloodChunk, fp.XW);
     const size_t lds_words = (size_t)64 * (chunk + 1);
     hipLaunchKernelGGL(arvx::flood_open_from_rec_kernel, dim3((unsigned)(g.tilesY * g.tilesZ)),
                        dim3(256), lds_words * sizeof(unsigned long long), ctx->stream, g,
-                       (const uint16_t *)ctx->d_flood_rec, fp);
+                       (const uint16_t *)ctx->d_flood_rec, (const uint8_t *)d_carv_code, fp);
     ARVX_HIP(hipGetLastError());
     // whole-tile pre-pass (fast_carve_kernels.h): seeds every completely open tile
     // that is connected to the origin tile through completely open tiles

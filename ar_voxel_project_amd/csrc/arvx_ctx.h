@@ -106,6 +106,7 @@ struct Ctx {
     int timeline_rec = 32;  // bytes per record
     bool fresh_pending = false;  // a fresh model that exists only as this flag (neither form valid)
     void *d_flood_rec = nullptr;  // records of the "carvable" plane of arvx_fast_carve
+    DevPool pool_flood_code;      // ... and the codes of the coarse tiles that exist only as a code
     size_t flood_rec_bytes = 0;
     void *d_coarse = nullptr;    // coarse pre-pass masks of the carve kernel
     size_t coarse_bytes = 0;
@@ -177,6 +178,7 @@ struct Ctx {
         pool_clo_rgba.release();
         pool_mc_cells.release();
         pool_raw_masks.release();
+        pool_flood_code.release();
         pool_mesh_verts.release();
         pool_mesh_rgb.release();
         pool_mesh_off.release();

@@ -60,8 +60,12 @@ __device__ __forceinline__ void flood_tile_row(const CarveParams &g, int b, int 
 // fresh model carved by all views -- a voxel is carvable where its occupancy bit is gone --,
 // g.rec the model's own records (not read for a fresh model).  reach = 0, and the seed at
 // voxel (0,0,0) if it is open.
+// carv_code (may be null): per coarse tile, 0 = the tile's records hold what the carve left, 1 =
+// the carve emptied the whole tile (all carvable; its records were never written), 2 / 3 = it left
+// the whole tile untouched (nothing carvable) -- the carve's lazy codes, arvx_device.h.
 __global__ __launch_bounds__(256) void flood_open_from_rec_kernel(const CarveParams g,
                                                                   const uint16_t *__restrict__ carv,
+                                                                  const uint8_t *__restrict__ carv_code,
                                                                   const FloodParams p) {
     extern __shared__ unsigned long long lds[];
     int ty, tz;
@@ -72,11 +76,14 @@ __global__ __launch_bounds__(256) void flood_open_from_rec_kernel(const CarvePar
         for (int t = wave; t < nt; t += 4) {  // lane = entry r of the tile's records
             const int tx = tx0 + t;
             const size_t rec0 = rec_index(g, tx, ty, tz, 0) * kRecU16;
+            const int code = carv_code ? (int)carv_code[coarse_of(g, tx, ty, tz)] : 0;
             unsigned long long w = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {  // the tile's four sub-tiles: 16 voxels each
                 if (64 * tx + 16 * k >= p.X) break;
-                unsigned long long o = (uint16_t)~carv[rec0 + k * kRecU16 + lane];
+                // carvable = the occupancy bit is gone (voxels outside the grid never had one)
+                unsigned long long o =
+                    code ? (uint16_t)~lazy_occ(g, code, tx, ty, tz, k, lane) : (uint16_t)~carv[rec0 + k * kRecU16 + lane];
                 if (!p.fresh)
                     o &= (unsigned long long)(uint16_t)~g.rec[rec0 + k * kRecU16 + 64 + lane];
                 w |= o << (16 * k);
