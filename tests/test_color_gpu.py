@@ -192,3 +192,28 @@ def test_color_call_order_errors(arvx):
         ctx.set_views(sc.M, sc.masks, campos=sc.campos)  # new views drop the images
         with pytest.raises(arvx.ArvxError):
             ctx.color_samples(one)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_views_scaled_by_powers_of_two(arvx, oracle, mode):
+    """Rows of M * world far outside the range in which two quotients may share one reciprocal
+    (divide2_shared_rcp, csrc/arvx_device.h: 2^-60 <= |a2| <= 2^60): every second view's matrix is
+    scaled by 2^-70 or 2^+70.  The scaling is exact and cancels in a0 / a2, a1 / a2, so the pixels are
+    those of the unscaled views -- through the IEEE divide the carve and the colour vote fall back
+    to; the oracle divides in the reference's way throughout."""
+    X, Y, Z, V = 40, 36, 28, 6
+    sc = scenes.syn.sphere_scene(40, V, W=160, H=120, with_images=True)
+    s = np.float32(0.512 / 40)
+    M = sc.M.copy()
+    M[1] *= np.float32(2.0 ** -70)
+    M[3] *= np.float32(2.0 ** 70)
+    M[5] *= np.float32(2.0 ** -70)
+    st = oracle.carve(X, Y, Z, s, M, sc.masks)
+    assert np.array_equal(st, oracle.carve(X, Y, Z, s, sc.M, sc.masks)), "the scaling cancels"
+    model = oracle.model_from_state(st)
+    want = oracle.color(X, Y, Z, s, M, sc.campos, sc.images, mode, model)
+    idx, rgb, depth, plain, unseen, gst = gpu_color(arvx, X, Y, Z, s, M, sc.campos, sc.masks,
+                                                    sc.images, mode)
+    assert np.array_equal(gst, st), "carve"
+    assert np.array_equal(want[idx, :3], rgb), "surface colours"
+    assert np.array_equal(plain, want), "exported Model::voxels"
