@@ -186,3 +186,48 @@ for rank in (0, world // 2):
     for _ in range(2):
         print(f"world {world} rank {rank}: 4 jobs in flight, per step: hand-offs on two side streams "
               f"{run_slots('A'):.1f} us, in the slot's own stream {run_slots('B'):.1f} us", flush=True)
+
+    # ... and one job after the other on ONE compute stream with TWO sets of state records taken in
+    # turn (two contexts on that stream): the carve of step k + 1 does not wait for the pack of step
+    # k, which reads the other set; the hand-offs run on two side streams (bench.py, N > 1, --jobs 1)
+    def run_two_sets(steps=120):
+        cs = [capi.Context(X, Y, Z, sc.voxel_size, stripes=(world, rank)) for _ in range(2)]
+        for c in cs:
+            c.set_stream(stream.cuda_stream)
+            c.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
+            c.reset()
+            c.carve()
+        pkss = [torch.zeros(world * S, dtype=torch.int64, device=dev) for _ in range(2)]
+        fulls = [torch.zeros(n64 * world, dtype=torch.int64, device=dev) for _ in range(2)]
+        sides = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        packed = [None, None]
+        best = None
+        for rep in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                b, c = k % 2, cs[k % 2]
+                c.reset()
+                c.set_views_device(sc.M, d_masks.data_ptr(), sc.W, sc.H, 1, campos=sc.campos)
+                if packed[b] is not None:
+                    stream.wait_event(packed[b])  # (the pack of step k - 2: long done)
+                c.carve()
+                carved = torch.cuda.Event()
+                carved.record(stream)
+                c.set_exchange_stream(sides[b].cuda_stream)
+                sides[b].wait_event(carved)
+                c.occupancy_pack_compress(pkss[b][rank * S:].data_ptr(), cap, fulls[b].data_ptr())
+                packed[b] = torch.cuda.Event()
+                packed[b].record(sides[b])
+                c.occupancy_expand_striped_others(pkss[b].data_ptr(), world, rank, n64, cap, wpg,
+                                                  fulls[b].data_ptr(), flag.data_ptr())
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - t0) / steps * 1e6
+            best = us if best is None or us < best else best
+        for c in cs:
+            c.set_exchange_stream(0)
+            c.close()
+        return best
+
+    print(f"world {world} rank {rank}: one job after the other, two sets of records in turn, hand-offs on two "
+          f"side streams: {run_two_sets():.1f} us per step", flush=True)
