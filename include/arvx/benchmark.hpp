@@ -70,7 +70,13 @@ class Benchmark {
     }
 
    private:
-    Benchmark() { NextRun("dummy", Vec4f()); }  // so that logging works before the first run
+    // (a first run so that logging works before NextRun, as in the reference; and the library's
+    // own stage brackets land here from the first GetInstance() on, as the reference's stages
+    // log into its singleton themselves: src/VoxelCarving.cpp:62,70)
+    Benchmark() {
+        NextRun("dummy", Vec4f(0, 0, 0, 0));
+        attach();
+    }
     std::vector<Run> runs_;
 };
 

@@ -35,18 +35,6 @@
 
 namespace arvx {
 
-struct Vec3f {  // stands in for Eigen::Vector3f
-    float v[3];
-    Vec3f() : v{0, 0, 0} {}
-    Vec3f(float a, float b, float c) : v{a, b, c} {}
-    float x() const { return v[0]; }
-    float y() const { return v[1]; }
-    float z() const { return v[2]; }
-    float operator[](int i) const { return v[i]; }
-    float &operator[](int i) { return v[i]; }
-    bool operator==(const Vec3f &o) const { return v[0] == o.v[0] && v[1] == o.v[1] && v[2] == o.v[2]; }
-};
-
 struct Triangle {  // src/MarchingCubes.h:19-31
     unsigned int idx0, idx1, idx2;
     unsigned int r, g, b;
@@ -286,7 +274,7 @@ inline SimpleMesh marchingCubesMesh(Model *model, float threshold = 0.5f) {
     mv.resize((size_t)n * 3);  // (recycled memory, not zeroed: host_pool.hpp)
     mt.resize((size_t)n);
     ARVX_TRACE("resize");
-    if (n) detail::check(arvx_mc_mesh_download_faces(ctx, &mv[0].v[0], &mt[0].idx0),
+    if (n) detail::check(arvx_mc_mesh_download_faces(ctx, mv[0].data(), &mt[0].idx0),
                          "arvx_mc_mesh_download_faces");
     ARVX_TRACE("download");
 #undef ARVX_TRACE

@@ -17,9 +17,8 @@
 // state are synchronised lazily: a stage leaves its result on the device, and the first host
 // accessor that needs it (get, isInner, visited, ...) downloads the two bit planes.
 //
-// Vec4f/Vec3i below stand in for Eigen::Vector4f / cv::Vec3i so that this header
-// needs neither library; include/arvx/opencv_dropin.hpp maps them when the real
-// ones are present.
+// Vec4f / Vec3i are Eigen::Vector4f / cv::Vec3i where those libraries are installed and
+// stand-ins with the same members otherwise (include/arvx/vec_types.hpp).
 #ifndef ARVX_MODEL_HPP
 #define ARVX_MODEL_HPP
 
@@ -37,34 +36,9 @@
 
 #include "arvx/arvx.h"
 #include "arvx/host_pool.hpp"
+#include "arvx/vec_types.hpp"
 
 namespace arvx {
-
-struct Vec4f {
-    float v[4];
-    Vec4f() : v{0, 0, 0, 0} {}
-    Vec4f(float a, float b, float c, float d) : v{a, b, c, d} {}
-    float &operator()(int i) { return v[i]; }
-    float operator()(int i) const { return v[i]; }
-    float &operator[](int i) { return v[i]; }
-    float operator[](int i) const { return v[i]; }
-    float x() const { return v[0]; }
-    float y() const { return v[1]; }
-    float z() const { return v[2]; }
-    float w() const { return v[3]; }
-    bool operator==(const Vec4f &o) const {
-        return v[0] == o.v[0] && v[1] == o.v[1] && v[2] == o.v[2] && v[3] == o.v[3];
-    }
-    bool operator!=(const Vec4f &o) const { return !(*this == o); }
-};
-
-struct Vec3i {
-    int v[3];
-    Vec3i() : v{0, 0, 0} {}
-    Vec3i(int a, int b, int c) : v{a, b, c} {}
-    int &operator()(int i) { return v[i]; }
-    int operator()(int i) const { return v[i]; }
-};
 
 struct DCLR {  // reference src/Model.h:70-73
     Vec4f color;

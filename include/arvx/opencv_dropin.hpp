@@ -247,6 +247,8 @@ inline void apply_pin(Model &model) {
 inline void carve(cv::Mat &cameraMatrix, cv::Mat &distCoeffs, Model &model,
                   std::vector<cv::Mat> &images, std::vector<cv::Mat> &masks,
                   bool intermediateMeshes = false) {
+    // (pose estimation and cv::undistort are inside the reference's bracket too: src/VoxelCarving.cpp:62)
+    arvx::detail::StageBracket timed(arvx::kStageCarving);
     arvx::dropin::Prepared p;
     arvx::dropin::prepare(cameraMatrix, distCoeffs, images, masks, false, p);
     arvx::dropin::apply_pin(model);
@@ -255,6 +257,7 @@ inline void carve(cv::Mat &cameraMatrix, cv::Mat &distCoeffs, Model &model,
 
 inline void fastCarve(cv::Mat &cameraMatrix, cv::Mat &distCoeffs, Model &model,
                       std::vector<cv::Mat> &images, std::vector<cv::Mat> &masks) {
+    arvx::detail::StageBracket timed(arvx::kStageCarving);
     arvx::dropin::Prepared p;
     arvx::dropin::prepare(cameraMatrix, distCoeffs, images, masks, false, p);
     arvx::dropin::apply_pin(model);
@@ -263,6 +266,7 @@ inline void fastCarve(cv::Mat &cameraMatrix, cv::Mat &distCoeffs, Model &model,
 
 inline void reconstructClosestColor(cv::Mat &cameraMatrix, cv::Mat &distCoeffs, Model &model,
                                     std::vector<cv::Mat> &images, std::vector<cv::Mat> &masks) {
+    arvx::detail::StageBracket timed(arvx::kStageColoring);
     arvx::dropin::Prepared p;
     arvx::dropin::prepare(cameraMatrix, distCoeffs, images, masks, true, p);
     arvx::dropin::apply_pin(model);
@@ -271,6 +275,7 @@ inline void reconstructClosestColor(cv::Mat &cameraMatrix, cv::Mat &distCoeffs, 
 
 inline void reconstructAvgColor(cv::Mat &cameraMatrix, cv::Mat &distCoeffs, Model &model,
                                 std::vector<cv::Mat> &images, std::vector<cv::Mat> &masks) {
+    arvx::detail::StageBracket timed(arvx::kStageColoring);
     arvx::dropin::Prepared p;
     arvx::dropin::prepare(cameraMatrix, distCoeffs, images, masks, true, p);
     arvx::dropin::apply_pin(model);

@@ -48,10 +48,9 @@ inline int applyClosure(Model *model, int kernelSize) {
     int64_t n = 0;
     detail::check(arvx_closure_count(ctx, &n), "arvx_closure_count");
     // straight into the model's own arrays (recycled page-locked memory, host_pool.hpp)
-    static_assert(sizeof(Vec4f) == 4 * sizeof(float), "Vec4f is four packed floats");
     HostVector<int> fidx((size_t)n);
     HostVector<Vec4f> frgba((size_t)n);
-    if (n) detail::check(arvx_closure_download32(ctx, fidx.data(), &frgba[0].v[0]),
+    if (n) detail::check(arvx_closure_download32(ctx, fidx.data(), frgba[0].data()),
                          "arvx_closure_download32");
     std::cout << "LOG - PP: starting erosion." << std::endl;  // a no-op in the reference too
     // the filled voxels: occupied on the device already, with their colours on the host now;

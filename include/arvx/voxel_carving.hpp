@@ -68,9 +68,18 @@ inline void setTimingSink(TimingSink sink) { timingSink() = std::move(sink); }
 
 namespace detail {
 
+// brackets nest: only the outermost pair of a stage reaches the sink (the drop-in signatures
+// bracket their OpenCV pre-processing together with the carve, as the reference's carve() does)
 inline void timing(Stage stage, bool start) {
+    static int depth[4] = {0, 0, 0, 0};
+    if (start ? depth[stage]++ != 0 : --depth[stage] != 0) return;
     if (timingSink()) timingSink()(stage, start);
 }
+struct StageBracket {
+    Stage stage;
+    explicit StageBracket(Stage s) : stage(s) { timing(s, true); }
+    ~StageBracket() { timing(stage, false); }
+};
 inline IntermediateHook &defaultIntermediateHook() {
     static IntermediateHook hook;
     return hook;

@@ -134,7 +134,7 @@ static int run_carve(const char *scene, const char *out, const char *mode) {
                         for (size_t k = 1; k < cl.size(); ++k)
                             if (cl[k].depth < cl[best].depth) best = k;
                         const Vec4f got = model.get(x, y, z);
-                        if (std::memcmp(got.v, cl[best].color.v, 16)) return 9;
+                        if (std::memcmp(got.data(), cl[best].color.data(), 16)) return 9;
                     }
             if (!with_list) return 10;
             Model copy(model);  // (a copy has no device context: only what addColor stored)
@@ -205,7 +205,7 @@ static int run_carve(const char *scene, const char *out, const char *mode) {
                     for (int y = 0; y < Y; ++y)
                         for (int x = 0; x < X; ++x) {
                             const Vec4f a = model.get(x, y, z), b = last[t]->get(x, y, z);
-                            if (std::memcmp(a.v, b.v, 16) ||
+                            if (std::memcmp(a.data(), b.data(), 16) ||
                                 model.visited(Vec3i(x, y, z)) != last[t]->visited(Vec3i(x, y, z))) {
                                 std::fprintf(stderr, "thread %d differs at %d %d %d\n", t, x, y, z);
                                 return 7;
@@ -222,7 +222,7 @@ static int run_carve(const char *scene, const char *out, const char *mode) {
         for (int y = 0; y < Y; ++y)
             for (int x = 0; x < X; ++x) {
                 Vec4f v = model.get(x, y, z);
-                o.write((const char *)v.v, 16);
+                o.write((const char *)v.data(), 16);
             }
     // then the seen bits, one byte each
     for (int z = 0; z < Z; ++z)
