@@ -264,7 +264,8 @@ constexpr int kExpandChunks = 4;
 // each, even) and rank q owns groups q, q + world, ...: its word i goes to
 // ((i / wpg) * world + q) * wpg + i % wpg; self = -1 expands every rank, the caller's included,
 // self = the caller's rank skips its packet (its words are in `full` already:
-// occ_pack_classify_kernel).
+// occ_pack_classify_kernel).  *overflow is raised when ANY packet, the skipped one included,
+// announces more mixed words than cap.
 __global__ __launch_bounds__(256) void occ_expand_kernel(const unsigned long long *__restrict__ in,
                                                          long long S, int world, int self,
                                                          long long n, long long cap,
@@ -277,13 +278,16 @@ __global__ __launch_bounds__(256) void occ_expand_kernel(const unsigned long lon
     if (wv >= per * world) return;
     const int q = (int)(wv / per);
     const long long c0 = (wv % per) * kExpandChunks;  // first 128-word chunk
-    if (q == self) return;
     const int lane = threadIdx.x & 63;
     const unsigned long long *pk = in + (long long)q * S;
+    // the caller's own packet is looked at too, although its words are never expanded: every
+    // rank must arrive at the same verdict about an exchange, or one of them repairs it (a
+    // collective) while the others go on
     if ((long long)pk[0] > cap) {
         if (c0 == 0 && lane == 0) *overflow = 1;
         return;
     }
+    if (q == self) return;
     const long long H = occ_packet_header(n);
     const unsigned *goff = reinterpret_cast<const unsigned *>(pk + 1 + 2 * nb);
     unsigned long long *dst = full + (wpg ? 0 : (long long)q * n);

@@ -274,18 +274,21 @@ class OccupancyExchange:
         was_fused, self.fused[b] = self.fused[b], False
         if verify and self.overflowed():
             # some slab had more mixed words than cap: redo this exchange in plain words.
-            # Every rank sees the same packets, so every rank takes this branch.
+            # Every rank sees the same packets and every expansion looks at all of them -- the
+            # caller's own included, which it otherwise skips --, so every rank takes this branch.
             self.overflow.zero_()
             self.fallbacks += 1
             self.cap = self.cap_max
             if self.layout == "striped":
                 # worst-case packets cannot overflow: the same exchange again at full size
                 S = self.header + self.cap_max
-                if was_fused:  # (from the state again: only a caller that has not carved since)
-                    self.codec.occupancy_pack_compress(self.packet[b].data_ptr(), self.cap_max, 0)
-                else:
-                    self.codec.occupancy_compress(self.local[b].data_ptr(), self.n64,
-                                                  self.packet[b].data_ptr(), self.cap_max)
+                if was_fused:
+                    # THIS job's own words are in full[b] (pack() stored them there); the
+                    # context may have carved another job since, so its state is not asked again
+                    own = self.full[b].view(torch.int64).view(-1, self.world, self.wpg)[:, self.rank, :]
+                    self.local[b].copy_(own.reshape(-1))
+                self.codec.occupancy_compress(self.local[b].data_ptr(), self.n64,
+                                              self.packet[b].data_ptr(), self.cap_max)
                 dist.all_gather_into_tensor(self.gathered[b][:self.world * S], self.packet[b][:S])
                 self.codec.occupancy_expand_striped(self.gathered[b].data_ptr(), self.world,
                                                     self.n64, self.cap_max, self.wpg,

@@ -265,6 +265,42 @@ def run_workloads(capi, synthetic, dev, check):
     return out
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run
+    --nproc-per-node N bench.py <the same arguments>` as a child process (one rank per GPU, RCCL
+    over 127.0.0.1), pass its output through, and check that the line rank 0 printed speaks of N
+    GPUs.  -> the exit status for this process (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           *sys.argv[1:]]
+    print(f"bench.py: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for text in child.stdout:
+        sys.stdout.write(text)
+        sys.stdout.flush()
+        if text.startswith("{"):
+            line = text
+    rc = child.wait()
+    if rc != 0:
+        print(f"bench.py: the ranks exited with status {rc}", file=sys.stderr)
+        return rc if 0 < rc < 256 else 1
+    try:
+        got = json.loads(line)["n_gpus"]
+    except (TypeError, ValueError, KeyError):
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        return 1
+    if got != n:
+        print(f"bench.py: --gpus {n} but the line says n_gpus = {got}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -303,10 +339,17 @@ def main():
                          "case for the culling and the 1024^3 target with parity)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: this process starts the N ranks itself --
+        # before anything here has touched a GPU -- as fresh child processes, relays their output
+        # and exits with their status.  (A launcher that sets WORLD_SIZE itself goes on below.)
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:  # never measure another number of GPUs than the line will say
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")

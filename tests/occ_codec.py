@@ -44,17 +44,18 @@ def compress(words, cap):
 
 def expand(packets, world, self_rank, n, cap, full):
     """packets: (world * S,) uint64; full: (world * n,) uint64, updated in place for every
-    q != self_rank.  -> True if some packet had outgrown cap (that slab is skipped)."""
+    q != self_rank.  -> True if some packet -- the caller's own included, so that every rank
+    arrives at the same verdict -- had outgrown cap (that slab is skipped)."""
     nb = (n + 63) // 64
     H = header_words(n)
     S = H + cap
     overflow = False
     for q in range(world):
-        if q == self_rank:
-            continue
         pk = packets[q * S:(q + 1) * S]
         if int(pk[0]) > cap:
             overflow = True
+            continue
+        if q == self_rank:
             continue
         ones = np.unpackbits(pk[1:1 + nb].view(np.uint8), bitorder="little")[:n].astype(bool)
         mixed = np.unpackbits(pk[1 + nb:1 + 2 * nb].view(np.uint8), bitorder="little")[:n].astype(bool)
@@ -103,4 +104,41 @@ class NumpyCodec:
         S = header_words(n) + cap
         if expand(_arr(packets_ptr, world * S), world, self_rank, n, cap,
                   _arr(full_ptr, world * n)):
+            _arr(overflow_ptr, 1, np.int32)[0] = 1
+
+
+class FusedNumpyCodec(NumpyCodec):
+    """A codec that also has the fused calls of capi.Context (occupancy_pack_compress,
+    occupancy_expand_striped_others): it stands for a context whose current state the test sets
+    with `carve(words)` -- the rank's occupancy words in local order -- so that the host logic of
+    sharding.OccupancyExchange's fused path runs over gloo."""
+
+    def __init__(self, world, rank, wpg):
+        self.world, self.rank, self.wpg = world, rank, wpg  # wpg = 0: contiguous slabs
+        self.state = None
+        self.carves = 0
+
+    def carve(self, words):
+        self.state = np.array(words, U64)
+        self.carves += 1
+
+    def occupancy_pack_compress(self, packet_ptr, cap, full_ptr):
+        n = len(self.state)
+        _arr(packet_ptr, header_words(n) + cap)[:] = compress(self.state, cap)
+        if full_ptr:
+            full = _arr(full_ptr, self.world * n)
+            if self.wpg:
+                full.reshape(-1, self.world, self.wpg)[:, self.rank, :] = self.state.reshape(-1, self.wpg)
+            else:
+                full[self.rank * n:(self.rank + 1) * n] = self.state
+
+    def occupancy_expand_striped_others(self, packets_ptr, world, self_rank, n, cap, wpg, full_ptr,
+                                        overflow_ptr):
+        S = header_words(n) + cap
+        packets = _arr(packets_ptr, world * S)
+        full = _arr(full_ptr, world * n)
+        own = full.reshape(-1, world, wpg)[:, self_rank, :].copy()
+        over = expand_striped(packets, world, n, cap, wpg, full)
+        full.reshape(-1, world, wpg)[:, self_rank, :] = own  # the caller's packet is skipped
+        if over:
             _arr(overflow_ptr, 1, np.int32)[0] = 1

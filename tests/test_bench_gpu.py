@@ -74,3 +74,29 @@ def test_two_rank_rehearsal_every_collective(jobs):
         assert c["merge_ok"] is True, name
         assert c["ms_per_step"] > 0 and c["exchange_bytes_per_rank"] > 0
     assert d["collective_backend"]["ranks"] == 2
+
+
+def test_bench_starts_its_own_ranks():
+    """Plain `python bench.py --gpus 2`, the way the driver starts `--gpus 1` (no launcher, no
+    WORLD_SIZE): the process starts its two ranks itself and relays rank 0's line -- it must not
+    measure one GPU and call it two (missing 3)."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ARVX_BENCH_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "128",
+                        "--steps", "6", "--warmup", "2", "--no-mgpu", "--rounds", "1", "--no-cpu",
+                        "--no-workloads"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["collective_backend"]["ranks"] == 2
+    assert d["config"]["merged_plane_holds_rank0_planes"] is True
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """--gpus N under a launcher that started another number of ranks fails loudly -- before any
+    GPU work (needs no GPU, but lives with the other bench tests)."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

@@ -311,3 +311,47 @@ def test_pack_compress_is_pack_then_compress(X, Y, Z, kind, state):
             for q in range(world):  # group g of rank q = global group g * world + q
                 got = full[q::world].reshape(-1)
                 assert np.array_equal(got, local), f"rank {q}'s stripes"
+
+
+@pytest.mark.parametrize("layout", ["slab", "striped"])
+@pytest.mark.parametrize("who", ["self", "other", "nobody"])
+def test_every_rank_sees_an_overflowing_packet(ctx, layout, who):
+    """One packet of the gathered buffer announces more mixed words than the cap.  The expansion
+    that skips the caller's own packet must still raise the flag when that packet is the caller's
+    own -- every rank has to arrive at the same verdict, or one of them repairs the exchange (a
+    collective) alone -- and must still expand the packets that fit."""
+    world, me, wpg, groups = 3, 1, 32, 4
+    n = wpg * groups
+    rng = np.random.default_rng(17)
+    slabs = [_words(rng, n, 0.6, 0.3) for _ in range(world)]
+    need = [int(((w != 0) & (w != occ_codec.ONES)).sum()) for w in slabs]
+    cap = max(need) + 2
+    S = occ_codec.header_words(n) + cap
+    d_pk = torch.zeros(world * S, dtype=torch.int64, device="cuda")
+    d_ws = [_dev(w) for w in slabs]
+    _settle()
+    for q, d_w in enumerate(d_ws):
+        ctx.occupancy_compress(d_w.data_ptr(), n, d_pk[q * S:].data_ptr(), cap)
+    ctx.synchronize()
+    over = {"self": me, "other": 2, "nobody": None}[who]
+    if over is not None:
+        d_pk[over * S] = cap + 1  # the header a packet carries when its slab outgrew the cap
+    pk = d_pk.cpu().numpy().view(np.uint64)
+    full0 = rng.integers(0, 2 ** 62, world * n, dtype=np.uint64)
+    d_full = _dev(full0)
+    d_flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _settle()
+    want = full0.copy()
+    if layout == "slab":
+        ctx.occupancy_expand(d_pk.data_ptr(), world, me, n, cap, d_full.data_ptr(), d_flag.data_ptr())
+        want_over = occ_codec.expand(pk, world, me, n, cap, want)
+    else:
+        ctx.occupancy_expand_striped_others(d_pk.data_ptr(), world, me, n, cap, wpg, d_full.data_ptr(),
+                                            d_flag.data_ptr())
+        own = want.reshape(-1, world, wpg)[:, me, :].copy()
+        want_over = occ_codec.expand_striped(pk, world, n, cap, wpg, want)
+        want.reshape(-1, world, wpg)[:, me, :] = own
+    ctx.synchronize()
+    assert want_over == (over is not None)
+    assert bool(d_flag.item()) == want_over
+    assert np.array_equal(d_full.cpu().numpy().view(np.uint64), want)

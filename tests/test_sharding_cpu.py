@@ -122,6 +122,86 @@ def test_compressed_exchange_overflow_falls_back_gloo(tmp_path, oracle, layout):
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
+def _fused_worker(rank, world, port, tmpdir, layout):
+    """The fused hand-off's host logic (pack() = Context.occupancy_pack_compress, the expansion that
+    skips the caller's packet) with a packet cap that only ONE rank's packet outgrows, and with the
+    context carving the next job before the exchange is waited for."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests import occ_codec
+        X, Y, Z = 32, 16, 32
+        n = X * Y * (Z // world) // 64
+        wpg = X * Y * 8 // 64 if layout == "striped" else 0
+        rng = np.random.default_rng(11)  # the same numbers on every rank
+
+        def job_words(mixed_of_rank):
+            out = []
+            for q in range(world):
+                w = np.where(rng.random(n) < 0.5, occ_codec.ONES, occ_codec.U64(0))
+                at = rng.choice(n, mixed_of_rank[q], replace=False)
+                w[at] = rng.integers(1, 2 ** 62, len(at), dtype=np.uint64)
+                out.append(w)
+            return out
+
+        def merged(words):
+            if layout == "striped":
+                full = np.zeros(world * n, np.uint64)
+                for q in range(world):
+                    full.reshape(-1, world, wpg)[:, q, :] = words[q].reshape(-1, wpg)
+                return full
+            return np.concatenate(words)
+
+        jobs = [job_words([5, 40]), job_words([6, 41]), job_words([30, 3])]
+        codec = occ_codec.FusedNumpyCodec(world, rank, wpg)
+        ex = sharding.OccupancyExchange(X, Y, Z, world, rank, "cpu", mode="compressed", buffers=2,
+                                        layout=layout, codec=codec)
+        assert ex.can_fuse and ex.n64 == n
+        codec.carve(jobs[0][rank])
+        ex.prepare(0)
+        ex.pack(codec, 0)
+        ex.launch(0)
+        ex.wait_all()
+        assert np.array_equal(ex.full[0].numpy().view(np.uint64), merged(jobs[0]))
+        assert ex.retune(0) >= 40 and ex.fallbacks == 0
+        ex.cap = 20  # rank 0's packets fit, rank 1's (41 mixed words) do not
+        codec.carve(jobs[1][rank])
+        ex.prepare(1)
+        ex.pack(codec, 1)
+        ex.launch(1, async_op=True)
+        codec.carve(jobs[2][rank])  # the context moves on to the next job before the wait
+        ex.wait(1)
+        assert ex.fallbacks == 1, f"rank {rank}: every rank must see the one packet that overflowed"
+        assert np.array_equal(ex.full[1].numpy().view(np.uint64), merged(jobs[1])), \
+            f"rank {rank}: the repaired exchange ships the job that was packed"
+        assert not ex.overflowed()
+        # and the exchange keeps working afterwards (cap is back at its worst case)
+        ex.prepare(0)
+        ex.pack(codec, 0)
+        ex.launch(0)
+        ex.wait_all()
+        assert np.array_equal(ex.full[0].numpy().view(np.uint64), merged(jobs[2]))
+        assert ex.fallbacks == 1
+        open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("layout", ["slab", "striped"])
+def test_fused_exchange_one_rank_overflows_gloo(tmp_path, layout):
+    """a packet cap that only one rank's packet outgrows must send EVERY rank
+    into the repair (the overflowing rank skips its own packet in the expansion, so it has to look
+    at its header all the same) -- otherwise one rank enters a collective alone; (medium) and the
+    repair re-ships the job that was packed, not whatever the context holds by then."""
+    world = 2
+    mp.spawn(_fused_worker, args=(world, _free_port(), str(tmp_path), layout), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
 def test_occupancy_packet_restatement():
     """The numpy packet codec round-trips and flags overflow (it is the GPU tests' checker)."""
     from tests import occ_codec
