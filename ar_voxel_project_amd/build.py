@@ -15,13 +15,16 @@ def _make(directory: str, *targets: str) -> None:
         raise RuntimeError(f"{' '.join(cmd)} failed:\n{res.stdout}")
 
 
-STEP_KERNEL_SOURCES = ("arvx_device.h", "carve_kernels.h", "views_kernels.h")
+# the kernels of a bench step, the file that holds their launch geometry, and the compiler flags
+STEP_KERNEL_SOURCES = ("arvx_device.h", "carve_kernels.h", "views_kernels.h", "arvx_ctx.h",
+                       "arvx_capi.hip", "Makefile")
 
 
 def source_stamp() -> str:
     """sha256 (16 hex digits) over the sources of the kernels of a bench step (view derivation +
-    carve): what ties a PMC pass under profiles/ (tools/make_traffic.py) to the build bench.py
-    is running."""
+    carve), their launch code (arvx_capi.hip, arvx_ctx.h) and the build's flags (the Makefile):
+    what ties a PMC pass under profiles/ (tools/make_traffic.py) to the build bench.py is
+    running."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "ar_voxel_project_amd", "csrc")

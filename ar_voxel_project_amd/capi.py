@@ -70,6 +70,7 @@ class Stats(C.Structure):
         ("subtile_views_total", C.c_uint64),
         ("surface_voxels", C.c_uint64),
         ("reserved", C.c_uint64 * 3),
+        ("host_total_fallbacks", C.c_uint64),
     ]
 
 
@@ -614,4 +615,5 @@ class Context:
         # (sub-tile, view) pairs that went to the exact kernel although every open voxel
         # got the same answer there: what a perfect classifier would have decided
         out["mixed_pairs_uniform"] = int(s.reserved[2])
+        out["host_total_fallbacks"] = int(s.host_total_fallbacks)
         return out

@@ -19,7 +19,9 @@
 
 #include "arvx_ctx.h"
 #include "carve_kernels.h"
-#include "carve_stream_kernels.h"
+#ifdef ARVX_EXPERIMENTS
+#include "carve_stream_kernels.h"  // the one-launch carve: loses by 11-24 %, experiment builds only
+#endif
 #include "views_kernels.h"
 #include "state_kernels.h"
 #include "undistort_kernels.h"
@@ -280,6 +282,9 @@ static int bit_compact(Ctx *ctx, const unsigned long long *bits, size_t nwords, 
 static long long host_total(Ctx *ctx, int slot) {
     const long long t = ctx->h_totals[slot];
     if (t >= 0 || !ctx->pool_compact.p) return t;
+    // never expected since the word is allocated coherent (EXPERIMENTS.md round 4): counted, so that
+    // a recurrence shows (arvx_get_stats: host_total_fallbacks; the list tests assert 0)
+    ++ctx->host_total_fallbacks;
     long long dev = -1;
     if (hipMemcpy(&dev, (const uint8_t *)ctx->pool_compact.p + 8 + 8 * slot, sizeof dev,
                   hipMemcpyDeviceToHost) != hipSuccess)
@@ -1259,6 +1264,7 @@ int arvx_occupancy_expand_striped_others(arvx_ctx *ctx, const void *dev_packets,
 // ---- carve -------------------------------------------------------------------
 
 // Launches the carve over planes [ze0, ze1) (owned + halo) of the records at `rec`.
+#ifdef ARVX_EXPERIMENTS
 // A fresh model carved by ONE persistent launch (carve_stream_kernels.h).  p: geometry, views and
 // flags filled in by launch_carve.
 static int launch_carve_stream(Ctx *ctx, arvx::CarveParams p, int ncu) {
@@ -1338,6 +1344,7 @@ static int launch_carve_stream(Ctx *ctx, arvx::CarveParams p, int ncu) {
     ctx->cstate_tiles = ncoarse;
     return ARVX_OK;
 }
+#endif
 
 // `fresh`: the model is all-occupied/unseen and exists only as that flag: nothing is read,
 // every record of the grid is written.
@@ -1385,11 +1392,17 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
     // caller asks for it (carve_stream_kernels.h; EXPERIMENTS.md, round 4: its sub-tile phase is
     // slower inside a launch of 128-register waves than as a launch of its own, so the three
     // launches below stay the default)
+#ifdef ARVX_EXPERIMENTS
     static const bool stream_default = experiment_flag("ARVX_STREAM_DEFAULT");
     if (fresh && split && rec == ctx->d_rec && !(flags & (ARVX_CARVE_STATS | ARVX_CARVE_NO_STREAM)) &&
         ((flags & ARVX_CARVE_STREAM) || (stream_default && (size_t)p.X * p.Y * p.Z >= ((size_t)1 << 26))) &&
         arvx::rec_count(p) < ((size_t)1 << 30) && p.tilesX < 65536 && p.tilesY < 65536 && p.tilesZ < 65536)
         return launch_carve_stream(ctx, p, ncu);
+#else
+    if (flags & ARVX_CARVE_STREAM)
+        return fail(ARVX_ERR_INVALID, "ARVX_CARVE_STREAM: the one-launch carve is only in -DARVX_EXPERIMENTS "
+                                      "builds (libarvx_experiments.so)");
+#endif
     if (cull) {
         const size_t words = ncoarse * p.nchunks;
         // coarse masks | coarse codes | undecided list | two list counters
@@ -1653,6 +1666,7 @@ int arvx_get_stats(arvx_ctx *ctx, arvx_stats *out) {
     out->reserved[0] = h[5];  // 256-voxel slices evaluated exactly
     out->reserved[1] = h[6];  // voxels among them that were not yet carved+seen
     out->reserved[2] = h[7];  // mixed pairs whose open voxels all got the same answer
+    out->host_total_fallbacks = ctx->host_total_fallbacks;
     return ARVX_OK;
 }
 

@@ -111,6 +111,9 @@ struct Ctx {
     void *d_coarse = nullptr;    // coarse pre-pass masks of the carve kernel
     size_t coarse_bytes = 0;
     unsigned long long *d_stats = nullptr;
+    // times a list total had to be fetched from the device because the page-locked word still
+    // read -1 at the synchronisation (host_total, arvx_capi.hip); expected: never
+    unsigned long long host_total_fallbacks = 0;
     void *d_scratch = nullptr;  // work buffer of the calls on `stream`
     size_t scratch_bytes = 0;
     // work buffer of the hand-off calls (arvx_occupancy_compress): they may run on `xstream`

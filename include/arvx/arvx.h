@@ -57,8 +57,10 @@ enum {
 #define ARVX_CARVE_NO_CULL 1u /* evaluate every voxel in every view (ablation) */
 #define ARVX_CARVE_STATS 2u   /* fill the counters read by arvx_get_stats */
 #define ARVX_CARVE_FUSED 8u   /* one kernel for rectangle tests and per-voxel work (A/B) */
-#define ARVX_CARVE_STREAM 16u    /* a fresh model: the one-launch streaming carve (A/B and tests; the
-                                    default is the three-launch chain) */
+#define ARVX_CARVE_STREAM 16u    /* a fresh model: the one-launch streaming carve.  It loses to the
+                                    three-launch chain and is compiled only into
+                                    -DARVX_EXPERIMENTS builds (libarvx_experiments.so, A/B and
+                                    tests); the shipped library answers ARVX_ERR_INVALID */
 #define ARVX_CARVE_NO_STREAM 32u /* never the streaming carve */
 
 /* colour modes: reference -color=1 / -color=2 (src/main.cpp:276-288) */
@@ -74,6 +76,10 @@ typedef struct arvx_stats {
     uint64_t subtile_views_total; /* (sub-tile, view) pairs classified */
     uint64_t surface_voxels;  /* colour pass: occupied non-inner voxels */
     uint64_t reserved[3];
+    uint64_t host_total_fallbacks; /* list totals the host had to fetch from the device because the
+                                      page-locked word did not show the kernel's store at the
+                                      synchronisation (colour pass, closure, cell list, mesh);
+                                      expected 0, counted over the context's life */
 } arvx_stats;
 
 int arvx_version(void);

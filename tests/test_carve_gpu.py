@@ -200,8 +200,8 @@ def test_cull_matches_no_cull_block_noise(arvx, seed, block, inside):
 def test_cull_matches_no_cull_sparse_background(arvx, seed, block, p_bg):
     """Mostly-foreground masks with a few small background squares (bench.py's `workloads`: the
     regime where no rectangle test settles anything and nearly every voxel stays occupied through
-    all views -- no early-out ends an item): the split carve, the fused kernel and the streaming
-    launch against the brute-force kernel, voxel for voxel; the reference has no early-out at all
+    all views -- no early-out ends an item): the split carve and the fused kernel against the
+    brute-force kernel, voxel for voxel; the reference has no early-out at all
     (src/VoxelCarving.cpp:39-55)."""
     N, V, W, H = 192, 9, 640, 480
     s = np.float32(0.512 / N)
@@ -211,7 +211,6 @@ def test_cull_matches_no_cull_sparse_background(arvx, seed, block, p_bg):
     assert (b & 1).mean() > 0.3  # (voxels do stay alive)
     assert_same(run_gpu(arvx, N, N, N, s, M, masks, 0), b, f"cull vs no-cull, sparse background seed={seed}")
     assert_same(run_gpu(arvx, N, N, N, s, M, masks, arvx.CARVE_FUSED), b, "fused kernel")
-    assert_same(run_gpu(arvx, N, N, N, s, M, masks, arvx.CARVE_STREAM), b, "streaming launch")
 
 
 def test_lazy_reset_and_reuse(arvx, oracle):

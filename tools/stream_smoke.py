@@ -1,5 +1,7 @@
-import sys, numpy as np
+import os, sys, numpy as np
 sys.path.insert(0, '.')
+# the streaming carve lives in the experiments build only
+os.environ.setdefault('ARVX_LIB_PATH', os.path.abspath('ar_voxel_project_amd/lib/libarvx_experiments.so'))
 from ar_voxel_project_amd import capi, synthetic, build
 build.build_oracle()
 from oracle import pyoracle

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-wave timeline of the streaming carve from a DIAGNOSTIC build
-(make -C ar_voxel_project_amd/csrc EXTRA=-DARVX_TIMELINE OUT=.../ab_libs/timeline.so):
+(make -C ar_voxel_project_amd/csrc EXTRA="-DARVX_TIMELINE -DARVX_EXPERIMENTS" OUT=.../ab_libs/timeline.so):
     ARVX_LIB_PATH=ab_libs/timeline.so python tools/stream_timeline.py 512"""
 import ctypes as C
 import json
