@@ -253,26 +253,32 @@ static int scan_counts(Ctx *ctx, const int *counts, const int4 *cells, long long
     return ARVX_OK;
 }
 
-// The ordered compaction in ONE launch (bit_compact_kernel): up to `cap` entries of the list go to
-// d_index, every word's SparseWord to d_words; the list's true length is left in device word
-// *d_total_out (for the kernels that follow) and in the page-locked ctx->h_totals[slot], which the
-// caller reads after its synchronisation.
+// The ordered compaction in ONE launch (bit_compact_counted_kernel) of a plane whose producer left the
+// set bits of every chunk of kBitChunk words in `counts`: up to `cap` entries of the list go to d_index,
+// every word's SparseWord to d_words; the list's true length is left in device word *d_total_out (for
+// the kernels that follow) and in the page-locked ctx->h_totals[slot], which the caller reads after
+// its synchronisation.
 static int bit_compact(Ctx *ctx, const unsigned long long *bits, size_t nwords, const arvx::BitGrid &g,
-                       long long cap, int *d_index, arvx::SparseWord *d_words, int slot,
+                       const int *counts, long long cap, int *d_index, arvx::SparseWord *d_words, int slot,
                        const long long **d_total_out) {
     const size_t nchunks = (nwords + arvx::kBitChunk - 1) / arvx::kBitChunk;
     uint8_t *base = nullptr;
     unsigned long long *status = nullptr;
-    if (int rc = compact_control(ctx, nchunks, &base, &status)) return rc;
+    if (int rc = compact_control(ctx, 0, &base, &status)) return rc;  // (the device totals live there)
     long long *d_total = (long long *)(base + 8 + 8 * slot);
     ctx->h_totals[slot] = -1;
-    hipLaunchKernelGGL(arvx::bit_compact_kernel, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream, bits,
-                       nwords, g, (unsigned *)base, (unsigned)ctx->compact_tickets, status,
-                       ctx->compact_epoch, cap, d_index, d_words,
-                       d_total, ctx->d_totals_host + slot, ctx->d_fault);
+    hipLaunchKernelGGL(arvx::bit_compact_counted_kernel, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream,
+                       bits, nwords, g, counts, cap, d_index, d_words, d_total, ctx->d_totals_host + slot);
     ARVX_HIP(hipGetLastError());
-    ctx->compact_tickets += nchunks;
     if (d_total_out) *d_total_out = d_total;
+    return ARVX_OK;
+}
+// room for the chunk counts of a plane of nwords words
+static int chunk_counts(Ctx *ctx, size_t nwords, int **counts, unsigned *nchunks) {
+    const size_t n = (nwords + arvx::kBitChunk - 1) / arvx::kBitChunk;
+    ARVX_HIP(ctx->pool_chunk_counts.reserve(n * sizeof(int)));
+    *counts = (int *)ctx->pool_chunk_counts.p;
+    *nchunks = (unsigned)n;
     return ARVX_OK;
 }
 
@@ -994,7 +1000,10 @@ int arvx_state_download_planes(arvx_ctx *ctx, uint32_t *occ, uint32_t *seen) {
 
 int arvx_handle_unseen(arvx_ctx *ctx) {
     ARVX_CHECK_CTX(ctx);
-    if (int mrc = need_rec(ctx)) return mrc;
+    // (coarse tiles that exist only as their code stay codes: "carved and seen", "untouched and
+    // seen" and "untouched, not seen" are all unchanged by occ |= ~seen -- the records behind a
+    // code are not read by anybody)
+    if (int mrc = need_rec(ctx, true)) return mrc;
     ctx->closure_ready = false;  // (colours and paint stay: only never-seen voxels change)
     arvx::CarveParams g;
     carve_geometry(ctx, g);
@@ -1741,7 +1750,7 @@ int arvx_color(arvx_ctx *ctx, int mode) {
     stage_ranges(ctx, 0, c_lo, c_hi, f_lo, f_hi);
     const arvx::BitGrid gext{ctx->X, ctx->Y, Zext, XW};
     const size_t row_words = (size_t)XW * ctx->Y;
-    const size_t nw_ext = row_words * Zext, nw_col = row_words * (size_t)(c_hi - c_lo);
+    const size_t nw_ext = row_words * Zext;
     if (int rc = ensure_scratch(ctx, nw_ext * sizeof(unsigned long long) + 64)) return rc;
     // the surface plane stays with the context: with its ranks it is the index of the colour
     // list (closure and mesh look colours up through it)
@@ -1750,10 +1759,13 @@ int arvx_color(arvx_ctx *ctx, int mode) {
     unsigned long long *d_occ = (unsigned long long *)ctx->d_scratch;
     unsigned long long *d_surf = (unsigned long long *)ctx->pool_col_bits.p;
     if (int rc = launch_bit_pack(ctx, gext, 0, 0, d_occ, nullptr)) return rc;
-    if (nw_col != nw_ext) ARVX_HIP(hipMemsetAsync(d_surf, 0, nw_ext * sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(arvx::bit_surface_kernel, dim3((unsigned)((nw_col + 255) / 256)), dim3(256),
-                       0, ctx->stream, d_occ, gext, c_lo - ctx->ze0, c_hi - c_lo,
-                       d_surf + row_words * (size_t)(c_lo - ctx->ze0));
+    // the surface plane of the planes [c_lo, c_hi) (zeros elsewhere) and, per chunk of the
+    // compaction, its number of set bits
+    int *d_counts = nullptr;
+    unsigned nchunks = 0;
+    if (int rc = chunk_counts(ctx, nw_ext, &d_counts, &nchunks)) return rc;
+    hipLaunchKernelGGL(arvx::bit_surface_count_kernel, dim3(nchunks), dim3(256), 0, ctx->stream, d_occ, gext,
+                       c_lo - ctx->ze0, c_hi - ctx->ze0, d_surf, d_counts);
     ARVX_HIP(hipGetLastError());
     // The list's length is not known before the compaction has run: the buffers are sized for what
     // the last pass needed (first call: a surface's share of the voxels), the kernels stop at that
@@ -1775,7 +1787,7 @@ int arvx_color(arvx_ctx *ctx, int mode) {
         ARVX_HIP(ctx->pool_surf_has.reserve((size_t)cap));
         ctx->d_surf_has = (uint8_t *)ctx->pool_surf_has.p;
         const long long *d_total = nullptr;
-        if (int rc = bit_compact(ctx, d_surf, nw_ext, gext, cap, ctx->d_surf_index,
+        if (int rc = bit_compact(ctx, d_surf, nw_ext, gext, d_counts, cap, ctx->d_surf_index,
                                  (arvx::SparseWord *)ctx->pool_col_rank.p, 0, &d_total))
             return rc;
         arvx::VoteParams vp;
@@ -2219,7 +2231,7 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
         return fail(ARVX_ERR_STATE,
                     "a slab needs %d halo planes for a closure of size %d (it has %d): "
                     "arvx_ctx_create_slab_halo", radius + 1, kernel_size, ctx->halo);
-    if (int mrc = need_rec(ctx)) return mrc;
+    if (int mrc = need_rec(ctx, true)) return mrc;  // (every kernel below knows the lazy codes)
     ctx->free_closure();
     // filled = dilate(occupied, box of radius r) and not occupied, on bit planes over the
     // context's planes
@@ -2240,16 +2252,15 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     const unsigned gw = (unsigned)((nwords + 255) / 256);
     hipLaunchKernelGGL(arvx::bit_dilate_xy_kernel, dim3(gw), dim3(256), 0, ctx->stream, d_occ, g,
                        radius, d_b);
-    hipLaunchKernelGGL(arvx::bit_dilate_yz_kernel, dim3(gw), dim3(256), 0, ctx->stream, d_b, g,
-                       radius, 2, (const unsigned long long *)d_occ, d_fill);
-    ARVX_HIP(hipGetLastError());
     // (halo planes outside [f_lo, f_hi): their boxes reach planes this context knows nothing
-    // about -- not filled here, their owners do it)
-    if (f_lo > ctx->ze0)
-        ARVX_HIP(hipMemsetAsync(d_fill, 0, row_words * (size_t)(f_lo - ctx->ze0) * 8, ctx->stream));
-    if (f_hi < ctx->ze1)
-        ARVX_HIP(hipMemsetAsync(d_fill + row_words * (size_t)(f_hi - ctx->ze0), 0,
-                                row_words * (size_t)(ctx->ze1 - f_hi) * 8, ctx->stream));
+    // about -- not filled here, their owners do it: zeros)
+    int *d_counts = nullptr;
+    unsigned nchunks = 0;
+    if (int rc = chunk_counts(ctx, nwords, &d_counts, &nchunks)) return rc;
+    hipLaunchKernelGGL(arvx::bit_dilate_z_count_kernel, dim3(nchunks), dim3(256), 0, ctx->stream, d_b, g,
+                       radius, (const unsigned long long *)d_occ, f_lo - ctx->ze0, f_hi - ctx->ze0, d_fill,
+                       d_counts);
+    ARVX_HIP(hipGetLastError());
     // The list of the filled voxels: compacted in one launch into buffers sized for what the last
     // closure needed (first call: a shell's share of the voxels); the true length is read at the
     // call's ONE synchronisation, and a list that outgrew its buffers is written again.
@@ -2268,7 +2279,7 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
         ARVX_HIP(ctx->pool_clo_rgba.reserve((size_t)cap * sizeof(float4)));
         ctx->d_clo_rgba = (void *)ctx->pool_clo_rgba.p;
         const long long *d_total = nullptr;
-        if (int rc = bit_compact(ctx, d_fill, nwords, g, cap, ctx->d_clo_index,
+        if (int rc = bit_compact(ctx, d_fill, nwords, g, d_counts, cap, ctx->d_clo_index,
                                  (arvx::SparseWord *)ctx->pool_clo_rank.p, 1, &d_total))
             return rc;
         arvx::ClosureParams cp;
@@ -2290,8 +2301,13 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
         if (attempt == 0) {
             // the filled voxels are occupied from now on (their w is count / count = 1); the fill
             // kernel reads the occupancy from the bit planes, not from the records
-            hipLaunchKernelGGL(arvx::rec_or_bitgrid_kernel, dim3(gw), dim3(256), 0, ctx->stream, rp, 0,
-                               g.Z, d_fill);
+            if (ctx->lazy)  // (tiles that exist only as their code and receive a voxel are written out)
+                hipLaunchKernelGGL(arvx::rec_or_bitgrid_lazy_kernel,
+                                   dim3((unsigned)((size_t)rp.coarseX * rp.coarseY * rp.coarseZ)), dim3(256), 0,
+                                   ctx->stream, rp, (const unsigned long long *)d_fill, (uint8_t *)ctx->pool_ccode.p);
+            else
+                hipLaunchKernelGGL(arvx::rec_or_bitgrid_kernel, dim3(gw), dim3(256), 0, ctx->stream, rp, 0,
+                                   g.Z, d_fill);
             ARVX_HIP(hipGetLastError());
         }
         ARVX_SYNC(ctx);
@@ -2365,7 +2381,7 @@ int arvx_closure_download(arvx_ctx *ctx, int64_t *index, float *rgba) {
 // The cell list, launched without a synchronisation: up to `cap` cells into the context's buffer,
 // the list's true length in device word *d_total (and ctx->h_totals[2] after the next sync).
 static int mc_cells_launch(Ctx *ctx, long long cap, const long long **d_total) {
-    if (int mrc = need_rec(ctx)) return mrc;
+    if (int mrc = need_rec(ctx, true)) return mrc;  // (mc_zpack_rec_kernel reads lazy tiles)
     arvx::McParams mp;
     mp.X = ctx->X;
     mp.Y = ctx->Y;

@@ -61,10 +61,11 @@ struct Ctx {
     DevPool pool_vstrip;          // views_strip_kernel: ticket counters + published column counts
     size_t vstrip_key = 0;        // layout (V, strips, granules) the pool was zeroed for
 
-    // bit_compact_kernel (bitplane_kernels.h): ticket counter, device totals, status granules; and
+    // scan_lookback_kernel (bitplane_kernels.h): ticket counter, device totals, status granules; and
     // what the host keeps beside it.  h_totals: page-locked words behind the fault word that the
     // kernels write the lists' lengths to (read at the call's one synchronisation).
     DevPool pool_compact;
+    DevPool pool_chunk_counts;  // set bits per kBitChunk words of the plane being compacted
     unsigned long long compact_tickets = 0;  // tickets all launches so far have taken
     uint32_t compact_epoch = 0;
     long long *h_totals = nullptr, *d_totals_host = nullptr;  // 6 slots (host / device address)
@@ -189,6 +190,7 @@ struct Ctx {
         pool_vstrip.release();
         vstrip_key = 0;
         pool_compact.release();
+        pool_chunk_counts.release();
         compact_tickets = 0;
         pool_paint.release();
         pool_ccode.release();

@@ -31,28 +31,6 @@ __device__ __forceinline__ unsigned long long bit_word(const unsigned long long 
     return bits[((size_t)z * g.Y + y) * g.XW + xw];
 }
 
-// surf = occupied and not inner (all six neighbours occupied; outside the planes
-// held = empty).  occ holds g.Z planes, the first owned plane is plane `halo_lo`;
-// out holds Zown planes.
-__global__ __launch_bounds__(256) void bit_surface_kernel(const unsigned long long *__restrict__ occ,
-                                                          const BitGrid g, int halo_lo, int Zown,
-                                                          unsigned long long *__restrict__ out) {
-    const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (w >= (size_t)g.XW * g.Y * Zown) return;
-    const int xw = (int)(w % g.XW);
-    const size_t row = w / g.XW;
-    const int y = (int)(row % g.Y), z = (int)(row / g.Y) + halo_lo;
-    const unsigned long long c = bit_word(occ, g, xw, y, z);
-    unsigned long long inner = c;
-    if (c) {
-        inner &= (c << 1) | (bit_word(occ, g, xw - 1, y, z) >> 63);
-        inner &= (c >> 1) | (bit_word(occ, g, xw + 1, y, z) << 63);
-        inner &= bit_word(occ, g, xw, y - 1, z) & bit_word(occ, g, xw, y + 1, z);
-        inner &= bit_word(occ, g, xw, y, z - 1) & bit_word(occ, g, xw, y, z + 1);
-    }
-    out[w] = c & ~inner;
-}
-
 // box dilation (r = radius, 1..4).  x and y in one launch: the rows y-r..y+r, each dilated along x on the way (round 4: one launch and
 // one pass over the plane less than bit_dilate_x_kernel + the y pass)
 __global__ __launch_bounds__(256) void bit_dilate_xy_kernel(const unsigned long long *__restrict__ in,
@@ -72,24 +50,6 @@ __global__ __launch_bounds__(256) void bit_dilate_xy_kernel(const unsigned long 
     }
     const int nbits = min(64, g.X - xw * 64);  // keep the padding clear
     if (nbits < 64) acc &= (1ull << nbits) - 1ull;
-    out[w] = acc;
-}
-
-// axis = 1: rows y-r..y+r ; axis = 2: planes z-r..z+r.  With `minus` the result is
-// and-ed with ~minus (the closure fills EMPTY voxels only).
-__global__ __launch_bounds__(256) void bit_dilate_yz_kernel(const unsigned long long *__restrict__ in,
-                                                            const BitGrid g, int r, int axis,
-                                                            const unsigned long long *__restrict__ minus,
-                                                            unsigned long long *__restrict__ out) {
-    const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (w >= (size_t)g.XW * g.Y * g.Z) return;
-    const int xw = (int)(w % g.XW);
-    const size_t row = w / g.XW;
-    const int y = (int)(row % g.Y), z = (int)(row / g.Y);
-    unsigned long long acc = 0ull;
-    for (int k = -r; k <= r; ++k)
-        acc |= (axis == 1) ? bit_word(in, g, xw, y + k, z) : bit_word(in, g, xw, y, z + k);
-    if (minus) acc &= ~minus[w];
     out[w] = acc;
 }
 
@@ -159,17 +119,15 @@ __global__ __launch_bounds__(256) void bit_write_kernel(const unsigned long long
     }
 }
 
-// ---- the same in ONE launch (round 4) -------------------------------------------------------
+// ---- scans in ONE launch (round 4) ------------------------------------------------------------
 //
-// bit_count_kernel -> surface_scan_kernel -> (the host reads the total and sizes the list) ->
-// bit_write_kernel were three launches and a synchronisation in the middle of every call that
-// compacts (colour pass, closure, mesh).  Here a workgroup takes a chunk of kBitChunk words by
-// TICKET, counts it, publishes the count, finds the set bits before its chunk by looking back at
-// the chunks before it (status words: tagged 8-byte granules {aggregate or inclusive prefix, tag};
-// a workgroup waits only for lower tickets, i.e. for workgroups that are running), and writes its
-// part of the list -- up to `cap` entries: the true total goes to *total (device) and to the
-// page-locked word *total_host, which the host reads at the call's ONE synchronisation; a call whose
-// list outgrew the capacity it guessed repeats the launch with room for all.
+// scan_lookback_kernel: a workgroup takes a chunk of kScanChunk entries by TICKET, sums it, publishes
+// the sum, finds the sum of the chunks before it by looking back at them (status words: tagged
+// 8-byte granules {aggregate or inclusive prefix, tag}; a workgroup waits only for lower tickets,
+// i.e. for workgroups that are running), and writes its offsets; the total goes to *total (device)
+// and to the page-locked word *total_host, which the host reads at the call's ONE synchronisation.
+// (Round 4 compacted the bit planes the same way; round 5 gave the compaction counts from the
+// plane's producer instead -- below -- because the tickets paced it.)
 // ticket_ctr: 32-bit (a 64-bit returning atomic on one word paced the launch), never reset, wraps;
 // ticket_base: the tickets all earlier launches took (modulo 2^32).
 constexpr uint32_t kCompactPrefix = 0x80000000u;  // status: the value is an inclusive prefix
@@ -191,7 +149,7 @@ __device__ __forceinline__ long long wg_scan_exclusive(long long mine, long long
     return pre;
 }
 
-// The set bits (or counts) before chunk c: wave 0 of the workgroup publishes the chunk's aggregate
+// (scan_lookback_kernel, below.)  The set bits (or counts) before chunk c: wave 0 of the workgroup publishes the chunk's aggregate
 // and looks back over the chunks before it, 64 at a time, until it meets one that has published
 // its inclusive prefix; then it publishes its own.  Returns the exclusive prefix (in every lane of
 // the wave).  A chunk only waits for lower tickets: workgroups that are running.
@@ -254,42 +212,127 @@ __device__ __forceinline__ long long lookback_exclusive(unsigned long long *__re
     return excl;
 }
 
-__global__ __launch_bounds__(256) void bit_compact_kernel(
+// ---- the compaction without tickets (round 5) ---------------------------------------------------
+//
+// Every plane that is compacted is PRODUCED by a kernel of the same call (the surface of the
+// colour pass, the closure's fill plane): that kernel now works in the compaction's own chunks of
+// kBitChunk words and leaves each chunk's number of set bits beside the plane.  The compaction then
+// needs no look-back, no status words and no ticket -- a chunk's workgroup adds up the counts of
+// the chunks before it (at most a few thousand ints from the L2) and goes straight to its words.
+// (The ticketed form was paced by its tickets: a returning atomic on one word is served every
+// ~25 ns, 13 of the kernel's 29 us at 512 chunks -- EXPERIMENTS.md rounds 4 and 5.)
+
+// the sum of one int per thread over the 256-thread workgroup, in every thread
+__device__ __forceinline__ long long wg_sum(long long mine, long long *wtot) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    if ((threadIdx.x & 63) == 0) wtot[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    const long long t = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    __syncthreads();
+    return t;
+}
+
+// surf = occupied and not inner for the planes [zlo, zhi) of the plane set (local planes of `occ`;
+// the other planes get zeros), and counts[chunk] = its set bits per chunk of kBitChunk words.
+__global__ __launch_bounds__(256) void bit_surface_count_kernel(const unsigned long long *__restrict__ occ,
+                                                                const BitGrid g, int zlo, int zhi,
+                                                                unsigned long long *__restrict__ out,
+                                                                int *__restrict__ counts) {
+    __shared__ long long wtot[4];
+    const size_t nwords = (size_t)g.XW * g.Y * g.Z;
+    const size_t base = (size_t)blockIdx.x * kBitChunk;
+    long long mine = 0;
+#pragma unroll 4
+    for (int it = 0; it < kBitChunk / 256; ++it) {
+        const size_t w = base + (size_t)it * 256 + threadIdx.x;
+        if (w >= nwords) break;
+        const int xw = (int)(w % g.XW);
+        const size_t row = w / g.XW;
+        const int y = (int)(row % g.Y), z = (int)(row / g.Y);
+        unsigned long long s = 0ull;
+        if (z >= zlo && z < zhi) {
+            const unsigned long long c = occ[w];
+            if (c) {
+                unsigned long long inner = c;
+                inner &= (c << 1) | (bit_word(occ, g, xw - 1, y, z) >> 63);
+                inner &= (c >> 1) | (bit_word(occ, g, xw + 1, y, z) << 63);
+                inner &= bit_word(occ, g, xw, y - 1, z) & bit_word(occ, g, xw, y + 1, z);
+                inner &= bit_word(occ, g, xw, y, z - 1) & bit_word(occ, g, xw, y, z + 1);
+                s = c & ~inner;
+            }
+        }
+        out[w] = s;
+        mine += __popcll(s);
+    }
+    const long long t = wg_sum(mine, wtot);
+    if (threadIdx.x == 0) counts[blockIdx.x] = (int)t;
+}
+
+// out = (OR of the planes z-r..z+r of `in`) & ~minus for the planes [zlo, zhi), zeros elsewhere;
+// counts[chunk] = its set bits (the closure's fill plane: bit_dilate_xy_kernel's output dilated
+// along z, without the voxels that are occupied already)
+__global__ __launch_bounds__(256) void bit_dilate_z_count_kernel(const unsigned long long *__restrict__ in,
+                                                                 const BitGrid g, int r,
+                                                                 const unsigned long long *__restrict__ minus,
+                                                                 int zlo, int zhi,
+                                                                 unsigned long long *__restrict__ out,
+                                                                 int *__restrict__ counts) {
+    __shared__ long long wtot[4];
+    const size_t nwords = (size_t)g.XW * g.Y * g.Z;
+    const size_t plane = (size_t)g.XW * g.Y;
+    const size_t base = (size_t)blockIdx.x * kBitChunk;
+    long long mine = 0;
+#pragma unroll 4
+    for (int it = 0; it < kBitChunk / 256; ++it) {
+        const size_t w = base + (size_t)it * 256 + threadIdx.x;
+        if (w >= nwords) break;
+        const int z = (int)(w / plane);
+        unsigned long long acc = 0ull;
+        if (z >= zlo && z < zhi) {
+            for (int k = -r; k <= r; ++k)
+                if (z + k >= 0 && z + k < g.Z) acc |= in[(size_t)((long long)w + (long long)k * (long long)plane)];
+            acc &= ~minus[w];
+        }
+        out[w] = acc;
+        mine += __popcll(acc);
+    }
+    const long long t = wg_sum(mine, wtot);
+    if (threadIdx.x == 0) counts[blockIdx.x] = (int)t;
+}
+
+// The ordered compaction of a plane whose chunk counts are known (one workgroup per chunk, in any
+// order): index[k] = flat index of the k-th set bit for k < cap, words[w] = {bits, set bits before
+// word w}; the list's length goes to *total and the page-locked *total_host.
+__global__ __launch_bounds__(256, 4) void bit_compact_counted_kernel(
     const unsigned long long *__restrict__ bits, size_t nwords, const BitGrid g,
-    unsigned *__restrict__ ticket_ctr, unsigned ticket_base,
-    unsigned long long *__restrict__ status, uint32_t tag, long long cap, int *__restrict__ index,
-    SparseWord *__restrict__ words, long long *__restrict__ total, long long *__restrict__ total_host,
-    unsigned *__restrict__ fault) {
+    const int *__restrict__ counts, long long cap, int *__restrict__ index,
+    SparseWord *__restrict__ words, long long *__restrict__ total, long long *__restrict__ total_host) {
     constexpr int kIt = kBitChunk / 256;  // words per thread: word it * 256 + thread (whole lines per wave)
     static_assert(kIt * 4 == 64, "one lane per (iteration, wave) pair below");
-    __shared__ int wtot[4];
+    __shared__ long long wtot[4];
     __shared__ int s_itw[kIt * 4];  // set bits of iteration it in wave w, at it * 4 + w
-    __shared__ int s_chunk;
-    __shared__ long long s_excl;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_chunk = (int)(atomicAdd(ticket_ctr, 1u) - ticket_base);
-    __syncthreads();
-    const int c = s_chunk;
-    const int nchunks = (int)((nwords + kBitChunk - 1) / kBitChunk);
+    const int c = blockIdx.x;
     const size_t base = (size_t)c * kBitChunk;
     unsigned long long b[kIt];
-    int mine = 0;
 #pragma unroll
     for (int it = 0; it < kIt; ++it) {
         const size_t w = base + (size_t)it * 256 + threadIdx.x;
         b[it] = (w < nwords) ? bits[w] : 0ull;
-        mine += __popcll(b[it]);
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
-    if (lane == 0) wtot[wave] = mine;
-    __syncthreads();
-    const int agg = wtot[0] + wtot[1] + wtot[2] + wtot[3];  // (< 2^19)
-    // Wave 0 looks back for the set bits before the chunk; meanwhile every wave ranks its own words:
-    // the words of one iteration are 256 consecutive ones, so a word's rank inside the chunk is the
-    // bits of the earlier iterations + those of the lower waves in its iteration + the wave's scan.
-    // (One scan per iteration across the workgroup -- two barriers each -- took most of the kernel.)
-    int before[kIt];  // set bits of the wave's lower lanes in iteration it
+    // the set bits before the chunk: the counts of the chunks before it
+    long long mine = 0;
+    for (int i = threadIdx.x; i < c; i += 256) mine += counts[i];
+    const long long excl = wg_sum(mine, wtot);
+    if (c == (int)gridDim.x - 1 && threadIdx.x == 0) {
+        const long long all = excl + counts[c];
+        *total = all;
+        if (total_host) __hip_atomic_store(total_host, all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // a word's rank inside the chunk: the bits of the earlier iterations + those of the lower waves
+    // in its iteration + the wave's scan (the words of one iteration are 256 consecutive ones)
+    int before[kIt];
 #pragma unroll
     for (int it = 0; it < kIt; ++it) {
         const int n = __popcll(b[it]);
@@ -302,17 +345,6 @@ __global__ __launch_bounds__(256) void bit_compact_kernel(
         before[it] = sc - n;
         if (lane == 63) s_itw[it * 4 + wave] = sc;
     }
-    if (wave == 0) {
-        const long long excl = lookback_exclusive(status, c, agg, tag, fault, lane);
-        if (lane == 0) {
-            s_excl = excl;
-            if (c == nchunks - 1) {
-                *total = excl + agg;
-                if (total_host)
-                    __hip_atomic_store(total_host, excl + agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
     __syncthreads();
     int pre = s_itw[lane];  // lane q = (iteration q >> 2, wave q & 3): exclusive scan in that order
     {
@@ -324,11 +356,9 @@ __global__ __launch_bounds__(256) void bit_compact_kernel(
         }
         pre -= n;
     }
-    const long long excl = s_excl;
-    // The list entries.  A lane that writes its word's entries one after the other takes as many
-    // rounds as the fullest word of the wave has bits, and every round is 64 stores to 64 different
-    // lines: words with more than kLightBits entries (faces of the model that run along x) are
-    // written by the whole wave instead -- lane j takes bit j, the entries leave as one run.
+    // The list entries: words with more than kLightBits entries (faces of the model that run along
+    // x) are written by the whole wave -- lane j takes bit j, the entries leave as one run --, the
+    // others bit by bit by their own lane.
     constexpr int kLightBits = 4;
 #pragma unroll
     for (int it = 0; it < kIt; ++it) {
