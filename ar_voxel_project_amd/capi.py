@@ -41,7 +41,8 @@ SYMBOLS = [
     "arvx_compose_projection", "arvx_set_views", "arvx_set_views_device",
     "arvx_set_images", "arvx_state_reset", "arvx_state_upload",
     "arvx_state_download", "arvx_state_device_ptr", "arvx_state_upload_halo",
-    "arvx_state_upload_planes", "arvx_state_download_planes", "arvx_host_register",
+    "arvx_state_upload_planes", "arvx_state_download_planes", "arvx_state_packet_geometry",
+    "arvx_state_download_packets", "arvx_host_register",
     "arvx_host_unregister", "arvx_handle_unseen", "arvx_undistort", "arvx_undistort_device",
     "arvx_pack_occupancy", "arvx_pack_occupancy_global", "arvx_carve", "arvx_carve_views", "arvx_fast_carve",
     "arvx_color", "arvx_surface_count", "arvx_surface_download",
@@ -127,6 +128,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     if hasattr(lib, "arvx_state_upload_planes"):
         lib.arvx_state_upload_planes.argtypes = [p, C.c_void_p, C.c_void_p]
         lib.arvx_state_download_planes.argtypes = [p, C.c_void_p, C.c_void_p]
+    if hasattr(lib, "arvx_state_download_packets"):
+        lib.arvx_state_packet_geometry.argtypes = [p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        lib.arvx_state_download_packets.argtypes = [p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.arvx_host_register.argtypes = [C.c_void_p, C.c_size_t]
         lib.arvx_host_unregister.argtypes = [C.c_void_p]
         lib.arvx_handle_unseen.argtypes = [p]
@@ -384,6 +389,35 @@ class Context:
         assert occ.size == seen.size == n and occ.dtype == seen.dtype == np.uint32
         self._ck(self._lib.arvx_state_download_planes(self._h, occ.ctypes.data, seen.ctypes.data))
         return occ, seen
+
+    def packet_geometry(self):
+        """(n, H): 64-bit words per plane of the owned voxels, header words of a state packet."""
+        n, h = C.c_int64(), C.c_int64()
+        self._ck(self._lib.arvx_state_packet_geometry(self._h, C.byref(n), C.byref(h)))
+        return int(n.value), int(h.value)
+
+    def download_packets(self, occ=None, seen=None):
+        """The owned voxels' occupancy and seen planes as compressed packets (arvx.h:
+        arvx_state_download_packets) -> (occ_packet, seen_packet, occ_need, seen_need), uint64
+        arrays of header + capacity words.  occ / seen: the caller's buffers (e.g. page-locked
+        ones); too small a buffer is reported through need > capacity and the caller asks again."""
+        n, H = self.packet_geometry()
+        if occ is None:
+            occ = np.empty(H + max(4096, n // 16), np.uint64)
+        if seen is None:
+            seen = np.empty(H + max(4096, n // 64), np.uint64)
+        for _ in range(2):
+            on, sn = C.c_int64(), C.c_int64()
+            self._ck(self._lib.arvx_state_download_packets(self._h, occ.ctypes.data, occ.size - H,
+                                                           seen.ctypes.data, seen.size - H,
+                                                           C.byref(on), C.byref(sn)))
+            if on.value <= occ.size - H and sn.value <= seen.size - H:
+                break
+            if on.value > occ.size - H:
+                occ = np.empty(H + on.value, np.uint64)
+            if sn.value > seen.size - H:
+                seen = np.empty(H + sn.value, np.uint64)
+        return occ, seen, int(on.value), int(sn.value)
 
     def upload_planes(self, occ, seen) -> None:
         occ = np.ascontiguousarray(occ, np.uint32)

@@ -184,7 +184,7 @@ static int launch_bit_pack(Ctx *ctx, const arvx::BitGrid &g, int closure_occupie
 // counts the set bits per block and scans the counts; *total = number of set bits
 static int bit_compact_count(Ctx *ctx, const unsigned long long *bits, size_t nwords, int *d_cnt,
                              long long *d_off, long long *total) {
-    const int nblk = (int)((nwords + arvx::kBitChunk - 1) / arvx::kBitChunk);
+    const int nblk = (int)((nwords + arvx::kBitBlock - 1) / arvx::kBitBlock);
     hipLaunchKernelGGL(arvx::bit_count_kernel, dim3(nblk), dim3(256), 0, ctx->stream, bits, nwords,
                        d_cnt);
     ARVX_HIP(hipGetLastError());
@@ -259,7 +259,7 @@ static int scan_counts(Ctx *ctx, const int *counts, const int4 *cells, long long
 // the kernels that follow) and in the page-locked ctx->h_totals[slot], which the caller reads after
 // its synchronisation.
 static int bit_compact(Ctx *ctx, const unsigned long long *bits, size_t nwords, const arvx::BitGrid &g,
-                       const int *counts, long long cap, int *d_index, arvx::SparseWord *d_words, int slot,
+                       long long cap, int *d_index, arvx::SparseWord *d_words, int slot,
                        const long long **d_total_out) {
     const size_t nchunks = (nwords + arvx::kBitChunk - 1) / arvx::kBitChunk;
     uint8_t *base = nullptr;
@@ -267,18 +267,34 @@ static int bit_compact(Ctx *ctx, const unsigned long long *bits, size_t nwords, 
     if (int rc = compact_control(ctx, 0, &base, &status)) return rc;  // (the device totals live there)
     long long *d_total = (long long *)(base + 8 + 8 * slot);
     ctx->h_totals[slot] = -1;
+    // the counts the producer has just left in buffer `counts_cur`; the other buffer is cleared for
+    // the next producer on the way
+    int *cur = (int *)ctx->pool_chunk_counts.p + (size_t)ctx->counts_cur * ctx->counts_stride;
+    int *other = (int *)ctx->pool_chunk_counts.p + (size_t)(ctx->counts_cur ^ 1) * ctx->counts_stride;
     hipLaunchKernelGGL(arvx::bit_compact_counted_kernel, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream,
-                       bits, nwords, g, counts, cap, d_index, d_words, d_total, ctx->d_totals_host + slot);
+                       bits, nwords, g, (const int *)cur, other, cap, d_index, d_words, d_total,
+                       ctx->d_totals_host + slot);
     ARVX_HIP(hipGetLastError());
+    ctx->counts_clean[ctx->counts_cur ^ 1] = true;
     if (d_total_out) *d_total_out = d_total;
     return ARVX_OK;
 }
-// room for the chunk counts of a plane of nwords words
-static int chunk_counts(Ctx *ctx, size_t nwords, int **counts, unsigned *nchunks) {
+// The count buffer the NEXT plane's producer adds into (zeroed): the two buffers take turns -- the
+// compaction that reads one clears the other --, so a call costs no fill launch of its own.
+static int chunk_counts(Ctx *ctx, size_t nwords, int **counts) {
     const size_t n = (nwords + arvx::kBitChunk - 1) / arvx::kBitChunk;
-    ARVX_HIP(ctx->pool_chunk_counts.reserve(n * sizeof(int)));
-    *counts = (int *)ctx->pool_chunk_counts.p;
-    *nchunks = (unsigned)n;
+    if (ctx->counts_stride < n || !ctx->pool_chunk_counts.p) {
+        ARVX_HIP(ctx->pool_chunk_counts.reserve(2 * n * sizeof(int)));
+        ctx->counts_stride = n;
+        ctx->counts_clean[0] = ctx->counts_clean[1] = false;
+    }
+    const int k = ctx->counts_cur ^ 1;
+    int *buf = (int *)ctx->pool_chunk_counts.p + (size_t)k * ctx->counts_stride;
+    if (!ctx->counts_clean[k])  // (first use, or a call that failed between producer and compaction)
+        ARVX_HIP(hipMemsetAsync(buf, 0, ctx->counts_stride * sizeof(int), ctx->stream));
+    ctx->counts_clean[k] = false;  // the producer is about to add into it
+    ctx->counts_cur = k;
+    *counts = buf;
     return ARVX_OK;
 }
 
@@ -301,7 +317,7 @@ static long long host_total(Ctx *ctx, int slot) {
 static int bit_compact_write(Ctx *ctx, const unsigned long long *bits, size_t nwords,
                              const arvx::BitGrid &g, const long long *d_off, int *d_index,
                              arvx::SparseWord *d_words) {
-    const int nblk = (int)((nwords + arvx::kBitChunk - 1) / arvx::kBitChunk);
+    const int nblk = (int)((nwords + arvx::kBitBlock - 1) / arvx::kBitBlock);
     hipLaunchKernelGGL(arvx::bit_write_kernel, dim3(nblk), dim3(256), 0, ctx->stream, bits, nwords,
                        g, d_off, d_index, d_words);
     ARVX_HIP(hipGetLastError());
@@ -857,6 +873,7 @@ static int need_rec(Ctx *ctx, bool lazy_ok) {
 // every call that changes occupied / seen bits goes through here: results derived from the
 // old state are dropped
 static void state_changes(Ctx *ctx, bool keeps_paint) {
+    ++ctx->state_seq;
     ctx->color_ready = false;
     ctx->closure_ready = false;
     if (!keeps_paint) ctx->paint_valid = false;
@@ -998,18 +1015,88 @@ int arvx_state_download_planes(arvx_ctx *ctx, uint32_t *occ, uint32_t *seen) {
     return ARVX_OK;
 }
 
+int arvx_state_packet_geometry(arvx_ctx *ctx, int64_t *words64, int64_t *header_words) {
+    if (!ctx || !words64 || !header_words) return fail(ARVX_ERR_INVALID, "null argument");
+    const size_t plane = (size_t)ctx->X * ctx->Y;
+    if (ctx->X % 32 || plane % 64)
+        return fail(ARVX_ERR_INVALID, "state packets need X %% 32 == 0 and X*Y %% 64 == 0 (X=%d, Y=%d)", ctx->X,
+                    ctx->Y);
+    const long long n = (long long)(plane / 64) * (ctx->z1 - ctx->z0);
+    if (2 * n >= (1ll << 32)) return fail(ARVX_ERR_INVALID, "slab too large for state packets (%lld words)", n);
+    *words64 = n;
+    *header_words = arvx::occ_packet_header(n);
+    return ARVX_OK;
+}
+
+int arvx_state_download_packets(arvx_ctx *ctx, uint64_t *occ_packet, int64_t occ_cap, uint64_t *seen_packet,
+                                int64_t seen_cap, int64_t *occ_need, int64_t *seen_need) {
+    ARVX_CHECK_CTX(ctx);
+    if (!occ_packet || !seen_packet || !occ_need || !seen_need || occ_cap < 0 || seen_cap < 0)
+        return fail(ARVX_ERR_INVALID, "bad argument");
+    int64_t n64 = 0, H64 = 0;
+    if (int rc = arvx_state_packet_geometry(ctx, &n64, &H64)) return rc;
+    const long long n = n64, H = H64, nb = (n + 63) / 64;
+    // the two packets at their worst-case size stay on the device until the state changes: a caller
+    // whose buffers were too small asks again and only the copies run
+    const size_t S = (size_t)(H + n);
+    if (!(ctx->packets_seq == ctx->state_seq && ctx->packets_valid && ctx->pool_state_packets.cap >= 2 * S * 8)) {
+        if (int mrc = need_rec(ctx, true)) return mrc;
+        ARVX_HIP(ctx->pool_state_packets.reserve(2 * S * 8));
+        arvx::CarveParams g;
+        carve_geometry(ctx, g);
+        g.rec = ctx->d_rec;
+        const int zl0 = ctx->z0 - ctx->ze0;
+        const int nwg = (int)((nb + arvx::kOccGroupsPerWg - 1) / arvx::kOccGroupsPerWg);
+        arvx::OccGeom og;
+        og.wpr = arvx::fast_div((unsigned)(ctx->X / 32));
+        og.Y = arvx::fast_div((unsigned)ctx->Y);
+        og.P64 = arvx::fast_div((unsigned)((size_t)ctx->X * ctx->Y / 64));
+        if (int rc = ensure_scratch(ctx, 2 * (size_t)nwg * sizeof(int) + 64)) return rc;
+        int *d_wgsum = (int *)ctx->d_scratch;
+        unsigned long long *pk = (unsigned long long *)ctx->pool_state_packets.p;
+        hipLaunchKernelGGL(arvx::occ_pack_classify_kernel<false>, dim3(nwg), dim3(256), 0, ctx->stream, g, og,
+                           zl0, n, pk, d_wgsum, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL(arvx::occ_pack_classify_kernel<true>, dim3(nwg), dim3(256), 0, ctx->stream, g, og,
+                           zl0, n, pk + S, d_wgsum + nwg, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL(arvx::occ_pack_write_kernel<false>, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0,
+                           ctx->stream, g, og, zl0, n, n, d_wgsum, nwg, pk);
+        hipLaunchKernelGGL(arvx::occ_pack_write_kernel<true>, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0,
+                           ctx->stream, g, og, zl0, n, n, d_wgsum + nwg, nwg, pk + S);
+        ARVX_HIP(hipGetLastError());
+        // the two counts first (16 bytes through the page-locked totals: slots 4 and 5)
+        ARVX_HIP(hipMemcpyAsync(ctx->h_totals + 4, pk, 8, hipMemcpyDeviceToHost, ctx->stream));
+        ARVX_HIP(hipMemcpyAsync(ctx->h_totals + 5, pk + S, 8, hipMemcpyDeviceToHost, ctx->stream));
+        ARVX_SYNC(ctx);
+        ctx->packet_need[0] = ctx->h_totals[4];
+        ctx->packet_need[1] = ctx->h_totals[5];
+        ctx->packets_seq = ctx->state_seq;
+        ctx->packets_valid = true;
+    }
+    const unsigned long long *pk = (const unsigned long long *)ctx->pool_state_packets.p;
+    *occ_need = ctx->packet_need[0];
+    *seen_need = ctx->packet_need[1];
+    ARVX_HIP(hipMemcpyAsync(occ_packet, pk, (size_t)(H + std::min<long long>(*occ_need, occ_cap)) * 8,
+                            hipMemcpyDeviceToHost, ctx->stream));
+    ARVX_HIP(hipMemcpyAsync(seen_packet, pk + S, (size_t)(H + std::min<long long>(*seen_need, seen_cap)) * 8,
+                            hipMemcpyDeviceToHost, ctx->stream));
+    ARVX_SYNC(ctx);
+    return ARVX_OK;
+}
+
 int arvx_handle_unseen(arvx_ctx *ctx) {
     ARVX_CHECK_CTX(ctx);
     // (coarse tiles that exist only as their code stay codes: "carved and seen", "untouched and
     // seen" and "untouched, not seen" are all unchanged by occ |= ~seen -- the records behind a
     // code are not read by anybody)
     if (int mrc = need_rec(ctx, true)) return mrc;
+    ++ctx->state_seq;
     ctx->closure_ready = false;  // (colours and paint stay: only never-seen voxels change)
     arvx::CarveParams g;
     carve_geometry(ctx, g);
     const size_t nrec = arvx::rec_count(g);
     hipLaunchKernelGGL(arvx::rec_handle_unseen_kernel, dim3((unsigned)((nrec * 32 + 255) / 256)),
-                       dim3(256), 0, ctx->stream, (uint32_t *)ctx->d_rec, nrec);
+                       dim3(256), 0, ctx->stream, (uint32_t *)ctx->d_rec, nrec, g.ccode,
+                       g.cyShift + g.czShift + 2);
     ARVX_HIP(hipGetLastError());
     return ARVX_OK;
 }
@@ -1407,10 +1494,6 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         ((flags & ARVX_CARVE_STREAM) || (stream_default && (size_t)p.X * p.Y * p.Z >= ((size_t)1 << 26))) &&
         arvx::rec_count(p) < ((size_t)1 << 30) && p.tilesX < 65536 && p.tilesY < 65536 && p.tilesZ < 65536)
         return launch_carve_stream(ctx, p, ncu);
-#else
-    if (flags & ARVX_CARVE_STREAM)
-        return fail(ARVX_ERR_INVALID, "ARVX_CARVE_STREAM: the one-launch carve is only in -DARVX_EXPERIMENTS "
-                                      "builds (libarvx_experiments.so)");
 #endif
     if (cull) {
         const size_t words = ncoarse * p.nchunks;
@@ -1625,6 +1708,11 @@ int arvx_carve_views(arvx_ctx *ctx, int first, int count, unsigned flags) {
         return fail(ARVX_ERR_INVALID, "view range [%d,%d) outside [0,%d)", first, first + count,
                     ctx->V);
     if (count == 0) return ARVX_OK;
+#ifndef ARVX_EXPERIMENTS
+    if (flags & ARVX_CARVE_STREAM)  // (refused before anything about the context changes)
+        return fail(ARVX_ERR_INVALID, "ARVX_CARVE_STREAM: the one-launch carve is only in -DARVX_EXPERIMENTS "
+                                      "builds (libarvx_experiments.so)");
+#endif
     state_changes(ctx, false);
     const bool fresh = ctx->fresh_pending;
     if (fresh) {  // the kernels write every record of the grid; nothing is read
@@ -1762,10 +1850,9 @@ int arvx_color(arvx_ctx *ctx, int mode) {
     // the surface plane of the planes [c_lo, c_hi) (zeros elsewhere) and, per chunk of the
     // compaction, its number of set bits
     int *d_counts = nullptr;
-    unsigned nchunks = 0;
-    if (int rc = chunk_counts(ctx, nw_ext, &d_counts, &nchunks)) return rc;
-    hipLaunchKernelGGL(arvx::bit_surface_count_kernel, dim3(nchunks), dim3(256), 0, ctx->stream, d_occ, gext,
-                       c_lo - ctx->ze0, c_hi - ctx->ze0, d_surf, d_counts);
+    if (int rc = chunk_counts(ctx, nw_ext, &d_counts)) return rc;
+    hipLaunchKernelGGL(arvx::bit_surface_count_kernel, dim3((unsigned)((nw_ext + 255) / 256)), dim3(256), 0,
+                       ctx->stream, d_occ, gext, c_lo - ctx->ze0, c_hi - ctx->ze0, d_surf, d_counts);
     ARVX_HIP(hipGetLastError());
     // The list's length is not known before the compaction has run: the buffers are sized for what
     // the last pass needed (first call: a surface's share of the voxels), the kernels stop at that
@@ -1787,7 +1874,7 @@ int arvx_color(arvx_ctx *ctx, int mode) {
         ARVX_HIP(ctx->pool_surf_has.reserve((size_t)cap));
         ctx->d_surf_has = (uint8_t *)ctx->pool_surf_has.p;
         const long long *d_total = nullptr;
-        if (int rc = bit_compact(ctx, d_surf, nw_ext, gext, d_counts, cap, ctx->d_surf_index,
+        if (int rc = bit_compact(ctx, d_surf, nw_ext, gext, cap, ctx->d_surf_index,
                                  (arvx::SparseWord *)ctx->pool_col_rank.p, 0, &d_total))
             return rc;
         arvx::VoteParams vp;
@@ -2180,7 +2267,7 @@ int arvx_colors_upload(arvx_ctx *ctx, int64_t n, const int64_t *index, const flo
         const int XW = (ctx->X + 63) / 64;
         const arvx::BitGrid gown{ctx->X, ctx->Y, ctx->ze1 - ctx->ze0, XW};  // the context's planes
         const size_t nw = (size_t)XW * gown.Y * gown.Z;
-        const int nblk = (int)((nw + arvx::kBitChunk - 1) / arvx::kBitChunk);
+        const int nblk = (int)((nw + arvx::kBitBlock - 1) / arvx::kBitBlock);
         ARVX_HIP(ctx->pool_col_bits.reserve(nw * sizeof(unsigned long long)));
         ARVX_HIP(ctx->pool_col_rank.reserve(nw * sizeof(arvx::SparseWord)));
         if (int rc = ensure_scratch(ctx, (size_t)(nblk + 1) * sizeof(long long) +
@@ -2231,7 +2318,7 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
         return fail(ARVX_ERR_STATE,
                     "a slab needs %d halo planes for a closure of size %d (it has %d): "
                     "arvx_ctx_create_slab_halo", radius + 1, kernel_size, ctx->halo);
-    if (int mrc = need_rec(ctx, true)) return mrc;  // (every kernel below knows the lazy codes)
+    if (int mrc = need_rec(ctx)) return mrc;  // (rec_or_bitgrid_kernel writes into records: all must exist)
     ctx->free_closure();
     // filled = dilate(occupied, box of radius r) and not occupied, on bit planes over the
     // context's planes
@@ -2255,9 +2342,8 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     // (halo planes outside [f_lo, f_hi): their boxes reach planes this context knows nothing
     // about -- not filled here, their owners do it: zeros)
     int *d_counts = nullptr;
-    unsigned nchunks = 0;
-    if (int rc = chunk_counts(ctx, nwords, &d_counts, &nchunks)) return rc;
-    hipLaunchKernelGGL(arvx::bit_dilate_z_count_kernel, dim3(nchunks), dim3(256), 0, ctx->stream, d_b, g,
+    if (int rc = chunk_counts(ctx, nwords, &d_counts)) return rc;
+    hipLaunchKernelGGL(arvx::bit_dilate_z_count_kernel, dim3(gw), dim3(256), 0, ctx->stream, d_b, g,
                        radius, (const unsigned long long *)d_occ, f_lo - ctx->ze0, f_hi - ctx->ze0, d_fill,
                        d_counts);
     ARVX_HIP(hipGetLastError());
@@ -2279,7 +2365,7 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
         ARVX_HIP(ctx->pool_clo_rgba.reserve((size_t)cap * sizeof(float4)));
         ctx->d_clo_rgba = (void *)ctx->pool_clo_rgba.p;
         const long long *d_total = nullptr;
-        if (int rc = bit_compact(ctx, d_fill, nwords, g, d_counts, cap, ctx->d_clo_index,
+        if (int rc = bit_compact(ctx, d_fill, nwords, g, cap, ctx->d_clo_index,
                                  (arvx::SparseWord *)ctx->pool_clo_rank.p, 1, &d_total))
             return rc;
         arvx::ClosureParams cp;
@@ -2299,15 +2385,11 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
                                (float4 *)ctx->d_clo_rgba);
         ARVX_HIP(hipGetLastError());
         if (attempt == 0) {
+            ++ctx->state_seq;
             // the filled voxels are occupied from now on (their w is count / count = 1); the fill
             // kernel reads the occupancy from the bit planes, not from the records
-            if (ctx->lazy)  // (tiles that exist only as their code and receive a voxel are written out)
-                hipLaunchKernelGGL(arvx::rec_or_bitgrid_lazy_kernel,
-                                   dim3((unsigned)((size_t)rp.coarseX * rp.coarseY * rp.coarseZ)), dim3(256), 0,
-                                   ctx->stream, rp, (const unsigned long long *)d_fill, (uint8_t *)ctx->pool_ccode.p);
-            else
-                hipLaunchKernelGGL(arvx::rec_or_bitgrid_kernel, dim3(gw), dim3(256), 0, ctx->stream, rp, 0,
-                                   g.Z, d_fill);
+            hipLaunchKernelGGL(arvx::rec_or_bitgrid_kernel, dim3(gw), dim3(256), 0, ctx->stream, rp, 0,
+                               g.Z, d_fill);
             ARVX_HIP(hipGetLastError());
         }
         ARVX_SYNC(ctx);

@@ -65,7 +65,12 @@ struct Ctx {
     // what the host keeps beside it.  h_totals: page-locked words behind the fault word that the
     // kernels write the lists' lengths to (read at the call's one synchronisation).
     DevPool pool_compact;
-    DevPool pool_chunk_counts;  // set bits per kBitChunk words of the plane being compacted
+    // set bits per kBitChunk words of the plane being compacted: two buffers of counts_stride
+    // ints used in turn (the compaction that reads one zeroes the other: arvx_capi.hip, chunk_counts)
+    DevPool pool_chunk_counts;
+    size_t counts_stride = 0;
+    int counts_cur = 0;
+    bool counts_clean[2] = {false, false};
     unsigned long long compact_tickets = 0;  // tickets all launches so far have taken
     uint32_t compact_epoch = 0;
     long long *h_totals = nullptr, *d_totals_host = nullptr;  // 6 slots (host / device address)
@@ -84,6 +89,13 @@ struct Ctx {
     uint16_t *d_rec = nullptr;   // records of planes ze0..ze1-1 (+ padding to whole coarse tiles)
     size_t rec_bytes = 0;
     bool rec_valid = false;      // d_rec holds the current state (else: fresh_pending)
+    // every call that changes occupied / seen bits counts here: what was derived from the state
+    // (the host hand-off's packets) is current while the count it was taken at still stands
+    unsigned long long state_seq = 1;
+    DevPool pool_state_packets;  // arvx_state_download_packets: occupancy | seen, worst-case size each
+    unsigned long long packets_seq = 0;
+    bool packets_valid = false;
+    long long packet_need[2] = {0, 0};
     // lazy state (arvx_device.h): after the carve of a fresh model the coarse tiles it settled
     // as a whole exist only as their code in `ccode`; their records are not written
     DevPool pool_ccode;
@@ -191,6 +203,9 @@ struct Ctx {
         vstrip_key = 0;
         pool_compact.release();
         pool_chunk_counts.release();
+        counts_stride = 0;
+        pool_state_packets.release();
+        packets_valid = false;
         compact_tickets = 0;
         pool_paint.release();
         pool_ccode.release();

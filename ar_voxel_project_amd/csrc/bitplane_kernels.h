@@ -55,14 +55,14 @@ __global__ __launch_bounds__(256) void bit_dilate_xy_kernel(const unsigned long 
 
 // ---- ordered compaction of the set bits ------------------------------------------------
 
-constexpr int kBitChunk = 4096;  // words per workgroup
+constexpr int kBitBlock = 4096;  // words per workgroup of the three-launch form (arvx_colors_upload)
 
 __global__ __launch_bounds__(256) void bit_count_kernel(const unsigned long long *__restrict__ bits,
                                                         size_t nwords, int *__restrict__ counts) {
     __shared__ int wsum[4];
-    const size_t base = (size_t)blockIdx.x * kBitChunk;
+    const size_t base = (size_t)blockIdx.x * kBitBlock;
     int mine = 0;
-    for (int it = 0; it < kBitChunk / 256; ++it) {
+    for (int it = 0; it < kBitBlock / 256; ++it) {
         const size_t w = base + (size_t)it * 256 + threadIdx.x;
         if (w < nwords) mine += __popcll(bits[w]);
     }
@@ -87,10 +87,10 @@ __global__ __launch_bounds__(256) void bit_write_kernel(const unsigned long long
                                                         int *__restrict__ index,
                                                         SparseWord *__restrict__ words) {
     __shared__ int wtot[4];
-    const size_t base = (size_t)blockIdx.x * kBitChunk;
+    const size_t base = (size_t)blockIdx.x * kBitBlock;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     long long run = offsets[blockIdx.x];
-    for (int it = 0; it < kBitChunk / 256; ++it) {
+    for (int it = 0; it < kBitBlock / 256; ++it) {
         const size_t w = base + (size_t)it * 256 + threadIdx.x;
         unsigned long long b = (w < nwords) ? bits[w] : 0ull;
         const int n = __popcll(b);
@@ -215,14 +215,16 @@ __device__ __forceinline__ long long lookback_exclusive(unsigned long long *__re
 // ---- the compaction without tickets (round 5) ---------------------------------------------------
 //
 // Every plane that is compacted is PRODUCED by a kernel of the same call (the surface of the
-// colour pass, the closure's fill plane): that kernel now works in the compaction's own chunks of
-// kBitChunk words and leaves each chunk's number of set bits beside the plane.  The compaction then
-// needs no look-back, no status words and no ticket -- a chunk's workgroup adds up the counts of
-// the chunks before it (at most a few thousand ints from the L2) and goes straight to its words.
-// (The ticketed form was paced by its tickets: a returning atomic on one word is served every
-// ~25 ns, 13 of the kernel's 29 us at 512 chunks -- EXPERIMENTS.md rounds 4 and 5.)
+// colour pass, the closure's fill plane): that kernel -- one word per thread, as before -- also
+// adds each wave's set bits to the count of its chunk of kBitChunk words.  The compaction then needs
+// no look-back, no status words and no ticket: a chunk's workgroup adds up the counts of the chunks
+// before it (a few thousand ints from the L2) and goes straight to its words.  (The ticketed form
+// was paced by its tickets: a returning atomic on one word is served every ~25 ns, 13 of the kernel's
+// 29 us at 512 chunks -- EXPERIMENTS.md rounds 4 and 5.)  The counts live in two buffers used in
+// turn: the compaction that reads one zeroes the other for the next producer.
+constexpr int kBitChunk = 1024;  // words per workgroup of the compaction (kIt = 4 per thread)
 
-// the sum of one int per thread over the 256-thread workgroup, in every thread
+// the sum of one value per thread over the 256-thread workgroup, in every thread
 __device__ __forceinline__ long long wg_sum(long long mine, long long *wtot) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
@@ -232,25 +234,27 @@ __device__ __forceinline__ long long wg_sum(long long mine, long long *wtot) {
     __syncthreads();
     return t;
 }
+// a wave's 64 consecutive words (one per lane, all inside one chunk) counted into their chunk
+__device__ __forceinline__ void chunk_count_add(int *__restrict__ counts, size_t w, int bits_set) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) bits_set += __shfl_xor(bits_set, d);
+    if ((threadIdx.x & 63) == 0 && bits_set) atomicAdd(counts + w / kBitChunk, bits_set);
+}
 
-// surf = occupied and not inner for the planes [zlo, zhi) of the plane set (local planes of `occ`;
-// the other planes get zeros), and counts[chunk] = its set bits per chunk of kBitChunk words.
+// surf = occupied and not inner (all six neighbours occupied; outside the planes held = empty) for
+// the planes [zlo, zhi) of the plane set (local planes of `occ`; the other planes get zeros), and
+// counts[chunk] += its set bits.  One word per thread; the grid covers whole waves.
 __global__ __launch_bounds__(256) void bit_surface_count_kernel(const unsigned long long *__restrict__ occ,
                                                                 const BitGrid g, int zlo, int zhi,
                                                                 unsigned long long *__restrict__ out,
                                                                 int *__restrict__ counts) {
-    __shared__ long long wtot[4];
     const size_t nwords = (size_t)g.XW * g.Y * g.Z;
-    const size_t base = (size_t)blockIdx.x * kBitChunk;
-    long long mine = 0;
-#pragma unroll 4
-    for (int it = 0; it < kBitChunk / 256; ++it) {
-        const size_t w = base + (size_t)it * 256 + threadIdx.x;
-        if (w >= nwords) break;
+    const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long s = 0ull;
+    if (w < nwords) {
         const int xw = (int)(w % g.XW);
         const size_t row = w / g.XW;
         const int y = (int)(row % g.Y), z = (int)(row / g.Y);
-        unsigned long long s = 0ull;
         if (z >= zlo && z < zhi) {
             const unsigned long long c = occ[w];
             if (c) {
@@ -263,14 +267,12 @@ __global__ __launch_bounds__(256) void bit_surface_count_kernel(const unsigned l
             }
         }
         out[w] = s;
-        mine += __popcll(s);
     }
-    const long long t = wg_sum(mine, wtot);
-    if (threadIdx.x == 0) counts[blockIdx.x] = (int)t;
+    chunk_count_add(counts, w, __popcll(s));
 }
 
 // out = (OR of the planes z-r..z+r of `in`) & ~minus for the planes [zlo, zhi), zeros elsewhere;
-// counts[chunk] = its set bits (the closure's fill plane: bit_dilate_xy_kernel's output dilated
+// counts[chunk] += its set bits (the closure's fill plane: bit_dilate_xy_kernel's output dilated
 // along z, without the voxels that are occupied already)
 __global__ __launch_bounds__(256) void bit_dilate_z_count_kernel(const unsigned long long *__restrict__ in,
                                                                  const BitGrid g, int r,
@@ -278,38 +280,31 @@ __global__ __launch_bounds__(256) void bit_dilate_z_count_kernel(const unsigned 
                                                                  int zlo, int zhi,
                                                                  unsigned long long *__restrict__ out,
                                                                  int *__restrict__ counts) {
-    __shared__ long long wtot[4];
     const size_t nwords = (size_t)g.XW * g.Y * g.Z;
     const size_t plane = (size_t)g.XW * g.Y;
-    const size_t base = (size_t)blockIdx.x * kBitChunk;
-    long long mine = 0;
-#pragma unroll 4
-    for (int it = 0; it < kBitChunk / 256; ++it) {
-        const size_t w = base + (size_t)it * 256 + threadIdx.x;
-        if (w >= nwords) break;
+    const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long acc = 0ull;
+    if (w < nwords) {
         const int z = (int)(w / plane);
-        unsigned long long acc = 0ull;
         if (z >= zlo && z < zhi) {
             for (int k = -r; k <= r; ++k)
                 if (z + k >= 0 && z + k < g.Z) acc |= in[(size_t)((long long)w + (long long)k * (long long)plane)];
             acc &= ~minus[w];
         }
         out[w] = acc;
-        mine += __popcll(acc);
     }
-    const long long t = wg_sum(mine, wtot);
-    if (threadIdx.x == 0) counts[blockIdx.x] = (int)t;
+    chunk_count_add(counts, w, __popcll(acc));
 }
 
 // The ordered compaction of a plane whose chunk counts are known (one workgroup per chunk, in any
 // order): index[k] = flat index of the k-th set bit for k < cap, words[w] = {bits, set bits before
-// word w}; the list's length goes to *total and the page-locked *total_host.
-__global__ __launch_bounds__(256, 4) void bit_compact_counted_kernel(
+// word w}; the list's length goes to *total and the page-locked *total_host.  zero_next: the other
+// count buffer, cleared for the next producer.
+__global__ __launch_bounds__(256) void bit_compact_counted_kernel(
     const unsigned long long *__restrict__ bits, size_t nwords, const BitGrid g,
-    const int *__restrict__ counts, long long cap, int *__restrict__ index,
+    const int *__restrict__ counts, int *__restrict__ zero_next, long long cap, int *__restrict__ index,
     SparseWord *__restrict__ words, long long *__restrict__ total, long long *__restrict__ total_host) {
     constexpr int kIt = kBitChunk / 256;  // words per thread: word it * 256 + thread (whole lines per wave)
-    static_assert(kIt * 4 == 64, "one lane per (iteration, wave) pair below");
     __shared__ long long wtot[4];
     __shared__ int s_itw[kIt * 4];  // set bits of iteration it in wave w, at it * 4 + w
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -324,12 +319,7 @@ __global__ __launch_bounds__(256, 4) void bit_compact_counted_kernel(
     // the set bits before the chunk: the counts of the chunks before it
     long long mine = 0;
     for (int i = threadIdx.x; i < c; i += 256) mine += counts[i];
-    const long long excl = wg_sum(mine, wtot);
-    if (c == (int)gridDim.x - 1 && threadIdx.x == 0) {
-        const long long all = excl + counts[c];
-        *total = all;
-        if (total_host) __hip_atomic_store(total_host, all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (threadIdx.x == 0) zero_next[c] = 0;
     // a word's rank inside the chunk: the bits of the earlier iterations + those of the lower waves
     // in its iteration + the wave's scan (the words of one iteration are 256 consecutive ones)
     int before[kIt];
@@ -345,26 +335,28 @@ __global__ __launch_bounds__(256, 4) void bit_compact_counted_kernel(
         before[it] = sc - n;
         if (lane == 63) s_itw[it * 4 + wave] = sc;
     }
-    __syncthreads();
-    int pre = s_itw[lane];  // lane q = (iteration q >> 2, wave q & 3): exclusive scan in that order
-    {
-        const int n = pre;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(pre, d);
-            if (lane >= d) pre += t;
-        }
-        pre -= n;
+    const long long excl = wg_sum(mine, wtot);  // (its barriers also publish s_itw)
+    if (c == (int)gridDim.x - 1 && threadIdx.x == 0) {
+        const long long all = excl + counts[c];
+        *total = all;
+        if (total_host) __hip_atomic_store(total_host, all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // The list entries: words with more than kLightBits entries (faces of the model that run along
     // x) are written by the whole wave -- lane j takes bit j, the entries leave as one run --, the
     // others bit by bit by their own lane.
     constexpr int kLightBits = 4;
+    int pre = 0;  // set bits of the chunk before (iteration it, this wave)
 #pragma unroll
     for (int it = 0; it < kIt; ++it) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < wave) pre += s_itw[it * 4 + q];
         const size_t w = base + (size_t)it * 256 + threadIdx.x;
         unsigned long long bw = b[it];
-        int slot = (int)(excl + __builtin_amdgcn_readlane(pre, it * 4 + wave) + before[it]);  // (< 2^31)
+        int slot = (int)(excl + pre + before[it]);  // (< 2^31)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q >= wave) pre += s_itw[it * 4 + q];
         if (words && w < nwords) words[w] = SparseWord{bw, slot, 0};
         if (!index) continue;
         const size_t row = w / g.XW;

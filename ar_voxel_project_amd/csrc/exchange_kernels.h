@@ -129,7 +129,9 @@ struct OccGeom {
     FastDiv P64;     // 64-bit words per plane
 };
 
-// 64-bit word i of the rank's planes in local order (planes zl0 .. zl0 + nz - 1); 2 i + 1 < 2^32
+// 64-bit word i of the rank's planes in local order (planes zl0 .. zl0 + nz - 1); 2 i + 1 < 2^32.
+// SEEN: the records' seen bits instead of their occupancy (the host hand-off ships both planes).
+template <bool SEEN = false>
 __device__ __forceinline__ unsigned long long occ_word_from_rec(const CarveParams &p, const OccGeom &og,
                                                                 int zl0, unsigned i) {
     unsigned long long w = 0;
@@ -143,12 +145,17 @@ __device__ __forceinline__ unsigned long long occ_word_from_rec(const CarveParam
         const int r = (z & 7) * 8 + (y & 7);
         const int code = lazy_code(p, k >> 1, y >> 3, z >> 3);
         uint32_t e;
-        if (code) {
+        // (X % 32 == 0: every voxel of a 32-bit word lies inside the grid, where the records'
+        // "outside = seen" convention does not reach)
+        if (code && SEEN) {
+            e = lazy_seen(p, code, k >> 1, y >> 3, z >> 3, (k & 1) * 2, r) |
+                (lazy_seen(p, code, k >> 1, y >> 3, z >> 3, (k & 1) * 2 + 1, r) << 16);
+        } else if (code) {
             e = lazy_occ(p, code, k >> 1, y >> 3, z >> 3, (k & 1) * 2, r) |
                 (lazy_occ(p, code, k >> 1, y >> 3, z >> 3, (k & 1) * 2 + 1, r) << 16);
         } else {
             const uint16_t *rec = p.rec + rec_index(p, k >> 1, y >> 3, z >> 3, (k & 1) * 2) * kRecU16;
-            e = (uint32_t)rec[r] | ((uint32_t)rec[kRecU16 + r] << 16);
+            e = (uint32_t)rec[(SEEN ? 64 : 0) + r] | ((uint32_t)rec[kRecU16 + (SEEN ? 64 : 0) + r] << 16);
         }
         w |= (unsigned long long)e << (32 * h);
     }
@@ -162,6 +169,7 @@ __device__ __forceinline__ long long occ_global_index(const CarveParams &p, cons
 }
 
 // occ_classify_kernel on records (same packet fields), + the rank's own words into `full`
+template <bool SEEN = false>
 __global__ __launch_bounds__(256) void occ_pack_classify_kernel(const CarveParams p, const OccGeom og,
                                                                 int zl0, long long n,
                                                                 unsigned long long *__restrict__ out,
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256) void occ_pack_classify_kernel(const CarveParam
         const long long i = (g0 + it) * 64 + lane;
         unsigned long long w = 0ull;  // (a word past n reads as 0: neither all-one nor mixed)
         if (i < n) {
-            w = occ_word_from_rec(p, og, zl0, (unsigned)i);
+            w = occ_word_from_rec<SEEN>(p, og, zl0, (unsigned)i);
             if (full) __builtin_nontemporal_store(w, full + occ_global_index(p, og, zl0, (unsigned)i));
         }
         const unsigned long long ones = __ballot(w == ~0ull);
@@ -201,6 +209,7 @@ __global__ __launch_bounds__(256) void occ_pack_classify_kernel(const CarveParam
 
 // occ_write_kernel with the workgroup offsets summed here (four groups per workgroup: one
 // classify workgroup's) and the mixed words taken from the records
+template <bool SEEN = false>
 __global__ __launch_bounds__(256) void occ_pack_write_kernel(const CarveParams p, const OccGeom og,
                                                              int zl0, long long n,
                                                              long long cap,
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(256) void occ_pack_write_kernel(const CarveParams p
     const long long i = g * 64 + lane;
     unsigned long long w = 0;
     const bool take = (mixed >> lane) & 1ull;
-    if (take) w = occ_word_from_rec(p, og, zl0, (unsigned)i);
+    if (take) w = occ_word_from_rec<SEEN>(p, og, zl0, (unsigned)i);
     if (lane == 0) goff[g] = (unsigned)off;
     if (take) {
         const long long at = off + __popcll(mixed & ((1ull << lane) - 1ull));

@@ -267,52 +267,16 @@ __global__ __launch_bounds__(256) void rec_or_bitgrid_kernel(const CarveParams p
     }
 }
 
-// The same where coarse tiles may exist only as their code (lazy state, arvx_device.h): one
-// workgroup per coarse tile.  A tile with a code that receives no bit stays a code; one that
-// receives bits gets all its records written -- the code's constants with the bits on top -- and
-// its code cleared (`ccode` is the context's code array, written here); a tile without a code
-// gets the bits OR-ed in as above.
-__global__ __launch_bounds__(256) void rec_or_bitgrid_lazy_kernel(const CarveParams p,
-                                                                  const unsigned long long *__restrict__ bits,
-                                                                  uint8_t *__restrict__ ccode) {
-    const int XW = (p.X + 63) >> 6;
-    const int ct = blockIdx.x;
-    const int cx = ct % p.coarseX, cy = (ct / p.coarseX) % p.coarseY, cz = ct / (p.coarseX * p.coarseY);
-    const int ny = 8 << p.cyShift, nz = 8 << p.czShift;  // rows of the coarse tile
-    const int code = ccode ? (int)ccode[ct] : 0;
-    // pass 1: does the tile receive a bit?  (4 rows per thread at 64 x 32 x 32)
-    int any = 0;
-    for (int r = threadIdx.x; r < ny * nz; r += 256) {
-        const int y = cy * ny + (r % ny), z = cz * nz + (r / ny);
-        if (y < p.Y && z < p.Z && bits[((size_t)z * p.Y + y) * XW + cx]) any = 1;
-    }
-    any = __syncthreads_or(any);
-    if (!any) return;
-    for (int r = threadIdx.x; r < ny * nz; r += 256) {
-        const int y = cy * ny + (r % ny), z = cz * nz + (r / ny);
-        const unsigned long long w = (y < p.Y && z < p.Z) ? bits[((size_t)z * p.Y + y) * XW + cx] : 0ull;
-        if (!code && !w) continue;
-        const int ty = y >> 3, tz = z >> 3, e = (z & 7) * 8 + (y & 7);
-        uint16_t *rec = p.rec + rec_index(p, cx, ty, tz, 0) * kRecU16;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint16_t f = (uint16_t)(w >> (16 * k));
-            if (code) {
-                rec[k * kRecU16 + e] = (uint16_t)(lazy_occ(p, code, cx, ty, tz, k, e) | f);
-                rec[k * kRecU16 + 64 + e] = (uint16_t)lazy_seen(p, code, cx, ty, tz, k, e);
-            } else if (f) {
-                rec[k * kRecU16 + e] |= f;
-            }
-        }
-    }
-    if (code && threadIdx.x == 0) ccode[ct] = 0;  // (read by the launches that follow)
-}
-
-// Model::handleUnseen on records: occ |= ~seen (voxels outside the grid are kept "seen")
-__global__ __launch_bounds__(256) void rec_handle_unseen_kernel(uint32_t *__restrict__ rec32,
-                                                                size_t nrec) {
+// Model::handleUnseen on records: occ |= ~seen (voxels outside the grid are kept "seen").  The
+// records of a coarse tile that exists only as its code (ccode, may be null; 2^rec_shift records
+// per coarse tile) are nobody's to read: skipped -- "carved and seen", "untouched and seen" and
+// "untouched, not seen" all stay what they are under occ |= ~seen.
+__global__ __launch_bounds__(256) void rec_handle_unseen_kernel(uint32_t *__restrict__ rec32, size_t nrec,
+                                                                const uint8_t *__restrict__ ccode,
+                                                                int rec_shift) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;  // record t / 32, word t % 32
     if (t >= nrec * 32) return;
+    if (ccode && ccode[(t >> 5) >> rec_shift]) return;
     uint32_t *r = rec32 + (t >> 5) * 64 + (t & 31);
     r[0] |= ~r[32];
 }

@@ -876,41 +876,77 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_e2e:
         # SURVEY 8d's second figure: the step with its inputs coming from and its result going to
-        # the HOST -- page-locked u8 masks -> device (arvx_set_views), carve, the carved model's two
-        # bit planes (N / 4 bytes) back into page-locked memory (arvx_state_download_planes)
+        # the HOST -- page-locked u8 masks -> device (arvx_set_views), carve, the carved model back
+        # in page-locked memory: as two compressed packets (arvx_state_download_packets; ~1/10 of the
+        # bytes) and, beside it, as two plain bit planes (N / 4 bytes, arvx_state_download_planes)
         def e2e_entry(N):
             sc_ = synthetic.sphere_scene(N, args.views)
             masks = torch.from_numpy(sc_.masks).pin_memory()
             words = ((N + 31) // 32) * N * N
             occ = torch.empty(words, dtype=torch.int32).pin_memory()
             seen = torch.empty(words, dtype=torch.int32).pin_memory()
-            ms = []
+            res = {}
             with capi.Context(N, N, N, sc_.voxel_size, device=dev.index) as c:
                 mnp = masks.numpy()
-                for _ in range(8):
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    c.reset()
-                    c.set_views(sc_.M, mnp)
-                    t1 = time.perf_counter()
-                    c.carve(0)
-                    c.synchronize()
-                    t2 = time.perf_counter()
-                    c.download_planes(occ.numpy().view(np.uint32), seen.numpy().view(np.uint32))
-                    t3 = time.perf_counter()
-                    ms.append(((t3 - t0) * 1e3, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
-            a = np.array(ms[3:])  # (the first rounds pay the first uses: staging buffers, pools)
+                n64, H = c.packet_geometry()
+                # the packets' host buffers, sized by one untimed hand-off (a caller keeps them
+                # from frame to frame: arvx::Model does)
+                c.set_views(sc_.M, mnp)
+                c.carve(0)
+                _, _, need_o, need_s = c.download_packets()
+                pk_o = torch.empty(H + need_o + need_o // 8, dtype=torch.int64).pin_memory()
+                pk_s = torch.empty(H + need_s + need_s // 8 + 16, dtype=torch.int64).pin_memory()
+                for form in ("packets", "planes"):
+                    ms = []
+                    for _ in range(8):
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        c.reset()
+                        c.set_views(sc_.M, mnp)
+                        t1 = time.perf_counter()
+                        c.carve(0)
+                        c.synchronize()
+                        t2 = time.perf_counter()
+                        if form == "packets":
+                            po, ps, no, ns = c.download_packets(pk_o.numpy().view(np.uint64),
+                                                                pk_s.numpy().view(np.uint64))
+                        else:
+                            c.download_planes(occ.numpy().view(np.uint32), seen.numpy().view(np.uint32))
+                        t3 = time.perf_counter()
+                        ms.append(((t3 - t0) * 1e3, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
+                    a = np.array(ms[3:])  # (the first rounds pay the first uses: staging buffers, pools)
+                    res[form] = a
+                # the two forms hold the same model (untimed): every mixed word at its place, the
+                # bitmaps against the planes' all-zero / all-one words
+                o64, s64 = occ.numpy().view(np.uint64), seen.numpy().view(np.uint64)
+                same = True
+                for pk, pl, need in ((po, o64, no), (ps, s64, ns)):
+                    nb = (n64 + 63) // 64
+                    ones = np.unpackbits(pk[1:1 + nb].view(np.uint8), bitorder="little")[:n64].astype(bool)
+                    mixed = np.unpackbits(pk[1 + nb:1 + 2 * nb].view(np.uint8), bitorder="little")[:n64].astype(bool)
+                    full = np.where(ones, np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64(0))
+                    full[mixed] = pk[H:H + need]
+                    same = same and int(pk[0]) == need == int(mixed.sum()) and bool(np.array_equal(full, pl))
+            a = res["packets"]
             tot = float(np.median(a[:, 0]))
+            pl = res["planes"]
             return {"grid": [N, N, N], "views": args.views, "ms_total": tot,
                     "ms_masks_h2d_and_views": float(np.median(a[:, 1])),
                     "ms_carve": float(np.median(a[:, 2])),
-                    "ms_planes_d2h": float(np.median(a[:, 3])),
+                    "ms_model_d2h": float(np.median(a[:, 3])),
                     "value": N ** 3 * args.views / (tot * 1e-3) / 1e6, "unit": "Mvoxel-views/s",
-                    "bytes_h2d": int(sc_.masks.nbytes), "bytes_d2h": int(2 * words * 4)}
+                    "bytes_h2d": int(sc_.masks.nbytes),
+                    "bytes_d2h": int(8 * (2 * H + need_o + need_s)),
+                    "packets_equal_planes": same,
+                    "planes_form": {"ms_total": float(np.median(pl[:, 0])),
+                                    "ms_planes_d2h": float(np.median(pl[:, 3])),
+                                    "bytes_d2h": int(2 * words * 4)}}
         try:
-            out["e2e"] = {"what": "page-locked host masks -> arvx_set_views -> arvx_carve -> "
-                                  "arvx_state_download_planes into page-locked memory; median of 5 "
-                                  "rounds after 3 warm ones; never part of `value`",
+            out["e2e"] = {"what": "page-locked host masks -> arvx_set_views -> arvx_carve -> the carved "
+                                  "model (occupancy + seen) into page-locked memory as compressed packets "
+                                  "(arvx_state_download_packets: what arvx::Model reads; `planes_form`: "
+                                  "the same as two plain bit planes, arvx_state_download_planes); median "
+                                  "of 5 rounds after 3 warm ones; never part of `value`",
                           "runs": [e2e_entry(args.grid)] +
                                   ([e2e_entry(args.extra_grid)] if args.extra_grid and
                                    args.extra_grid != args.grid else [])}

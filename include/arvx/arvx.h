@@ -210,6 +210,25 @@ int arvx_state_download(arvx_ctx *ctx, uint8_t *state);
  * voxel) and the host-side arvx::Model mirrors, so a carve result crosses PCIe as N / 4 bytes. */
 int arvx_state_upload_planes(arvx_ctx *ctx, const uint32_t *occ, const uint32_t *seen);
 int arvx_state_download_planes(arvx_ctx *ctx, uint32_t *occ, uint32_t *seen);
+/* The same two planes of the owned voxels as compressed PACKETS -- what a carved model mostly is:
+ * long runs of empty space (all-zero words), solid interior (all-one words) and a thin shell of
+ * mixed words.  The planes are read as 64-bit words in flat order (bit i % 64 of word i / 64 =
+ * voxel i = x + X * (y + Y * z), z relative to the first owned plane; needs X % 32 == 0 and
+ * X * Y % 64 == 0), and a packet is the layout of arvx_occupancy_compress (below):
+ *   [0] number of mixed words   [1, 1+nb) bitmap of the all-one words   [1+nb, 1+2nb) bitmap of the
+ *   mixed words   [1+2nb, H) per group of 64 words the number of mixed words before it (u32)
+ *   [H, H+need) the mixed words in order           nb = ceil(n / 64), H = 1 + 2 nb + ceil(nb / 2)
+ * so a reader finds word i without expanding anything: all-one / mixed by its bit in group i / 64,
+ * a mixed word at H + offset[group] + popcount(mixed bits below it).  1024^3 sphere: 24 MB instead of
+ * 268 MB across PCIe.  arvx_state_packet_geometry: n (words64) and H (header_words).
+ * arvx_state_download_packets: each host buffer has room for H + cap words; *need = the packet's
+ * number of mixed words.  A packet that needed more than its cap is copied up to the cap only: call
+ * again with larger buffers -- the device keeps both packets while the state is unchanged, so the
+ * second call only copies.  Host side: include/arvx/model.hpp answers get / isInner / visited
+ * straight from the packets. */
+int arvx_state_packet_geometry(arvx_ctx *ctx, int64_t *words64, int64_t *header_words);
+int arvx_state_download_packets(arvx_ctx *ctx, uint64_t *occ_packet, int64_t occ_cap, uint64_t *seen_packet,
+                                int64_t seen_cap, int64_t *occ_need, int64_t *seen_need);
 /* Model::handleUnseen() on the device state (reference src/Model.cpp:36-47): every voxel that
  * no view saw becomes occupied (the reference paints it UNSEEN_COLOR, w = 1); seen bits stay. */
 int arvx_handle_unseen(arvx_ctx *ctx);

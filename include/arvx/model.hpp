@@ -137,7 +137,7 @@ class Model {
     Vec4f get(int x, int y, int z) const {  // src/Model.h:119-124: zero outside the grid
         if (x < 0 || x >= size_x || y < 0 || y >= size_y || z < 0 || z >= size_z)
             return Vec4f(0, 0, 0, 0);
-        sync_host();
+        sync_bits();
         const int i = flatten(x, y, z);
         if (!overlay_.empty()) {  // what set() stored, exactly
             auto it = overlay_.find(i);
@@ -145,7 +145,7 @@ class Model {
         }
         const size_t w = word(x, y, z);
         const uint32_t b = 1u << (x & 31);
-        if (!(occ_[w] & b)) return Vec4f(0, 0, 0, 0);  // carved (src/VoxelCarving.cpp:52)
+        if (!occ_bit(x, y, z)) return Vec4f(0, 0, 0, 0);  // carved (src/VoxelCarving.cpp:52)
         if (!paint_.empty() && (paint_[w] & b)) return unseen_color();
         if (!fidx_.empty()) {  // filled by the closure (newer than the colour pass's list)
             auto it = std::lower_bound(fidx_.begin(), fidx_.end(), i);
@@ -214,8 +214,8 @@ class Model {
     }
     void visit(Vec3i v) { see(v(0), v(1), v(2)); }  // :154-156
     bool visited(Vec3i v) const {                   // :158-160
-        sync_host();
-        return (seen_[word(v(0), v(1), v(2))] >> (v(0) & 31)) & 1u;
+        sync_bits();
+        return seen_bit(v(0), v(1), v(2));
     }
 
     // src/Model.cpp:36-47: every voxel that no view saw becomes UNSEEN_COLOR (204, 0, 0, 1) --
@@ -438,7 +438,7 @@ class Model {
     // explicit colours of occupied, unpainted voxels, ascending flat index
     // (for arvx_colors_upload); false if one of them has w != 1 (the device list holds RGB only)
     bool sorted_colors(std::vector<int64_t> &index, std::vector<float> &rgb) const {
-        sync_host();
+        sync_bits();
         std::vector<std::pair<int, Vec4f>> extra(overlay_.begin(), overlay_.end());
         std::sort(extra.begin(), extra.end(),
                   [](const std::pair<int, Vec4f> &a, const std::pair<int, Vec4f> &b) {
@@ -451,7 +451,7 @@ class Model {
             const int x = i % size_x, y = (i / size_x) % size_y, z = i / (size_x * size_y);
             const size_t w = word(x, y, z);
             const uint32_t b = 1u << (x & 31);
-            if (!(occ_[w] & b) || (!paint_.empty() && (paint_[w] & b))) return;
+            if (!occ_bit(x, y, z) || (!paint_.empty() && (paint_[w] & b))) return;
             if (v == model_color()) return;  // what the state alone says
             if (v.w() != 1.f) plain = false;
             index.push_back(i);
@@ -527,15 +527,45 @@ class Model {
     uint32_t *seen_plane_for_writing() { return seen_.data(); }
     void planes_replaced() { host_changed(); }
 
-    // bring the host planes up to date with the device (no-op when they are)
-    void sync_host() const {
+    // Bring the host's knowledge of the state up to date with the device (no-op when it is).
+    // Where the grid allows it (X % 32 == 0, X * Y % 64 == 0) the state crosses PCIe as two
+    // compressed PACKETS (arvx_state_download_packets: bitmaps of the all-one and the mixed 64-bit
+    // words + the mixed words; a carved 1024^3 model is 24 MB instead of the planes' 268 MB) and the
+    // accessors answer from them -- get / isInner / visited cost one bitmap look-up and at most one
+    // more word; the planes are rebuilt from the packets only when somebody needs them as planes
+    // (sync_host: a host-side write, an upload, a copy).
+    void sync_bits() const {
         if (!host_stale_) return;
         host_stale_ = false;
-        detail::check(arvx_state_download_planes(link_->ctx, occ_.data(), seen_.data()),
-                      "arvx_state_download_planes");
+        int64_t n64 = 0, H = 0;
+        if (size_x % 32 == 0 && ((size_t)size_x * size_y) % 64 == 0 &&
+            arvx_state_packet_geometry(link_->ctx, &n64, &H) == ARVX_OK) {
+            pk_n_ = n64;
+            pk_H_ = H;
+            // room for what the last hand-off needed (first: a shell's share of the words)
+            if (pk_occ_.size() < (size_t)H + 1024) pk_occ_.resize((size_t)(H + std::max<int64_t>(1024, n64 / 16)));
+            if (pk_seen_.size() < (size_t)H + 1024) pk_seen_.resize((size_t)(H + std::max<int64_t>(1024, n64 / 64)));
+            for (int attempt = 0;; ++attempt) {
+                int64_t on = 0, sn = 0;
+                detail::check(arvx_state_download_packets(link_->ctx, pk_occ_.data(), (int64_t)pk_occ_.size() - H,
+                                                          pk_seen_.data(), (int64_t)pk_seen_.size() - H,
+                                                          &on, &sn),
+                              "arvx_state_download_packets");
+                if ((on <= (int64_t)pk_occ_.size() - H && sn <= (int64_t)pk_seen_.size() - H) || attempt) break;
+                // (the device kept the packets: the second call only copies)
+                if (on > (int64_t)pk_occ_.size() - H) pk_occ_.resize((size_t)(H + on + on / 8));
+                if (sn > (int64_t)pk_seen_.size() - H) pk_seen_.resize((size_t)(H + sn + sn / 8));
+            }
+            planes_stale_ = true;
+        } else {
+            detail::check(arvx_state_download_planes(link_->ctx, occ_.data(), seen_.data()),
+                          "arvx_state_download_planes");
+            planes_stale_ = false;
+        }
         Model *self = const_cast<Model *>(this);
-        if (paint_pending_) {
+        if (paint_pending_) {  // (the paint plane is derived from the seen PLANE)
             paint_pending_ = false;
+            expand_planes();
             self->paint_unseen_host();
         }
         // what set() stored for a voxel that the device has carved since is gone
@@ -543,17 +573,30 @@ class Model {
         for (auto it = self->overlay_.begin(); it != self->overlay_.end();) {
             const int i = it->first;
             const int x = i % size_x, y = (i / size_x) % size_y, z = i / (size_x * size_y);
-            const bool o = (occ_[word(x, y, z)] >> (x & 31)) & 1u;
-            if (it->second.w() != 0 && !o) it = self->overlay_.erase(it);
+            if (it->second.w() != 0 && !occ_bit(x, y, z)) it = self->overlay_.erase(it);
             else ++it;
         }
     }
+    // ... and the two bit PLANES current as well (everything that reads or writes them as arrays)
+    void sync_host() const {
+        sync_bits();
+        expand_planes();
+    }
+    // does the host hold the state as packets only right now?  (tests, tools/dropin_times)
+    bool planes_pending() const { return planes_stale_; }
+    size_t packet_bytes() const { return planes_stale_ ? 8 * (size_t)(2 * pk_H_ + (int64_t)pk_occ_[0] + (int64_t)pk_seen_[0]) : 0; }
 
    private:
     const int size_x, size_y, size_z;
     const float voxel_size;
     const int wpr_;  // 32-bit words per voxel row
     mutable std::vector<uint32_t> occ_, seen_;  // bit planes, rows padded to words
+    // the same two planes as the device's compressed packets (include/arvx/arvx.h,
+    // arvx_state_download_packets), in recycled page-locked memory; planes_stale_: the packets are
+    // what is current, occ_ / seen_ are rebuilt from them on demand (expand_planes)
+    mutable HostVector<uint64_t> pk_occ_, pk_seen_;
+    mutable int64_t pk_n_ = 0, pk_H_ = 0;
+    mutable bool planes_stale_ = false;
     mutable std::vector<uint32_t> paint_;       // painted UNSEEN_COLOR (empty: none)
     bool pristine_ = true;
     bool paint_is_unseen_ = false;
@@ -581,8 +624,57 @@ class Model {
     }
     bool occ(int x, int y, int z) const {
         if (x < 0 || x >= size_x || y < 0 || y >= size_y || z < 0 || z >= size_z) return false;
-        sync_host();
+        sync_bits();
+        return occ_bit(x, y, z);
+    }
+    // one voxel's bit from a packet: its 64-bit word is all-one, or mixed (then it is the
+    // popcount-th mixed word of its group of 64 words), or all-zero
+    static bool packet_bit(const uint64_t *pk, int64_t n, int64_t H, size_t i) {
+        const int64_t nb = (n + 63) / 64;
+        const size_t W = i >> 6, g = W >> 6;
+        const unsigned b = (unsigned)(W & 63);
+        if ((pk[1 + g] >> b) & 1u) return true;
+        const uint64_t m = pk[1 + nb + g];
+        if (!((m >> b) & 1u)) return false;
+        const uint32_t *goff = reinterpret_cast<const uint32_t *>(pk + 1 + 2 * nb);
+        const uint64_t w = pk[H + goff[g] + (uint32_t)__builtin_popcountll(m & ((1ull << b) - 1ull))];
+        return (w >> (i & 63)) & 1u;
+    }
+    // (in-grid voxel; after sync_bits)
+    bool occ_bit(int x, int y, int z) const {
+        if (planes_stale_) return packet_bit(pk_occ_.data(), pk_n_, pk_H_, (size_t)flatten(x, y, z));
         return (occ_[word(x, y, z)] >> (x & 31)) & 1u;
+    }
+    bool seen_bit(int x, int y, int z) const {
+        if (planes_stale_) return packet_bit(pk_seen_.data(), pk_n_, pk_H_, (size_t)flatten(x, y, z));
+        return (seen_[word(x, y, z)] >> (x & 31)) & 1u;
+    }
+    // packets -> planes (X % 32 == 0: the planes' 32-bit words are the packets' 64-bit words in halves)
+    void expand_planes() const {
+        if (!planes_stale_) return;
+        planes_stale_ = false;
+        const int64_t n = pk_n_, nb = (n + 63) / 64, H = pk_H_;
+        for (int which = 0; which < 2; ++which) {
+            const uint64_t *pk = which ? pk_seen_.data() : pk_occ_.data();
+            uint32_t *out = which ? seen_.data() : occ_.data();
+            const uint32_t *goff = reinterpret_cast<const uint32_t *>(pk + 1 + 2 * nb);
+            for (int64_t g = 0; g < nb; ++g) {
+                const uint64_t ones = pk[1 + g], mixed = pk[1 + nb + g];
+                const uint64_t *mw = pk + H + goff[g];
+                const int64_t w0 = g * 64, w1 = std::min<int64_t>(w0 + 64, n);
+                if (!mixed && (ones == 0 || (ones == ~0ull && w1 - w0 == 64))) {  // a uniform group
+                    std::fill(out + 2 * w0, out + 2 * w1, ones ? 0xffffffffu : 0u);
+                    continue;
+                }
+                for (int64_t w = w0; w < w1; ++w) {
+                    const unsigned b = (unsigned)(w - w0);
+                    uint64_t v = ((ones >> b) & 1u) ? ~0ull : 0ull;
+                    if ((mixed >> b) & 1u) v = *mw++;
+                    out[2 * w] = (uint32_t)v;
+                    out[2 * w + 1] = (uint32_t)(v >> 32);
+                }
+            }
+        }
     }
     // merge a sorted list into the colour list, the new values win
     void merge_into_colors(const HostVector<int> &idx, const HostVector<Vec4f> &val) {

@@ -169,6 +169,35 @@ static int run_carve(const char *scene, const char *out, const char *mode) {
             model.handleUnseen();
             if (!model.WriteModel(std::string(out) + ".off")) return 12;
             if (model.WriteModel("/nonexistent-dir/x.off")) return 13;
+        } else if (!std::strcmp(mode, "packets")) {
+            // The carved model reaches the host as two compressed packets (Model::sync_bits) where
+            // the grid allows it; the accessors must answer from them exactly what they answer
+            // from the planes, which exist only after somebody asks for them as planes.
+            arvx::carve(intr, model, views);
+            const size_t N = (size_t)X * Y * Z;
+            std::vector<uint8_t> a(N), b(N);
+            auto sweep = [&](std::vector<uint8_t> &dst) {
+                for (int z = 0; z < Z; ++z)
+                    for (int y = 0; y < Y; ++y)
+                        for (int x = 0; x < X; ++x)
+                            dst[(size_t)x + (size_t)X * (y + (size_t)Y * z)] =
+                                (uint8_t)((model.get(x, y, z)(3) != 0) | (model.isInner(x, y, z) << 1) |
+                                          (model.visited(Vec3i(x, y, z)) << 2));
+            };
+            sweep(a);
+            if (!model.planes_pending() || model.packet_bytes() == 0) return 14;  // (answered from packets)
+            const uint32_t *po = model.occ_plane(), *ps = model.seen_plane();  // now as planes
+            if (model.planes_pending()) return 15;
+            sweep(b);
+            if (a != b) return 16;
+            std::vector<uint32_t> qo(model.plane_words()), qs(model.plane_words());
+            if (arvx_state_download_planes(model.device_if_any(), qo.data(), qs.data()) != ARVX_OK) return 17;
+            if (std::memcmp(qo.data(), po, qo.size() * 4) || std::memcmp(qs.data(), ps, qs.size() * 4)) return 18;
+            // a host-side write goes to the planes, the next carve brings packets again
+            model.set(1, 1, 1, Vec4f(0, 0, 0, 0));
+            arvx::carve(intr, model, views);
+            if (model.get(1, 1, 1)(3) != 0 || !model.planes_pending()) return 19;
+            model.handleUnseen();  // (on the device; the paint plane is derived at the next sync)
         } else if (!std::strcmp(mode, "threads")) {
             // several jobs in flight from several host threads: every thread owns its models
             // (contexts share nothing; calls on ONE context are not thread safe, calls on

@@ -45,6 +45,8 @@ def test_one_gpu_line():
     t = d["throughput_jobs_in_flight"]
     assert t["jobs"] == 4 and t["slots_agree"] is True and t["value"] > 0
     assert d["e2e"]["runs"][0]["ms_total"] > 0 and d["e2e"]["runs"][0]["bytes_h2d"] > 0
+    assert d["e2e"]["runs"][0]["packets_equal_planes"] is True
+    assert d["e2e"]["runs"][0]["bytes_d2h"] < d["e2e"]["runs"][0]["planes_form"]["bytes_d2h"]
     assert d["parity_vs_oracle"] is True
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["latency_ms_per_step"] > 0
     assert d["roofline"]["kernel_ms"] > 0 and d["cpu_baseline"]["value"] > 0

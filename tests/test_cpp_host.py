@@ -117,6 +117,31 @@ def test_cpp_entry_points_match_oracle(host_bin, oracle, tmp_path, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("X,Y,Z", [(64, 24, 12), (32, 2, 2), (96, 64, 40)])
+def test_cpp_model_answers_from_packets(host_bin, oracle, tmp_path, X, Y, Z):
+    """A grid with X % 32 == 0 and X * Y % 64 == 0: the carved model crosses PCIe as compressed
+    packets (arvx_state_download_packets) and Model::get / isInner / visited answer from them;
+    the binary checks the accessor sweep against the plane form and the C-ABI's planes, this test
+    the final model against the oracle (reference src/Model.h:119-160, src/Model.cpp:36-47)."""
+    V = 5
+    sc = scenes.syn.sphere_scene(32, V, W=96, H=72, with_images=True)
+    s = np.float32(0.512 / max(X, Y, Z))
+    rng = np.random.default_rng(3)
+    st0 = np.where(rng.random((Z, Y, X)) < 0.05, 0, 1).astype(np.uint8)
+    scene, out = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
+    write_scene(scene, X, Y, Z, s, sc.K, sc.Rt, sc.masks, sc.images, st0)
+    r = subprocess.run([host_bin, "carve", scene, out, "packets"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    rgba, seen = read_result(out, X * Y * Z)
+    M = oracle.compose(sc.K, sc.Rt)
+    st0[1, 1, 1] &= 0xfe  # the binary's set(1, 1, 1, zero) between its two carves
+    st = oracle.carve(X, Y, Z, s, M, sc.masks, state=st0)
+    want = oracle.handle_unseen(st, oracle.model_from_state(st))
+    assert np.array_equal(seen, (st.reshape(-1) & 2) == 2)
+    assert np.array_equal(rgba, want)
+
+
+@pytest.mark.gpu
 def test_cpp_debug_mesh(host_bin, oracle, tmp_path):
     """Model::WriteModel (reference src/Model.cpp:49-107): a cube per voxel that is there and not
     inner, x outermost, in the voxel's colour -- the text restated here from the oracle's model."""
