@@ -234,11 +234,13 @@ __device__ __forceinline__ long long wg_sum(long long mine, long long *wtot) {
     __syncthreads();
     return t;
 }
-// a wave's 64 consecutive words (one per lane, all inside one chunk) counted into their chunk
+// a workgroup's 256 consecutive words (one per thread, all inside one chunk) counted into their
+// chunk: ONE atomic per workgroup (one per wave cost the producers 4 us at 512^3)
 __device__ __forceinline__ void chunk_count_add(int *__restrict__ counts, size_t w, int bits_set) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) bits_set += __shfl_xor(bits_set, d);
-    if ((threadIdx.x & 63) == 0 && bits_set) atomicAdd(counts + w / kBitChunk, bits_set);
+    __shared__ long long s_cnt[4];
+    static_assert(kBitChunk % 256 == 0, "a workgroup's words lie in one chunk");
+    const long long t = wg_sum(bits_set, s_cnt);
+    if (threadIdx.x == 0 && t) atomicAdd(counts + w / kBitChunk, (int)t);
 }
 
 // surf = occupied and not inner (all six neighbours occupied; outside the planes held = empty) for
