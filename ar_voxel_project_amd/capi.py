@@ -22,6 +22,7 @@ CARVE_NO_CULL = 1
 CARVE_STATS = 2
 CARVE_FUSED = 8
 CARVE_STREAM = 16
+CARVE_FILTER = 64
 CARVE_NO_STREAM = 32
 # test plumbing: flags OR-ed into every carve of this process, e.g. ARVX_CARVE_EXTRA_FLAGS=16 runs a
 # whole test module with the streaming carve forced on every fresh model (the library itself reads

@@ -136,6 +136,13 @@ static int check_fault(Ctx *ctx) {
     ctx->vstrip_key = 0;   // the ticket counters no longer match the launches: start over
     ctx->carve_layout = 0;
     ctx->stream_layout = 0;
+    // (the scans' tickets and status granules too: a chunk that gave up published a prefix under a
+    // valid tag -- the control block is zeroed again at its next use)
+    ctx->pool_compact.release();
+    ctx->compact_tickets = 0;
+    ctx->compact_epoch = 0;
+    ctx->counts_clean[0] = ctx->counts_clean[1] = false;
+    ctx->packets_valid = false;
     return fail(ARVX_ERR_HIP, "a kernel gave up waiting for another workgroup (mark %u): the "
                 "results of the calls since the last synchronisation are undefined", what);
 }
@@ -529,6 +536,16 @@ int arvx_ctx_set_exchange_stream(arvx_ctx *ctx, void *hip_stream) {
     ctx->xstream = (hipStream_t)hip_stream;
     return ARVX_OK;
 }
+
+#ifdef ARVX_EXPERIMENTS
+// Experiment builds only (tests/test_fault_gpu.py): leave the mark a kernel leaves when it gives up
+// waiting for another workgroup, as if the launches since the last synchronisation had done so.
+extern "C" int arvx_experiment_mark_fault(arvx_ctx *ctx, unsigned mark) {
+    if (!ctx || !ctx->h_fault) return fail(ARVX_ERR_INVALID, "null context");
+    *ctx->h_fault = mark;
+    return ARVX_OK;
+}
+#endif
 
 int arvx_ctx_synchronize(arvx_ctx *ctx) {
     ARVX_CHECK_CTX(ctx);
@@ -1653,7 +1670,28 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
 #endif
         const bool left = ctx->assoc == ARVX_ASSOC_LEFT;
         const bool may_split = p.flags & 8u;
-        if (blocks && left && may_split)
+        // the fp32 filter in front of the exact projection (carve_kernels.h, filtered_view_blocks):
+        // for callers whose masks leave most blocks of an item to be projected (ARVX_CARVE_FILTER)
+        const bool filter = (flags & ARVX_CARVE_FILTER) != 0;
+        if (blocks && filter && left && may_split)
+            hipLaunchKernelGGL((arvx::carve_exact_blocks_kernel<true, true, false, true>), dim3(pgrid), dim3(256), 0,
+                               ctx->stream, p);
+        else if (blocks && filter && left && fresh)
+            hipLaunchKernelGGL((arvx::carve_exact_blocks_kernel<true, false, true, true>), dim3(pgrid), dim3(256), 0,
+                               ctx->stream, p);
+        else if (blocks && filter && left)
+            hipLaunchKernelGGL((arvx::carve_exact_blocks_kernel<true, false, false, true>), dim3(pgrid), dim3(256), 0,
+                               ctx->stream, p);
+        else if (blocks && filter && may_split)
+            hipLaunchKernelGGL((arvx::carve_exact_blocks_kernel<false, true, false, true>), dim3(pgrid), dim3(256), 0,
+                               ctx->stream, p);
+        else if (blocks && filter && fresh)
+            hipLaunchKernelGGL((arvx::carve_exact_blocks_kernel<false, false, true, true>), dim3(pgrid), dim3(256), 0,
+                               ctx->stream, p);
+        else if (blocks && filter)
+            hipLaunchKernelGGL((arvx::carve_exact_blocks_kernel<false, false, false, true>), dim3(pgrid), dim3(256), 0,
+                               ctx->stream, p);
+        else if (blocks && left && may_split)
             hipLaunchKernelGGL((arvx::carve_exact_blocks_kernel<true, true>), dim3(pgrid), dim3(256), 0,
                                ctx->stream, p);
         else if (blocks && left && fresh)
@@ -2318,7 +2356,10 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
         return fail(ARVX_ERR_STATE,
                     "a slab needs %d halo planes for a closure of size %d (it has %d): "
                     "arvx_ctx_create_slab_halo", radius + 1, kernel_size, ctx->halo);
-    if (int mrc = need_rec(ctx)) return mrc;  // (rec_or_bitgrid_kernel writes into records: all must exist)
+    // (the planes are built from the lazy form; the tiles that exist only as a code are written out
+    // further down, just before rec_or_bitgrid_kernel needs every record to exist -- written out
+    // first, their non-temporal stores had emptied the caches of the records the planes are built from)
+    if (int mrc = need_rec(ctx, true)) return mrc;
     ctx->free_closure();
     // filled = dilate(occupied, box of radius r) and not occupied, on bit planes over the
     // context's planes
@@ -2385,7 +2426,9 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
                                (float4 *)ctx->d_clo_rgba);
         ARVX_HIP(hipGetLastError());
         if (attempt == 0) {
+            if (int mrc = need_rec(ctx)) return mrc;  // every record exists from here on
             ++ctx->state_seq;
+            state_rewritten(ctx);  // (before any exit: voxels of tiles an earlier carve emptied may be occupied again)
             // the filled voxels are occupied from now on (their w is count / count = 1); the fill
             // kernel reads the occupancy from the bit planes, not from the records
             hipLaunchKernelGGL(arvx::rec_or_bitgrid_kernel, dim3(gw), dim3(256), 0, ctx->stream, rp, 0,
@@ -2398,7 +2441,6 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
         if (total <= cap || attempt) break;
         cap = total + total / 8;  // (once more, with room for all)
     }
-    if (total > 0) state_rewritten(ctx);  // (voxels of tiles an earlier carve emptied may be occupied again)
     ctx->clo_count = total;
     ctx->clo_host_count = -1;  // the list's host copy is fetched when somebody asks
     if (total == 0) {

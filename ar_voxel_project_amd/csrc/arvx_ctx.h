@@ -55,7 +55,9 @@ struct Ctx {
     // Kernels that wait for other workgroups inside a launch (views_strip_kernel, the streaming
     // carve) give up after seconds and leave a mark here instead of hanging the device: one word of
     // page-locked host memory the device writes directly, read by the host after its next
-    // synchronisation (arvx_capi.hip, check_fault).  Never seen set outside fault-injection tests.
+    // synchronisation (arvx_capi.hip, check_fault).  Never seen set by a kernel; the host's side of
+    // it -- the call fails, the next one starts from clean control blocks -- is exercised by
+    // tests/test_fault_gpu.py through the experiment build's arvx_experiment_mark_fault.
     unsigned *h_fault = nullptr;  // host address
     unsigned *d_fault = nullptr;  // the same word as the device sees it
     DevPool pool_vstrip;          // views_strip_kernel: ticket counters + published column counts

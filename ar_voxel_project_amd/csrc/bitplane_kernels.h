@@ -208,7 +208,13 @@ __device__ __forceinline__ long long lookback_exclusive(unsigned long long *__re
             }
         }
     }
-    if (lane == 0) granule_store(status + c, (uint32_t)(excl + agg) | kCompactPrefix, tag);
+    if (lane == 0) {
+        // the granules carry prefixes in 31 bits: a total that does not fit is reported like a
+        // give-up (mark 7: the host fails the call at its synchronisation) instead of wrapping
+        if ((unsigned long long)(excl + agg) >= (unsigned long long)kCompactPrefix && fault)
+            __hip_atomic_store(fault, 7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        granule_store(status + c, (uint32_t)(excl + agg) | kCompactPrefix, tag);
+    }
     return excl;
 }
 

@@ -1529,6 +1529,161 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
     return __all(st[0] == kDone4 && st[1] == kDone4 && st[2] == kDone4 && st[3] == kDone4);
 }
 
+// ---- the fp32 filter (round 5) -----------------------------------------------------------------
+//
+// A voxel's pixel is (round(u), round(v)) of the reference's u = fl32(a0 / a2), v = fl32(a1 / a2),
+// a_r = fl32(the fp64 row sum) -- 6 fp64 adds, 3 conversions and a correctly rounded two-wide
+// division per voxel and view.  Almost always the same pixel comes out of plain fp32: three FMAs per
+// row from the fp32 matrix, one v_rcp, two multiplications.  "Almost": the two differ only where u
+// or v lies within the filter's error of a rounding tie k + 1/2 (the image's borders -1/2 and
+// W - 1/2 are such ties too).  With
+//   E_r  = sum_k |M[r][k]| max|w_k| (over the sub-tile) + |M[r][3]|
+//   |ahat_r - a_r| <= e_r = 4.5 * 2^-24 * E_r     (three fp32 roundings of partial sums <= E_r here,
+//                                                  one of the reference's own, fp64 dust)
+//   uhat = fl32(ahat_0 * rcp(ahat_2)),  |rcp| error 1 ulp, the product's 1/2 ulp, the reference's
+//                                        division 1/2 ulp:  <= 1.25 * 2^-22 |u| together
+//   |uhat - u| <= ((e_0 + |u| e_2) / |ahat_2|) / (1 - e_2 / |ahat_2|) + 1.25 * 2^-22 |u|
+// a lane whose uhat, vhat keep that distance from every tie has the reference's pixel for certain;
+// the others -- a few in a thousand -- are flagged, and ONE exact evaluation per view (rarely two)
+// settles all flagged (lane, block) pairs of the view together, each lane on its own block.  The
+// guard e_2 / |ahat_2| < 1/64 (else: flagged) makes the second factor <= 1.016; 1.02 is used.
+// NaN / infinity anywhere fails the comparisons and flags the lane.
+// Pays where a view projects many of the sub-tile's blocks: its per-view set-up (the bounds, the
+// hoisted partial sums) and the flagged pass are paid per view, not per block.  A launch runs all
+// its views through the filter or none (both paths in one kernel: 108 B/lane of scratch).
+
+// the table reads and the state update of a view: pix[m][j] for the blocks in `did`
+__device__ __forceinline__ bool apply_view_pixels(const uint32_t *__restrict__ bgv, const uint32_t (&pix)[4][4],
+                                                  const unsigned did, uint32_t (&st)[4]) {
+    uint32_t word[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((did >> (4 * m + j)) & 1u) word[m][j] = bgv[(pix[m][j] & 0x7fffffffu) >> 5];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        if (!((did >> (4 * m)) & 15u)) continue;
+        uint32_t w = st[m];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!((did >> (4 * m + j)) & 1u)) continue;
+            const uint32_t isbg = __builtin_amdgcn_ubfe(word[m][j], pix[m][j], 1u);  // bit pix & 31
+            const uint32_t seen = (pix[m][j] >> 31) << (8 * j + 1);
+            w = (w | seen) & ~(isbg << (8 * j));
+        }
+        st[m] = w;
+    }
+    return __all(st[0] == kDone4 && st[1] == kDone4 && st[2] == kDone4 && st[3] == kDone4);
+}
+
+// exact_view_blocks with the filter in front.  wmax: max |w| of the sub-tile's voxels (y, x, z terms).
+template <bool LEFT>
+__device__ __forceinline__ bool filtered_view_blocks(const CarveParams &p, const int view,
+                                                     const bool fast, const float (&wy)[2],
+                                                     const float (&wx)[4], const float (&wz)[2],
+                                                     const float (&wmax)[3], uint32_t (&st)[4],
+                                                     const unsigned need) {
+    const uint32_t *__restrict__ bgv = p.bg + (size_t)view * p.bgWords;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 row0, row1, row2;
+    const float *Mv = p.M + 12 * view;
+    asm volatile(
+        "s_load_dwordx4 %0, %3, 0x0\n\t"
+        "s_load_dwordx4 %1, %3, 0x10\n\t"
+        "s_load_dwordx4 %2, %3, 0x20\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(row0), "=&s"(row1), "=&s"(row2)
+        : "s"(Mv)
+        : "memory");
+    const float mf[3][4] = {{row0.x, row0.y, row0.z, row0.w}, {row1.x, row1.y, row1.z, row1.w},
+                            {row2.x, row2.y, row2.z, row2.w}};
+    const float wlim = (float)p.W - 0.5f, hlim = (float)p.H - 0.5f;
+    const int zero_pix = 32 * (p.bgWords - 1);
+    // the filter's error scales for this view and sub-tile (the same in every lane)
+    const float kE = 4.5f * 5.9604644775390625e-08f * 1.02f;  // 4.5 * 2^-24 * 1.02
+    float e[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        e[r] = (fabsf(mf[r][0]) * wmax[0] + fabsf(mf[r][1]) * wmax[1] + fabsf(mf[r][2]) * wmax[2] +
+                fabsf(mf[r][3])) * kE;
+    const float kQ = 1.25f * 2.384185791015625e-07f * 1.02f;  // 1.25 * 2^-22 * 1.02
+    uint32_t pix[4][4];
+    unsigned did = 0;
+    unsigned flagged = 0;  // per LANE: bit 4 m + j = this lane's voxel of block (m, j) is near a tie
+#pragma unroll
+    for (int byi = 0; byi < 2; ++byi) {
+        if (!((need >> (8 * byi)) & 0xffu)) continue;
+        if (!__any(st[2 * byi] != kDone4 || st[2 * byi + 1] != kDone4)) continue;
+        float c[3][4];  // the (y, x) part of the rows: two roundings, the z term below a third
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float ty = fmaf(mf[r][0], wy[byi], mf[r][3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[r][j] = fmaf(mf[r][1], wx[j], ty);
+        }
+#pragma unroll
+        for (int bzi = 0; bzi < 2; ++bzi) {
+            const int m = 2 * byi + bzi;
+            const uint32_t w = st[m];
+            if (!((need >> (4 * m)) & 15u) || !__any(w != kDone4)) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!((need >> (4 * m + j)) & 1u)) continue;
+                if (!__any(((w >> (8 * j)) & 0xffu) != 2u)) continue;
+                const float a0 = fmaf(mf[0][2], wz[bzi], c[0][j]);
+                const float a1 = fmaf(mf[1][2], wz[bzi], c[1][j]);
+                const float a2 = fmaf(mf[2][2], wz[bzi], c[2][j]);
+                const float rc = __builtin_amdgcn_rcpf(a2);
+                const float u = a0 * rc, v = a1 * rc;
+                const float arc = fabsf(rc);
+                const float g2 = arc * e[2];
+                const float q = g2 + kQ;
+                const float du = fmaf(fabsf(u), q, arc * e[0]);
+                const float dv = fmaf(fabsf(v), q, arc * e[1]);
+                const float fu = __builtin_amdgcn_fractf(u) - 0.5f, fv = __builtin_amdgcn_fractf(v) - 0.5f;
+                // (negated >=: a NaN anywhere flags the lane)
+                const bool near = (int)!(fabsf(fu) >= du) | (int)!(fabsf(fv) >= dv) | (int)!(g2 < 0.015625f);
+                did |= 1u << (4 * m + j);
+                pix[m][j] = pixel_tagged(u, v, p.W, wlim, hlim, zero_pix);
+                flagged |= near ? (1u << (4 * m + j)) : 0u;
+            }
+        }
+    }
+    if (!did) return false;
+    // the flagged (lane, block) pairs in the reference's own arithmetic: every lane takes its lowest
+    // flagged block, all lanes together
+    while (__any(flagged != 0u)) {
+        const bool act = flagged != 0u;
+        const int b = act ? (__ffs((int)flagged) - 1) : 0;
+        flagged &= flagged - 1u;
+        const int j = b & 3, byi = (b >> 3) & 1, bzi = (b >> 2) & 1;
+        const float lwx = j == 0 ? wx[0] : (j == 1 ? wx[1] : (j == 2 ? wx[2] : wx[3]));
+        const float lwy = byi ? wy[1] : wy[0], lwz = bzi ? wz[1] : wz[0];
+        float a[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double p0 = (double)mf[r][0] * (double)lwy, p1 = (double)mf[r][1] * (double)lwx,
+                         p2 = (double)mf[r][2] * (double)lwz;
+            a[r] = row_sum<LEFT>(p0, p1, p2, (double)mf[r][3]);
+        }
+        float u, v;
+        if (fast) {
+            divide2_shared_rcp(a[0], a[1], a[2], u, v);
+        } else {
+            u = a[0] / a[2];
+            v = a[1] / a[2];
+        }
+        const uint32_t np = pixel_tagged(u, v, p.W, wlim, hlim, zero_pix);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                if ((did >> (4 * m + jj)) & 1u) pix[m][jj] = (act && b == 4 * m + jj) ? np : pix[m][jj];
+    }
+    return apply_view_pixels(bgv, pix, did, st);
+}
+
 // Rectangle tests per 4 x 4 x 4 BLOCK, for the views of one chunk that are "mixed" for the
 // sub-tile: the silhouette's edge crosses the sub-tile's pixel rectangle, but most of its
 // sixteen blocks lie on one side of it.  Four views at a time, lane = (view q = lane >> 4,
@@ -1668,12 +1823,18 @@ __device__ __forceinline__ unsigned block_tests_lds(const CarveParams &p, const 
 #ifndef ARVX_EXACT_WAVES_PER_SIMD
 #define ARVX_EXACT_WAVES_PER_SIMD 4  // (A/B builds: 5 -> 102 registers, see EXPERIMENTS.md)
 #endif
+#ifndef ARVX_EXACT_SPLIT_WAVES_PER_SIMD  // the small-grid instantiation (items shared between waves)
+#define ARVX_EXACT_SPLIT_WAVES_PER_SIMD 4  // (A/B builds: 3 -> no scratch, see EXPERIMENTS.md round 5)
+#endif
 // SPLIT: items may be handed to several waves (flags bit3: small grids and slabs).  The large
 // grids never do: their instantiation carries none of that code (no atomic merge of the parts,
 // fewer registers alive across an item).
 // FRESH: the model is fresh (flags bit2) -- known when the kernel is compiled: no record is read.
-template <bool LEFT, bool SPLIT = true, bool FRESH = false>
-__global__ __launch_bounds__(256, ARVX_EXACT_WAVES_PER_SIMD) void carve_exact_blocks_kernel(const CarveParams p) {
+// FILTER: every view goes through the fp32 filter (filtered_view_blocks) -- for the launches whose
+// views mostly project many blocks of an item.
+template <bool LEFT, bool SPLIT = true, bool FRESH = false, bool FILTER = false>
+__global__ __launch_bounds__(256, (SPLIT && !FRESH ? ARVX_EXACT_SPLIT_WAVES_PER_SIMD : ARVX_EXACT_WAVES_PER_SIMD))
+void carve_exact_blocks_kernel(const CarveParams p) {
 #ifdef ARVX_TIMELINE
     WaveTimeline wave_timeline(p.timeline);
 #endif
@@ -1752,6 +1913,13 @@ __global__ __launch_bounds__(256, ARVX_EXACT_WAVES_PER_SIMD) void carve_exact_bl
                 wy[b] = (float)(t.sy0 + 4 * b + ly) * p.s;
                 wz[b] = (float)(-global_z(p, t.sz0 + 4 * b + lz)) * p.s;
             }
+            float wmax[3] = {0.f, 0.f, 0.f};  // max |w| over the sub-tile (the filter's error scale)
+            if (FILTER) {
+                wmax[0] = (float)(t.sy0 + 7) * p.s;
+                wmax[1] = (float)(t.sx0 + 15) * p.s;
+                wmax[2] = fmaxf(fabsf((float)(-global_z(p, t.sz0)) * p.s),
+                                fabsf((float)(-global_z(p, t.sz0 + 7)) * p.s));
+            }
             bool done = false;
 #ifdef ARVX_TIMELINE
             wave_timeline.tick(1);
@@ -1796,8 +1964,12 @@ __global__ __launch_bounds__(256, ARVX_EXACT_WAVES_PER_SIMD) void carve_exact_bl
                                               : (unsigned)__builtin_amdgcn_readlane(needLanes, slot);
                     ++slot;
                     if (!need) continue;  // every block settled by its rectangle
-                    done = exact_view_blocks<LEFT>(p, __builtin_amdgcn_readfirstlane(p.v0 + 64 * c + b),
-                                             (fastdiv >> b) & 1ull, wy, wx, wz, st, need);
+                    if (FILTER)
+                        done = filtered_view_blocks<LEFT>(p, __builtin_amdgcn_readfirstlane(p.v0 + 64 * c + b),
+                                                          (fastdiv >> b) & 1ull, wy, wx, wz, wmax, st, need);
+                    else
+                        done = exact_view_blocks<LEFT>(p, __builtin_amdgcn_readfirstlane(p.v0 + 64 * c + b),
+                                                       (fastdiv >> b) & 1ull, wy, wx, wz, st, need);
 #ifdef ARVX_TIMELINE
                     wave_timeline.view_done();
 #endif

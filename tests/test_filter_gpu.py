@@ -1,0 +1,95 @@
+"""The fp32 projection filter (ARVX_CARVE_FILTER; csrc/carve_kernels.h, filtered_view_blocks): a
+cheaper first evaluation of every voxel's pixel with an exact fall-back for the voxels within the
+filter's error of a rounding tie.  The model it leaves must be the reference's, bit for bit
+(src/VoxelCarving.cpp:38-55): against the oracle on random ragged grids, slabs, models that are not
+fresh and both row-sum groupings; against the brute-force kernel where every block is projected in
+every view; and on cameras built so that EVERY voxel lands exactly on, or a few ulps beside, a tie
+k + 1/2 -- where the filter must hand every voxel to the exact path."""
+import numpy as np
+import pytest
+
+from tests import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def carve(arvx, X, Y, Z, s, M, masks, flags, state=None, **kw):
+    with arvx.Context(X, Y, Z, s, **kw) as ctx:
+        ctx.set_views(M, masks)
+        if state is not None:
+            ctx.upload_state(state)
+        ctx.carve(flags)
+        return ctx.download_state()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_filter_equals_oracle_on_random_ragged_grids(arvx, oracle, seed):
+    rng = np.random.default_rng(4000 + seed)
+    X, Y, Z = (int(v) for v in rng.integers(1, 150, size=3))
+    V = int(rng.choice([1, 2, 7, 36, 64, 65, 70]))
+    W, H = (640, 480) if seed % 2 else (320, 240)
+    extent = 0.3
+    s = np.float32(extent / max(X, Y, Z))
+    _, _, M = scenes.random_cameras(V, extent, seed=seed, W=W, H=H, inside=bool(seed % 3 == 0))
+    masks = scenes.noise_masks(V, H, W, block=int(rng.choice([1, 2, 4, 16])), p_bg=float(rng.uniform(0.02, 0.6)),
+                               seed=seed + 7)
+    st0 = None
+    if seed % 4 == 1:  # a model that is not fresh
+        st0 = np.where(rng.random((Z, Y, X)) < 0.3, rng.integers(0, 4, (Z, Y, X)), 1).astype(np.uint8)
+        st0[(st0 & 1) == 0] |= 0  # (carved voxels may be unseen in an uploaded model)
+    assoc = arvx.ASSOC_RIGHT if seed % 5 == 2 else arvx.ASSOC_LEFT
+    with oracle.variant("assoc_right" if assoc == arvx.ASSOC_RIGHT else "assoc_left"):
+        want = oracle.carve(X, Y, Z, s, M, masks, state=st0)
+    got = carve(arvx, X, Y, Z, s, M, masks, arvx.CARVE_FILTER, state=st0, assoc=assoc)
+    assert np.array_equal(got, want), f"{X}x{Y}x{Z} x {V}: {(got != want).sum()} voxels differ"
+
+
+@pytest.mark.parametrize("seed,block,p_bg", [(11, 2, 0.02), (12, 2, 0.10), (13, 1, 0.005), (14, 1, 0.5)])
+def test_filter_matches_brute_force_where_every_block_is_projected(arvx, seed, block, p_bg):
+    N, V, W, H = 192, 9, 640, 480
+    s = np.float32(0.512 / N)
+    _, _, M = scenes.random_cameras(V, 0.512, seed=seed, W=W, H=H, inside=False)
+    masks = scenes.noise_masks(V, H, W, block=block, p_bg=p_bg, seed=seed + 100)
+    want = carve(arvx, N, N, N, s, M, masks, arvx.CARVE_NO_CULL)
+    got = carve(arvx, N, N, N, s, M, masks, arvx.CARVE_FILTER)
+    assert np.array_equal(got, want), f"{(got != want).sum()} voxels differ"
+    parts = [carve(arvx, N, N, N, s, M, masks, arvx.CARVE_FILTER, z_range=r) for r in [(0, 70), (70, 71), (71, 192)]]
+    assert np.array_equal(np.concatenate(parts, axis=0), want), "slabs"
+
+
+@pytest.mark.parametrize("eps_ulps", [0, 1, -1, 3, -3, 40, -40])
+def test_every_voxel_on_a_rounding_tie(arvx, oracle, eps_ulps):
+    """u = x + 1/2 (+ a few ulps), v = y + 1/2 (+ a few ulps) for every voxel: an affine camera with
+    s = 2^-6 and focal length 2^6, so that the products are exact and the quotients are the ties
+    themselves.  One pixel off in any voxel shows: the masks are single-pixel noise."""
+    N, W, H = 64, 96, 80
+    s = np.float32(2.0 ** -6)
+    f = np.float32(2.0 ** 6)
+    base = np.float32(0.5)
+    c = np.nextafter(base, np.float32(2 if eps_ulps > 0 else -2), dtype=np.float32) if eps_ulps else base
+    for _ in range(max(0, abs(eps_ulps) - 1)):
+        c = np.nextafter(c, np.float32(2 if eps_ulps > 0 else -2), dtype=np.float32)
+    # Model::toWord: world = (y s, x s, -z s, 1): row 0 picks x (the second coordinate), row 1 picks y
+    M = np.zeros((3, 3, 4), np.float32)
+    for k, (cu, cv, a2) in enumerate(((c, base, 1.0), (base, c, 1.0), (c, c, 2.0))):
+        M[k, 0] = (0, f * a2, 0, cu * a2)
+        M[k, 1] = (f * a2, 0, 0, cv * a2)
+        M[k, 2] = (0, 0, 0, a2)
+    masks = scenes.noise_masks(3, H, W, block=1, p_bg=0.5, seed=5)
+    want = oracle.carve(N, N, N, s, M, masks)
+    for flags in (0, arvx.CARVE_FILTER):
+        got = carve(arvx, N, N, N, s, M, masks, flags)
+        assert np.array_equal(got, want), f"flags {flags}: {(got != want).sum()} voxels differ"
+
+
+def test_filter_on_the_sphere_and_on_views_in_pieces(arvx, oracle):
+    N, V = 160, 24
+    sc = scenes.small_sphere(N, V, W=640, H=480)
+    want = oracle.carve(N, N, N, sc.voxel_size, sc.M, sc.masks)
+    assert np.array_equal(carve(arvx, N, N, N, sc.voxel_size, sc.M, sc.masks, arvx.CARVE_FILTER), want)
+    with arvx.Context(N, N, N, sc.voxel_size) as ctx:
+        ctx.set_views(sc.M, sc.masks)
+        ctx.carve_views(0, 5, arvx.CARVE_FILTER)
+        ctx.carve_views(5, 1, arvx.CARVE_FILTER)
+        ctx.carve_views(6, V - 6, 0)
+        assert np.array_equal(ctx.download_state(), want)
