@@ -1670,6 +1670,7 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
 #endif
         const bool left = ctx->assoc == ARVX_ASSOC_LEFT;
         const bool may_split = p.flags & 8u;
+#ifdef ARVX_EXPERIMENTS
         // the fp32 filter in front of the exact projection (carve_kernels.h, filtered_view_blocks):
         // for callers whose masks leave most blocks of an item to be projected (ARVX_CARVE_FILTER)
         const bool filter = (flags & ARVX_CARVE_FILTER) != 0;
@@ -1691,7 +1692,9 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         else if (blocks && filter)
             hipLaunchKernelGGL((arvx::carve_exact_blocks_kernel<false, false, false, true>), dim3(pgrid), dim3(256), 0,
                                ctx->stream, p);
-        else if (blocks && left && may_split)
+        else
+#endif
+        if (blocks && left && may_split)
             hipLaunchKernelGGL((arvx::carve_exact_blocks_kernel<true, true>), dim3(pgrid), dim3(256), 0,
                                ctx->stream, p);
         else if (blocks && left && fresh)
@@ -1750,6 +1753,9 @@ int arvx_carve_views(arvx_ctx *ctx, int first, int count, unsigned flags) {
     if (flags & ARVX_CARVE_STREAM)  // (refused before anything about the context changes)
         return fail(ARVX_ERR_INVALID, "ARVX_CARVE_STREAM: the one-launch carve is only in -DARVX_EXPERIMENTS "
                                       "builds (libarvx_experiments.so)");
+    if (flags & ARVX_CARVE_FILTER)
+        return fail(ARVX_ERR_INVALID, "ARVX_CARVE_FILTER: the fp32 projection filter is only in "
+                                      "-DARVX_EXPERIMENTS builds (libarvx_experiments.so)");
 #endif
     state_changes(ctx, false);
     const bool fresh = ctx->fresh_pending;

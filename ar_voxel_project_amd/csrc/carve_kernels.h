@@ -1529,7 +1529,7 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
     return __all(st[0] == kDone4 && st[1] == kDone4 && st[2] == kDone4 && st[3] == kDone4);
 }
 
-// ---- the fp32 filter (round 5) -----------------------------------------------------------------
+// ---- the fp32 filter (round 5; experiment builds only: it loses, EXPERIMENTS.md) -------------------
 //
 // A voxel's pixel is (round(u), round(v)) of the reference's u = fl32(a0 / a2), v = fl32(a1 / a2),
 // a_r = fl32(the fp64 row sum) -- 6 fp64 adds, 3 conversions and a correctly rounded two-wide
@@ -1577,6 +1577,7 @@ __device__ __forceinline__ bool apply_view_pixels(const uint32_t *__restrict__ b
     return __all(st[0] == kDone4 && st[1] == kDone4 && st[2] == kDone4 && st[3] == kDone4);
 }
 
+#ifdef ARVX_EXPERIMENTS
 // exact_view_blocks with the filter in front.  wmax: max |w| of the sub-tile's voxels (y, x, z terms).
 template <bool LEFT>
 __device__ __forceinline__ bool filtered_view_blocks(const CarveParams &p, const int view,
@@ -1683,6 +1684,8 @@ __device__ __forceinline__ bool filtered_view_blocks(const CarveParams &p, const
     }
     return apply_view_pixels(bgv, pix, did, st);
 }
+
+#endif  // ARVX_EXPERIMENTS
 
 // Rectangle tests per 4 x 4 x 4 BLOCK, for the views of one chunk that are "mixed" for the
 // sub-tile: the silhouette's edge crosses the sub-tile's pixel rectangle, but most of its
@@ -1830,8 +1833,7 @@ __device__ __forceinline__ unsigned block_tests_lds(const CarveParams &p, const 
 // grids never do: their instantiation carries none of that code (no atomic merge of the parts,
 // fewer registers alive across an item).
 // FRESH: the model is fresh (flags bit2) -- known when the kernel is compiled: no record is read.
-// FILTER: every view goes through the fp32 filter (filtered_view_blocks) -- for the launches whose
-// views mostly project many blocks of an item.
+// FILTER (experiment builds): every view goes through the fp32 filter (filtered_view_blocks).
 template <bool LEFT, bool SPLIT = true, bool FRESH = false, bool FILTER = false>
 __global__ __launch_bounds__(256, (SPLIT && !FRESH ? ARVX_EXACT_SPLIT_WAVES_PER_SIMD : ARVX_EXACT_WAVES_PER_SIMD))
 void carve_exact_blocks_kernel(const CarveParams p) {
@@ -1964,10 +1966,12 @@ void carve_exact_blocks_kernel(const CarveParams p) {
                                               : (unsigned)__builtin_amdgcn_readlane(needLanes, slot);
                     ++slot;
                     if (!need) continue;  // every block settled by its rectangle
+#ifdef ARVX_EXPERIMENTS
                     if (FILTER)
                         done = filtered_view_blocks<LEFT>(p, __builtin_amdgcn_readfirstlane(p.v0 + 64 * c + b),
                                                           (fastdiv >> b) & 1ull, wy, wx, wz, wmax, st, need);
                     else
+#endif
                         done = exact_view_blocks<LEFT>(p, __builtin_amdgcn_readfirstlane(p.v0 + 64 * c + b),
                                                        (fastdiv >> b) & 1ull, wy, wx, wz, st, need);
 #ifdef ARVX_TIMELINE

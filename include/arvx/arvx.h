@@ -62,11 +62,10 @@ enum {
                                     -DARVX_EXPERIMENTS builds (libarvx_experiments.so, A/B and
                                     tests); the shipped library answers ARVX_ERR_INVALID */
 #define ARVX_CARVE_NO_STREAM 32u /* never the streaming carve */
-#define ARVX_CARVE_FILTER 64u    /* project through the fp32 filter first (exact fall-back for voxels
-                                    within the filter's error of a rounding tie: the same model, bit
-                                    for bit): for masks that leave most 4x4x4 blocks of the surface
-                                    region to be projected voxel by voxel -- speckled or noisy
-                                    silhouettes; slower on clean ones */
+#define ARVX_CARVE_FILTER 64u    /* project through an fp32 filter first, exact fall-back for voxels within
+                                    the filter's error of a rounding tie: the same model bit for bit, but
+                                    1.16-1.23x SLOWER than the exact kernel (EXPERIMENTS.md round 5) --
+                                    compiled only into -DARVX_EXPERIMENTS builds like ARVX_CARVE_STREAM */
 
 /* colour modes: reference -color=1 / -color=2 (src/main.cpp:276-288) */
 #define ARVX_COLOR_CLOSEST 0

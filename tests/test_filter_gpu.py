@@ -13,6 +13,31 @@ from tests import scenes
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module")
+def arvx(arvx):
+    """The filter lost its A/B (1.16-1.23x slower than the exact kernel, EXPERIMENTS.md round 5) and is
+    compiled only into the experiments build of the library (csrc/Makefile: libarvx_experiments.so):
+    these tests keep it honest there."""
+    import functools
+    import os
+    import types
+    exp = os.path.join(os.path.dirname(arvx.LIB_PATH), "libarvx_experiments.so")
+    if not os.path.exists(exp):
+        pytest.fail("libarvx_experiments.so is missing: run __graft_entry__.build()")
+    ns = types.SimpleNamespace(**{k: getattr(arvx, k) for k in dir(arvx) if k.isupper()})
+    ns.Context = functools.partial(arvx.Context, lib_path=exp)
+    return ns
+
+
+def test_shipped_library_refuses_the_filter():
+    from ar_voxel_project_amd import capi
+    sc = scenes.small_sphere(32, 3, W=96, H=72)
+    with capi.Context(32, 32, 32, sc.voxel_size) as ctx:
+        ctx.set_views(sc.M, sc.masks)
+        with pytest.raises(capi.ArvxError, match="ARVX_EXPERIMENTS"):
+            ctx.carve(capi.CARVE_FILTER)
+
+
 def carve(arvx, X, Y, Z, s, M, masks, flags, state=None, **kw):
     with arvx.Context(X, Y, Z, s, **kw) as ctx:
         ctx.set_views(M, masks)

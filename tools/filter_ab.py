@@ -3,13 +3,15 @@
 against the default exact kernel on one box: the sphere at 512^3 / 1024^3, bench.py's three
 sparse-background workloads, 8x8 and 2x2 block noise.  Per workload: best-of-7 carve times with HIP
 events, interleaved, and whether the two models are the same bit for bit.
-    python tools/filter_ab.py [rounds]"""
+    python tools/filter_ab.py [rounds [workload substring]]"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the filter lives in the experiments build only (both sides of the A/B run on that build)
+os.environ.setdefault("ARVX_LIB_PATH", os.path.join(ROOT, "ar_voxel_project_amd", "lib", "libarvx_experiments.so"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -17,6 +19,7 @@ import bench  # noqa: E402
 from ar_voxel_project_amd import capi, synthetic  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+only = sys.argv[2] if len(sys.argv) > 2 else ""  # a substring of the workloads to run
 stream = torch.cuda.Stream()
 torch.cuda.set_stream(stream)
 
@@ -32,6 +35,8 @@ def timed(ctx, flags):
 
 
 def entry(name, N, M, masks, s):
+    if only and only not in name:
+        return None
     with capi.Context(N, N, N, s) as ctx:
         ctx.set_stream(stream.cuda_stream)
         ctx.set_views(M, masks)
