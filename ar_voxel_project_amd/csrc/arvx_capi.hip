@@ -1106,6 +1106,11 @@ int arvx_handle_unseen(arvx_ctx *ctx) {
     // seen" and "untouched, not seen" are all unchanged by occ |= ~seen -- the records behind a
     // code are not read by anybody)
     if (int mrc = need_rec(ctx, true)) return mrc;
+    if (ctx->planes_ok && ctx->planes_seq == ctx->state_seq) {
+        // the colour pass's planes stay usable: occupied is now their occupancy | never-seen
+        ctx->planes_seq = ctx->state_seq + 1;
+        ctx->planes_unseen = true;
+    }
     ++ctx->state_seq;
     ctx->closure_ready = false;  // (colours and paint stay: only never-seen voxels change)
     arvx::CarveParams g;
@@ -1524,7 +1529,10 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         const size_t nitems = cap * arvx::kWorkLists;
         // one persistent workgroup per workgroup slot of the chip (4 per CU at 128 VGPRs)
         static const int exact_wgs = experiment_int("ARVX_EXACT_WGS_PER_CU");  // (A/B builds)
-        const unsigned pgrid = (unsigned)ncu * (exact_wgs > 0 ? (unsigned)exact_wgs : (unsigned)ARVX_EXACT_WAVES_PER_SIMD);
+        // (the small grids' instantiation -- items shared between waves -- holds 149 registers: 3 per CU)
+        const unsigned per_cu = (size_t)p.X * p.Y * p.Z <= ((size_t)1 << 26) ? (unsigned)ARVX_EXACT_SPLIT_WAVES_PER_SIMD
+                                                                           : (unsigned)ARVX_EXACT_WAVES_PER_SIMD;
+        const unsigned pgrid = (unsigned)ncu * (exact_wgs > 0 ? (unsigned)exact_wgs : per_cu);
         const size_t nwaves = (size_t)pgrid * 4;
         const size_t nctr_pool = (size_t)arvx::kPoolCounters * arvx::kCounterStride;
         const size_t ints = nctr + nctr_pool;  // list fill counters, pool ticket counters
@@ -1883,14 +1891,22 @@ int arvx_color(arvx_ctx *ctx, int mode) {
     const arvx::BitGrid gext{ctx->X, ctx->Y, Zext, XW};
     const size_t row_words = (size_t)XW * ctx->Y;
     const size_t nw_ext = row_words * Zext;
-    if (int rc = ensure_scratch(ctx, nw_ext * sizeof(unsigned long long) + 64)) return rc;
     // the surface plane stays with the context: with its ranks it is the index of the colour
     // list (closure and mesh look colours up through it)
     ARVX_HIP(ctx->pool_col_bits.reserve(nw_ext * sizeof(unsigned long long)));
     ARVX_HIP(ctx->pool_col_rank.reserve(nw_ext * sizeof(arvx::SparseWord)));
-    unsigned long long *d_occ = (unsigned long long *)ctx->d_scratch;
+    // ... and so do the occupancy plane and the plane of the voxels no view has seen: a closure that
+    // follows -- with nothing but handleUnseen in between, src/main.cpp:282-299 -- starts from them
+    // instead of converting the records again (state_planes)
+    ARVX_HIP(ctx->pool_occ_bits.reserve(nw_ext * sizeof(unsigned long long)));
+    ARVX_HIP(ctx->pool_nseen_bits.reserve(nw_ext * sizeof(unsigned long long)));
+    unsigned long long *d_occ = (unsigned long long *)ctx->pool_occ_bits.p;
     unsigned long long *d_surf = (unsigned long long *)ctx->pool_col_bits.p;
-    if (int rc = launch_bit_pack(ctx, gext, 0, 0, d_occ, nullptr)) return rc;
+    ctx->planes_ok = false;
+    if (int rc = launch_bit_pack(ctx, gext, 0, 1, d_occ, (unsigned long long *)ctx->pool_nseen_bits.p)) return rc;
+    ctx->planes_ok = true;
+    ctx->planes_seq = ctx->state_seq;
+    ctx->planes_unseen = false;
     // the surface plane of the planes [c_lo, c_hi) (zeros elsewhere) and, per chunk of the
     // compaction, its number of set bits
     int *d_counts = nullptr;
@@ -2381,11 +2397,26 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     unsigned long long *d_occ = (unsigned long long *)ctx->d_scratch;
     unsigned long long *d_unseen = d_occ + nwords, *d_b = d_unseen + nwords;
     unsigned long long *d_fill = (unsigned long long *)ctx->pool_clo_bits.p;
-    if (int rc = launch_bit_pack(ctx, g, 1, apply_unseen ? 1 : 0, d_occ, paints ? d_unseen : nullptr))
-        return rc;
     const unsigned gw = (unsigned)((nwords + 255) / 256);
-    hipLaunchKernelGGL(arvx::bit_dilate_xy_kernel, dim3(gw), dim3(256), 0, ctx->stream, d_occ, g,
-                       radius, d_b);
+    if (ctx->planes_ok && ctx->planes_seq == ctx->state_seq && !ctx->paint_valid &&
+        ctx->pool_occ_bits.cap >= nwords * 8 && ctx->pool_nseen_bits.cap >= nwords * 8) {
+        // the colour pass's planes are the state's (nothing but handleUnseen ran since): what the
+        // closure calls occupied is their occupancy, with the never-seen voxels once those are occupied
+        // (handleUnseen ran, or the caller says apply_unseen); the UNSEEN_COLOR plane is the never-seen one
+        const unsigned long long *p_occ = (const unsigned long long *)ctx->pool_occ_bits.p;
+        const unsigned long long *p_nseen = (const unsigned long long *)ctx->pool_nseen_bits.p;
+        const bool merge = ctx->planes_unseen || apply_unseen;
+        hipLaunchKernelGGL(arvx::bit_dilate_xy_kernel, dim3(gw), dim3(256), 0, ctx->stream, p_occ,
+                           merge ? p_nseen : (const unsigned long long *)nullptr, g, radius, d_b, d_occ);
+        if (!merge) d_occ = const_cast<unsigned long long *>(p_occ);
+        d_unseen = const_cast<unsigned long long *>(p_nseen);  // (read only where `paints`)
+    } else {
+        if (int rc = launch_bit_pack(ctx, g, 1, apply_unseen ? 1 : 0, d_occ, paints ? d_unseen : nullptr))
+            return rc;
+        hipLaunchKernelGGL(arvx::bit_dilate_xy_kernel, dim3(gw), dim3(256), 0, ctx->stream,
+                           (const unsigned long long *)d_occ, (const unsigned long long *)nullptr, g, radius, d_b,
+                           (unsigned long long *)nullptr);
+    }
     // (halo planes outside [f_lo, f_hi): their boxes reach planes this context knows nothing
     // about -- not filled here, their owners do it: zeros)
     int *d_counts = nullptr;

@@ -94,6 +94,12 @@ struct Ctx {
     // every call that changes occupied / seen bits counts here: what was derived from the state
     // (the host hand-off's packets) is current while the count it was taken at still stands
     unsigned long long state_seq = 1;
+    // the colour pass's bit planes of the state (occupied; seen by no view), kept for a closure that
+    // follows: valid while state_seq == planes_seq; planes_unseen: handleUnseen has run since (the
+    // records' occupancy is the occupancy plane | the never-seen plane)
+    DevPool pool_occ_bits, pool_nseen_bits;
+    unsigned long long planes_seq = 0;
+    bool planes_ok = false, planes_unseen = false;
     DevPool pool_state_packets;  // arvx_state_download_packets: occupancy | seen, worst-case size each
     unsigned long long packets_seq = 0;
     bool packets_valid = false;
@@ -207,6 +213,9 @@ struct Ctx {
         pool_chunk_counts.release();
         counts_stride = 0;
         pool_state_packets.release();
+        pool_occ_bits.release();
+        pool_nseen_bits.release();
+        planes_ok = false;
         packets_valid = false;
         compact_tickets = 0;
         pool_paint.release();

@@ -32,10 +32,15 @@ __device__ __forceinline__ unsigned long long bit_word(const unsigned long long 
 }
 
 // box dilation (r = radius, 1..4).  x and y in one launch: the rows y-r..y+r, each dilated along x on the way (round 4: one launch and
-// one pass over the plane less than bit_dilate_x_kernel + the y pass)
+// one pass over the plane less than bit_dilate_x_kernel + the y pass).  in2 (may be null): a second
+// plane OR-ed onto `in` as it is read -- the closure's "occupied" is the colour pass's occupancy
+// plane | its never-seen plane once handleUnseen has run --, and merged (with in2): in | in2 written
+// out for the kernels that follow.
 __global__ __launch_bounds__(256) void bit_dilate_xy_kernel(const unsigned long long *__restrict__ in,
+                                                            const unsigned long long *__restrict__ in2,
                                                             const BitGrid g, int r,
-                                                            unsigned long long *__restrict__ out) {
+                                                            unsigned long long *__restrict__ out,
+                                                            unsigned long long *__restrict__ merged) {
     const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (w >= (size_t)g.XW * g.Y * g.Z) return;
     const int xw = (int)(w % g.XW);
@@ -43,8 +48,14 @@ __global__ __launch_bounds__(256) void bit_dilate_xy_kernel(const unsigned long 
     const int y = (int)(row % g.Y), z = (int)(row / g.Y);
     unsigned long long acc = 0ull;
     for (int dy = -r; dy <= r; ++dy) {
-        const unsigned long long c = bit_word(in, g, xw, y + dy, z);
-        const unsigned long long L = bit_word(in, g, xw - 1, y + dy, z), R = bit_word(in, g, xw + 1, y + dy, z);
+        unsigned long long c = bit_word(in, g, xw, y + dy, z);
+        unsigned long long L = bit_word(in, g, xw - 1, y + dy, z), R = bit_word(in, g, xw + 1, y + dy, z);
+        if (in2) {
+            c |= bit_word(in2, g, xw, y + dy, z);
+            L |= bit_word(in2, g, xw - 1, y + dy, z);
+            R |= bit_word(in2, g, xw + 1, y + dy, z);
+            if (dy == 0) merged[w] = c;
+        }
         acc |= c;
         for (int k = 1; k <= r; ++k) acc |= (c << k) | (c >> k) | (L >> (64 - k)) | (R << (64 - k));
     }

@@ -1827,7 +1827,8 @@ __device__ __forceinline__ unsigned block_tests_lds(const CarveParams &p, const 
 #define ARVX_EXACT_WAVES_PER_SIMD 4  // (A/B builds: 5 -> 102 registers, see EXPERIMENTS.md)
 #endif
 #ifndef ARVX_EXACT_SPLIT_WAVES_PER_SIMD  // the small-grid instantiation (items shared between waves)
-#define ARVX_EXACT_SPLIT_WAVES_PER_SIMD 4  // (A/B builds: 3 -> no scratch, see EXPERIMENTS.md round 5)
+#define ARVX_EXACT_SPLIT_WAVES_PER_SIMD 3  // 149 registers, no scratch (4: 128 registers + 60 B/lane of
+                                           // scratch, C1 / C2 carves 10 / 7 % slower: EXPERIMENTS.md round 5)
 #endif
 // SPLIT: items may be handed to several waves (flags bit3: small grids and slabs).  The large
 // grids never do: their instantiation carries none of that code (no atomic merge of the parts,
