@@ -1529,10 +1529,10 @@ static int launch_carve(Ctx *ctx, uint16_t *rec, int first, int count, unsigned 
         const size_t nitems = cap * arvx::kWorkLists;
         // one persistent workgroup per workgroup slot of the chip (4 per CU at 128 VGPRs)
         static const int exact_wgs = experiment_int("ARVX_EXACT_WGS_PER_CU");  // (A/B builds)
-        // (the small grids' instantiation -- items shared between waves -- holds 149 registers: 3 per CU)
-        const unsigned per_cu = (size_t)p.X * p.Y * p.Z <= ((size_t)1 << 26) ? (unsigned)ARVX_EXACT_SPLIT_WAVES_PER_SIMD
-                                                                           : (unsigned)ARVX_EXACT_WAVES_PER_SIMD;
-        const unsigned pgrid = (unsigned)ncu * (exact_wgs > 0 ? (unsigned)exact_wgs : per_cu);
+        // (the small grids' instantiation -- items shared between waves -- holds 149 registers, 3 per CU;
+        // launched 4 per CU all the same: the fourth takes over as the first ends, C1 / C2 3 / 9 %
+        // faster than with 3, EXPERIMENTS.md round 5)
+        const unsigned pgrid = (unsigned)ncu * (exact_wgs > 0 ? (unsigned)exact_wgs : (unsigned)ARVX_EXACT_WAVES_PER_SIMD);
         const size_t nwaves = (size_t)pgrid * 4;
         const size_t nctr_pool = (size_t)arvx::kPoolCounters * arvx::kCounterStride;
         const size_t ints = nctr + nctr_pool;  // list fill counters, pool ticket counters
