@@ -146,8 +146,15 @@ class OccupancyExchange:
     the collective is ordered against that stream, and so must the kernels around it be."""
 
     def __init__(self, X: int, Y: int, Z: int, world: int, rank: int, device,
-                 mode: str = "allreduce", buffers: int = 2, layout: str = "slab", codec=None):
+                 mode: str = "allreduce", buffers: int = 2, layout: str = "slab", codec=None,
+                 lazy_expand: bool = False):
+        """lazy_expand (mode "compressed"): the exchange's product stays what travelled -- every
+        rank's packet, each with its own index (bitmaps + per-group offsets: a word is found
+        without expanding anything, include/arvx/arvx.h) -- and the plain merged plane is built
+        only when somebody asks for it (merged_plane(b)): the expansion writes N/8 bytes per job that
+        no stage of the sharded pipeline reads (colour pass, closure and mesh run on slabs)."""
         assert mode in ("allreduce", "allgather", "compressed") and layout in ("slab", "striped")
+        self.lazy_expand = bool(lazy_expand) and mode == "compressed"
         self.X, self.Y, self.Z, self.world, self.rank, self.mode = X, Y, Z, world, rank, mode
         self.layout = layout
         self.z0, self.z1 = slab_of(Z, world, rank)
@@ -236,7 +243,7 @@ class OccupancyExchange:
                                             self.packet[b][:S], async_op=async_op)
             self.cap_of[b] = cap
             self.unexpanded[b] = True
-            if not async_op:
+            if not async_op and not self.lazy_expand:
                 self._expand(b, True)
         self.pending[b] = w if async_op else None
 
@@ -300,7 +307,13 @@ class OccupancyExchange:
     def overflowed(self) -> bool:
         """Has any expand since the last reset met a packet that outgrew its cap?
         (Reads a device flag: synchronises.)"""
-        return self.mode == "compressed" and bool(self.overflow.item())
+        if self.mode != "compressed":
+            return False
+        if self.lazy_expand and self.world > 1:  # (no expansion has looked at the packets yet)
+            if any(self.unexpanded[b] and self.pending[b] is None and self._packets_overflow(b)
+                   for b in range(len(self.full))):
+                return True
+        return bool(self.overflow.item())
 
     def wait(self, b: int, verify: bool = True) -> None:
         """Buffer b's exchange is complete (in stream order).  compressed: verify=True reads
@@ -310,8 +323,25 @@ class OccupancyExchange:
         if w is not None:
             w.wait()
             self.pending[b] = None
+        if self.mode == "compressed" and self.unexpanded[b] and not self.lazy_expand:
+            self._expand(b, verify)
+        elif self.mode == "compressed" and self.unexpanded[b] and verify and self._packets_overflow(b):
+            self._expand(b, True)  # (an overflowed exchange is repaired at once: a collective, all ranks)
+
+    def _packets_overflow(self, b: int) -> bool:
+        """lazy_expand: did a packet of buffer b's exchange outgrow its cap?  (Reads the gathered
+        headers: synchronises.  Every rank holds the same packets and arrives at the same answer.)"""
+        S = self.header + self.cap_of[b]
+        counts = self.gathered[b][:self.world * S].view(self.world, S)[:, 0]
+        return bool((counts > self.cap_of[b]).any().item())
+
+    def merged_plane(self, b: int, verify: bool = True) -> "torch.Tensor":
+        """The whole grid's packed occupancy of buffer b's exchange (int32 words), expanded now if
+        the exchange kept it as packets (lazy_expand)."""
+        self.wait(b, verify)
         if self.mode == "compressed" and self.unexpanded[b]:
             self._expand(b, verify)
+        return self.full[b]
 
     def wait_all(self, verify: bool = True) -> None:
         for b in range(len(self.full)):

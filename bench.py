@@ -309,13 +309,16 @@ def main():
     ap.add_argument("--grid", type=int, default=512, help="base grid edge per GPU")
     ap.add_argument("--views", type=int, default=36)
     ap.add_argument("--no-cull", action="store_true", help="evaluate every voxel in every view")
-    ap.add_argument("--collective", default="compressed", choices=["allreduce", "allgather", "compressed", "none"],
+    ap.add_argument("--collective", default="compressed",
+                    choices=["allreduce", "allgather", "compressed", "packets", "none"],
                     help="end-of-carve merge of the packed occupancy: all-gather of compressed "
                          "packets (default: bitmaps + mixed words, ~1/7 of the bytes; checked "
                          "by an untimed trial first and replaced by the plain all-gather if the "
                          "trial fails or a packet overflows), in-place all-gather of contiguous "
                          "slabs, or the north star's all-reduce (SUM over zero-filled planes, "
-                         "striped slabs)")
+                         "striped slabs); `packets`: the compressed all-gather whose product STAYS the "
+                         "ranks' packets (each with its own index) -- the plain merged plane is built "
+                         "on demand, outside the step (reported beside the others under `collectives`)")
     ap.add_argument("--jobs", type=int, default=1,
                     help="jobs in flight for the HEADLINE (default 1: one step after the other, what "
                          "the metric means); > 1 deals the steps to that many contexts and streams")
@@ -427,9 +430,13 @@ def main():
         # job at a time with the hand-off behind the carve, 120 us beside the next one).
         own = jobs > 1
         ex, exs = None, []
+        lazy = collective == "packets"  # the compressed exchange, its product kept as packets
+        if lazy:
+            collective = "compressed"
         if world > 1 and collective != "none":
             exs = [sharding.OccupancyExchange(X, Y, Z, world, rank, dev, mode=collective,
-                                              buffers=1 if own else 2, layout=layout, codec=ctxs[k])
+                                              buffers=1 if own else 2, layout=layout, codec=ctxs[k],
+                                              lazy_expand=lazy)
                    for k in range(jobs if own else 1)]
             ex = exs[0]
         n_ev = max(1, min(5, steps // 4))  # timed steps that carry events, evenly spaced
@@ -560,7 +567,14 @@ def main():
         overflowed = any(xs.overflowed() for xs in exs)
         # the slot of the LAST job: its planes are what the last exchange merged
         last = (nstep[0] - 1) % jobs
-        merged_plane = (exs[last].full[0] if own else ex.full[(nstep[0] - 1) % 2]) if ex is not None else None
+        merged_plane = None
+        if ex is not None:  # (`packets`: expanded here, on demand -- after the timed region)
+            for c in ctxs:
+                c.set_exchange_stream(0)
+            xs_last = exs[last] if own else ex
+            xs_last.codec = ctxs[last] if own else ctxs[0]
+            merged_plane = xs_last.merged_plane(0 if own else (nstep[0] - 1) % 2, verify=False)
+            torch.cuda.synchronize()
         ctx = ctxs[last]
         st = ctx.download_state() if (rank == 0 or ex is not None) else None
         # every slot that ran a job must hold the same model
@@ -786,7 +800,7 @@ def main():
                     "carve_kernel_ms": c["kern_ms"], "views_kernel_ms": c["views_ms"]}
         coll = {args.collective: coll_entry(r, args.steps)}
         kc = max(5, args.steps // 10)
-        for mode in ("compressed", "allreduce", "allgather"):
+        for mode in ("compressed", "allreduce", "allgather", "packets"):
             if mode in coll:
                 continue
             try:

@@ -70,7 +70,7 @@ def test_two_rank_rehearsal_every_collective(jobs):
     assert d["n_gpus"] == 2 and d["config"]["jobs_in_flight"] == jobs and d["slots_agree"] is True
     assert d["rounds"]["n"] == 2
     assert d["config"]["merged_plane_holds_rank0_planes"] is True
-    assert set(d["collectives"]) == {"compressed", "allreduce", "allgather"}
+    assert set(d["collectives"]) == {"compressed", "allreduce", "allgather", "packets"}
     for name, c in d["collectives"].items():
         assert "error" not in c, (name, c)
         assert c["merge_ok"] is True, name

@@ -210,6 +210,8 @@ def test_gpu_mesh_reproduces_1_off(arvx, oracle, off1):
     with arvx.Context(X, Y, Z, off1["s"]) as ctx:
         ctx.upload_state(state_of(off1["occ"]))
         verts, rgb = ctx.mc_mesh()
+        # (round 4's lost total: the page-locked word is coherent now, the fall-back never runs)
+        assert ctx.stats()["host_total_fallbacks"] == 0
     assert len(verts) == off1["nv"] and len(rgb) == off1["nf"]
     text = oracle.off_text(verts, rgb, scale_factor=np.float32(1.0) * off1["s"])
     assert text.encode() == off1["text"]

@@ -35,6 +35,8 @@ def test_pipeline_256(arvx, oracle, scene):
         fidx, frgba = ctx.closure(3, True)
         cells1 = ctx.mc_cells()
         closed = ctx.export_model(True)
+        # every list total reached the host through its page-locked word
+        assert ctx.stats()["host_total_fallbacks"] == 0
     assert len(idx) > 50000 and np.all(np.diff(idx) > 0)
     assert np.array_equal(cells0, oracle.mc_cells(N, N, N, oracle.model_from_state(st)))
     want = oracle.closure(N, N, N, model)
@@ -96,3 +98,4 @@ def test_pipeline_fuzz(arvx, oracle):
             ctx.closure(3, True)
             assert np.array_equal(ctx.export_model(True), closed), what + " closure"
             assert np.array_equal(ctx.mc_cells(), oracle.mc_cells(X, Y, Z, closed)), what + " cells"
+            assert ctx.stats()["host_total_fallbacks"] == 0, what

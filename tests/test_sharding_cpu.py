@@ -191,6 +191,68 @@ def _fused_worker(rank, world, port, tmpdir, layout):
         dist.destroy_process_group()
 
 
+def _lazy_worker(rank, world, port, tmpdir, layout):
+    """lazy_expand: the exchange's product stays packets; merged_plane() builds the plane on demand;
+    an overflowing packet is seen from the headers alone."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests import occ_codec
+        X, Y, Z = 32, 16, 32
+        n = X * Y * (Z // world) // 64
+        wpg = X * Y * 8 // 64 if layout == "striped" else 0
+        rng = np.random.default_rng(23)
+        words = []
+        for q in range(world):
+            w = np.where(rng.random(n) < 0.5, occ_codec.ONES, occ_codec.U64(0))
+            at = rng.choice(n, 9 + 20 * q, replace=False)
+            w[at] = rng.integers(1, 2 ** 62, len(at), dtype=np.uint64)
+            words.append(w)
+        if layout == "striped":
+            want = np.zeros(world * n, np.uint64)
+            for q in range(world):
+                want.reshape(-1, world, wpg)[:, q, :] = words[q].reshape(-1, wpg)
+        else:
+            want = np.concatenate(words)
+        codec = occ_codec.FusedNumpyCodec(world, rank, wpg)
+        ex = sharding.OccupancyExchange(X, Y, Z, world, rank, "cpu", mode="compressed", buffers=2,
+                                        layout=layout, codec=codec, lazy_expand=True)
+        codec.carve(words[rank])
+        ex.prepare(0)
+        ex.pack(codec, 0)
+        ex.launch(0)
+        ex.wait_all()
+        assert ex.unexpanded[0] and not ex.overflowed()  # still packets: nothing was expanded
+        own = ex.full[0].numpy().view(np.uint64).copy()
+        assert not np.array_equal(own, want)  # (only the rank's own words are in the plane so far)
+        assert np.array_equal(ex.merged_plane(0).numpy().view(np.uint64), want)
+        assert not ex.unexpanded[0]
+        ex.retune(0)
+        ex.cap = 12  # rank 0's 9 mixed words fit, rank 1's 29 do not
+        ex.prepare(1)
+        ex.pack(codec, 1)
+        ex.launch(1, async_op=True)
+        ex.wait(1, verify=False)  # a pipelined caller: nothing read yet ...
+        assert ex.overflowed()    # ... the headers say it at the caller's own synchronisation point
+        ex.wait(1)                # and the exchange is repaired (every rank: a collective)
+        assert ex.fallbacks == 1
+        assert np.array_equal(ex.merged_plane(1).numpy().view(np.uint64), want)
+        open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("layout", ["slab", "striped"])
+def test_lazy_exchange_keeps_packets_gloo(tmp_path, layout):
+    world = 2
+    mp.spawn(_lazy_worker, args=(world, _free_port(), str(tmp_path), layout), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
 @pytest.mark.parametrize("layout", ["slab", "striped"])
 def test_fused_exchange_one_rank_overflows_gloo(tmp_path, layout):
     """a packet cap that only one rank's packet outgrows must send EVERY rank

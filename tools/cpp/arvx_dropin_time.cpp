@@ -57,11 +57,18 @@ int main(int argc, char **argv) {
             auto t1 = Clock::now();
             arvx::carve(intr, model, views);
             auto t2 = Clock::now();
-            model.sync_host();
+            // the model on the host: as packets where the grid allows (what the accessors read:
+            // Model::sync_bits), then -- on demand only -- rebuilt as two bit planes (sync_host)
+            model.sync_bits();
             auto t3 = Clock::now();
+            const size_t pkb = model.packet_bytes();
+            const bool inner = model.isInner(X / 2, Y / 2, Z / 2);
+            model.sync_host();
+            auto t4 = Clock::now();
             std::fprintf(stderr, "round %d  %dx%dx%d x %d views (C=%d): Model() %.2f | carve %.3f | "
-                                 "+ state on host %.3f ms\n",
-                         r, X, Y, Z, V, C, ms(t0, t1), ms(t1, t2), ms(t2, t3));
+                                 "+ state on host %.3f ms (%s, %.2f MB) | + planes rebuilt on the host %.3f ms%s\n",
+                         r, X, Y, Z, V, C, ms(t0, t1), ms(t1, t2), ms(t2, t3), pkb ? "packets" : "planes",
+                         pkb ? pkb / 1e6 : 2.0 * model.plane_words() * 4 / 1e6, ms(t3, t4), inner ? "" : " ");
         }
         // the pipeline of src/main.cpp:262-303: nothing comes back to the host before the
         // closure's colours and the mesh are needed there
