@@ -1898,12 +1898,12 @@ int arvx_color(arvx_ctx *ctx, int mode) {
     // ... and so do the occupancy plane and the plane of the voxels no view has seen: a closure that
     // follows -- with nothing but handleUnseen in between, src/main.cpp:282-299 -- starts from them
     // instead of converting the records again (state_planes)
-    ARVX_HIP(ctx->pool_occ_bits.reserve(nw_ext * sizeof(unsigned long long)));
-    ARVX_HIP(ctx->pool_nseen_bits.reserve(nw_ext * sizeof(unsigned long long)));
-    unsigned long long *d_occ = (unsigned long long *)ctx->pool_occ_bits.p;
+    ARVX_HIP(ctx->pool_state_planes.reserve(2 * nw_ext * sizeof(unsigned long long)));  // (one allocation)
+    unsigned long long *d_occ = (unsigned long long *)ctx->pool_state_planes.p;
     unsigned long long *d_surf = (unsigned long long *)ctx->pool_col_bits.p;
     ctx->planes_ok = false;
-    if (int rc = launch_bit_pack(ctx, gext, 0, 1, d_occ, (unsigned long long *)ctx->pool_nseen_bits.p)) return rc;
+    if (int rc = launch_bit_pack(ctx, gext, 0, 1, d_occ, d_occ + nw_ext)) return rc;
+    ctx->planes_words = nw_ext;
     ctx->planes_ok = true;
     ctx->planes_seq = ctx->state_seq;
     ctx->planes_unseen = false;
@@ -2398,13 +2398,13 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     unsigned long long *d_unseen = d_occ + nwords, *d_b = d_unseen + nwords;
     unsigned long long *d_fill = (unsigned long long *)ctx->pool_clo_bits.p;
     const unsigned gw = (unsigned)((nwords + 255) / 256);
-    if (ctx->planes_ok && ctx->planes_seq == ctx->state_seq && !ctx->paint_valid &&
-        ctx->pool_occ_bits.cap >= nwords * 8 && ctx->pool_nseen_bits.cap >= nwords * 8) {
+    if (ctx->planes_ok && ctx->planes_seq == ctx->state_seq && !ctx->paint_valid && ctx->planes_words == nwords &&
+        ctx->pool_state_planes.cap >= 2 * nwords * 8) {
         // the colour pass's planes are the state's (nothing but handleUnseen ran since): what the
         // closure calls occupied is their occupancy, with the never-seen voxels once those are occupied
         // (handleUnseen ran, or the caller says apply_unseen); the UNSEEN_COLOR plane is the never-seen one
-        const unsigned long long *p_occ = (const unsigned long long *)ctx->pool_occ_bits.p;
-        const unsigned long long *p_nseen = (const unsigned long long *)ctx->pool_nseen_bits.p;
+        const unsigned long long *p_occ = (const unsigned long long *)ctx->pool_state_planes.p;
+        const unsigned long long *p_nseen = p_occ + nwords;
         const bool merge = ctx->planes_unseen || apply_unseen;
         hipLaunchKernelGGL(arvx::bit_dilate_xy_kernel, dim3(gw), dim3(256), 0, ctx->stream, p_occ,
                            merge ? p_nseen : (const unsigned long long *)nullptr, g, radius, d_b, d_occ);

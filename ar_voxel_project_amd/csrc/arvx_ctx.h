@@ -97,7 +97,8 @@ struct Ctx {
     // the colour pass's bit planes of the state (occupied; seen by no view), kept for a closure that
     // follows: valid while state_seq == planes_seq; planes_unseen: handleUnseen has run since (the
     // records' occupancy is the occupancy plane | the never-seen plane)
-    DevPool pool_occ_bits, pool_nseen_bits;
+    DevPool pool_state_planes;  // occupancy plane, then never-seen plane (planes_words words each)
+    size_t planes_words = 0;
     unsigned long long planes_seq = 0;
     bool planes_ok = false, planes_unseen = false;
     DevPool pool_state_packets;  // arvx_state_download_packets: occupancy | seen, worst-case size each
@@ -213,8 +214,7 @@ struct Ctx {
         pool_chunk_counts.release();
         counts_stride = 0;
         pool_state_packets.release();
-        pool_occ_bits.release();
-        pool_nseen_bits.release();
+        pool_state_planes.release();
         planes_ok = false;
         packets_valid = false;
         compact_tickets = 0;
