@@ -20,7 +20,8 @@ further round with HIP events around single launches for `carve_kernel_ms` / `vi
 its own stream -- a caller with a stream of frames hides one job's latency-bound kernels behind
 another's issue-bound one; reported beside the headline, never as it.
 `e2e`: what SURVEY 8d asks for beside the resident-input figure: page-locked host masks -> device,
-the step, and the carved model's two bit planes back on the host.
+the step, and the carved model back on the host -- as two compressed packets (what arvx::Model reads;
+`planes_form`: as two plain bit planes).
 
 metric  Mvoxel-views/s = voxels x views / carve time  (BASELINE.json)
 N = 1   512^3 grid x 36 views (the configuration the metric is quoted on)
