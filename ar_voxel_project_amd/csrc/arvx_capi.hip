@@ -2421,9 +2421,33 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
     // about -- not filled here, their owners do it: zeros)
     int *d_counts = nullptr;
     if (int rc = chunk_counts(ctx, nwords, &d_counts)) return rc;
+    arvx::CarveParams rp;
+    carve_geometry(ctx, rp);
+    rp.rec = ctx->d_rec;
+    // Coarse tiles that exist only as their code: the few that receive a voxel are marked by the fill
+    // plane's producer and written out by rec_or_bitgrid_lazy_kernel, the others stay codes (grids
+    // whose rows and planes fill whole tiles; else every tile is written out first, as in round 4)
+    const bool lazy_or = ctx->lazy && ctx->Y % 8 == 0 && Zext % 8 == 0;
+    arvx::CoarseMark mark{lazy_or ? (uint8_t *)ctx->pool_ccode.p : nullptr, rp.coarseX, rp.coarseY, rp.cyShift,
+                          rp.czShift};
     hipLaunchKernelGGL(arvx::bit_dilate_z_count_kernel, dim3(gw), dim3(256), 0, ctx->stream, d_b, g,
                        radius, (const unsigned long long *)d_occ, f_lo - ctx->ze0, f_hi - ctx->ze0, d_fill,
-                       d_counts);
+                       d_counts, mark);
+    ARVX_HIP(hipGetLastError());
+    // The filled voxels are occupied from now on (their w is count / count = 1; the fill kernel reads
+    // the occupancy from the bit planes, not from the records).  Launched HERE, right behind the
+    // producer that marked the tiles: from this launch on the marks and the records agree, whatever
+    // happens to the rest of the call.
+    if (!lazy_or)
+        if (int mrc = need_rec(ctx)) return mrc;  // every record exists from here on
+    ++ctx->state_seq;
+    state_rewritten(ctx);  // (voxels of tiles an earlier carve emptied may be occupied again)
+    if (lazy_or)
+        hipLaunchKernelGGL(arvx::rec_or_bitgrid_lazy_kernel, dim3(gw), dim3(256), 0, ctx->stream, rp, g.Z,
+                           (const unsigned long long *)d_fill, (const uint8_t *)ctx->pool_ccode.p);
+    else
+        hipLaunchKernelGGL(arvx::rec_or_bitgrid_kernel, dim3(gw), dim3(256), 0, ctx->stream, rp, 0, g.Z,
+                           d_fill);
     ARVX_HIP(hipGetLastError());
     // The list of the filled voxels: compacted in one launch into buffers sized for what the last
     // closure needed (first call: a shell's share of the voxels); the true length is read at the
@@ -2433,9 +2457,6 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
         const double v = (double)nwords * 64.0;
         cap = (long long)std::min<double>(v, 8.0 * std::cbrt(v) * std::cbrt(v) + 4096.0);
     }
-    arvx::CarveParams rp;
-    carve_geometry(ctx, rp);
-    rp.rec = ctx->d_rec;
     long long total = 0;
     for (int attempt = 0;; ++attempt) {
         ARVX_HIP(ctx->pool_clo_index.reserve((size_t)cap * sizeof(int)));
@@ -2462,16 +2483,6 @@ int arvx_closure(arvx_ctx *ctx, int kernel_size, int apply_unseen) {
                                dim3(256), 0, ctx->stream, cp, ctx->d_clo_index, cap, d_total,
                                (float4 *)ctx->d_clo_rgba);
         ARVX_HIP(hipGetLastError());
-        if (attempt == 0) {
-            if (int mrc = need_rec(ctx)) return mrc;  // every record exists from here on
-            ++ctx->state_seq;
-            state_rewritten(ctx);  // (before any exit: voxels of tiles an earlier carve emptied may be occupied again)
-            // the filled voxels are occupied from now on (their w is count / count = 1); the fill
-            // kernel reads the occupancy from the bit planes, not from the records
-            hipLaunchKernelGGL(arvx::rec_or_bitgrid_kernel, dim3(gw), dim3(256), 0, ctx->stream, rp, 0,
-                               g.Z, d_fill);
-            ARVX_HIP(hipGetLastError());
-        }
         ARVX_SYNC(ctx);
         total = host_total(ctx, 1);
         if (total < 0) return fail(ARVX_ERR_HIP, "the compaction left no count");

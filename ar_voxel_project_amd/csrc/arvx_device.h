@@ -135,8 +135,13 @@ __host__ __device__ __forceinline__ size_t rec_count(const CarveParams &p) {
 __device__ __forceinline__ int coarse_of(const CarveParams &p, int tx, int ty, int tz) {
     return tx + p.coarseX * ((ty >> p.cyShift) + p.coarseY * (tz >> p.czShift));
 }
+// (bit 7 of a code: the tile's records have been written out since -- by the closure, which
+// fills voxels into a few coded tiles, rec_or_bitgrid_lazy_kernel -- and hold the state again)
+constexpr int kCodeWritten = 0x80;
 __device__ __forceinline__ int lazy_code(const CarveParams &p, int tx, int ty, int tz) {
-    return p.ccode ? (int)p.ccode[coarse_of(p, tx, ty, tz)] : 0;
+    if (!p.ccode) return 0;
+    const int c = (int)p.ccode[coarse_of(p, tx, ty, tz)];
+    return (c & kCodeWritten) ? 0 : c;
 }
 // in-grid voxels of entry r of sub-tile `wave` of tile (tx, ty, tz)
 __device__ __forceinline__ uint32_t row_inmask(const CarveParams &p, int tx, int ty, int tz,

@@ -293,12 +293,21 @@ __global__ __launch_bounds__(256) void bit_surface_count_kernel(const unsigned l
 // out = (OR of the planes z-r..z+r of `in`) & ~minus for the planes [zlo, zhi), zeros elsewhere;
 // counts[chunk] += its set bits (the closure's fill plane: bit_dilate_xy_kernel's output dilated
 // along z, without the voxels that are occupied already)
+// mark (may be null): the per-coarse-tile codes of the lazy state (arvx_device.h); a coded tile that
+// receives a bit here gets bit 7 of its code set (every writer stores the same byte), for
+// rec_or_bitgrid_lazy_kernel.  A coarse tile is 64 voxels in x -- one word -- by 8 << cyShift rows by
+// 8 << czShift planes, coarseX x coarseY tiles per plane of tiles.
+struct CoarseMark {
+    uint8_t *code;
+    int coarseX, coarseY, cyShift, czShift;
+};
 __global__ __launch_bounds__(256) void bit_dilate_z_count_kernel(const unsigned long long *__restrict__ in,
                                                                  const BitGrid g, int r,
                                                                  const unsigned long long *__restrict__ minus,
                                                                  int zlo, int zhi,
                                                                  unsigned long long *__restrict__ out,
-                                                                 int *__restrict__ counts) {
+                                                                 int *__restrict__ counts,
+                                                                 const CoarseMark mark) {
     const size_t nwords = (size_t)g.XW * g.Y * g.Z;
     const size_t plane = (size_t)g.XW * g.Y;
     const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -311,6 +320,13 @@ __global__ __launch_bounds__(256) void bit_dilate_z_count_kernel(const unsigned 
             acc &= ~minus[w];
         }
         out[w] = acc;
+        if (acc && mark.code) {
+            const int xw = (int)(w % g.XW), y = (int)((w / g.XW) % g.Y);
+            uint8_t *c = mark.code + xw + mark.coarseX * ((y >> (3 + mark.cyShift)) +
+                                                         mark.coarseY * (z >> (3 + mark.czShift)));
+            const uint8_t v = *c;
+            if (v && !(v & 0x80)) *c = (uint8_t)(v | 0x80);
+        }
     }
     chunk_count_add(counts, w, __popcll(acc));
 }

@@ -391,7 +391,9 @@ __device__ __forceinline__ void coarse_fill(const CarveParams &p, const int ct, 
 
 // (flags bit4: every coarse tile as "untouched, not seen" -- a fresh model as records)
 __global__ __launch_bounds__(256) void carve_fill_kernel(const CarveParams p) {
-    coarse_fill(p, blockIdx.x, (p.flags & 16u) ? 3 : p.coarseCarved[blockIdx.x]);
+    int code = (p.flags & 16u) ? 3 : p.coarseCarved[blockIdx.x];
+    if (code & kCodeWritten) code = 0;  // (written out already: rec_or_bitgrid_lazy_kernel)
+    coarse_fill(p, blockIdx.x, code);
 }
 
 // Pre-pass and fill in one launch, one workgroup per coarse tile: its first wave classifies

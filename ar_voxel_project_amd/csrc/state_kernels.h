@@ -267,6 +267,43 @@ __global__ __launch_bounds__(256) void rec_or_bitgrid_kernel(const CarveParams p
     }
 }
 
+// rec_or_bitgrid_kernel where coarse tiles may exist only as their code (lazy state, arvx_device.h;
+// Y and the planes held are multiples of 8: every row of a tile has a word of the plane).  The
+// plane's producer has marked the coded tiles that receive a bit (bit 7 of the code,
+// bit_dilate_z_count_kernel): every word's thread of such a tile writes its row's eight entries --
+// the code's constants with the bits on top --, and from this launch on the marked code reads as
+// "records hold the state" (lazy_code).  Tiles without a code get the bits OR-ed in as above; coded
+// tiles without a mark receive nothing and stay codes.
+__global__ __launch_bounds__(256) void rec_or_bitgrid_lazy_kernel(const CarveParams p, int nz,
+                                                                  const unsigned long long *__restrict__ bits,
+                                                                  const uint8_t *__restrict__ ccode) {
+    const int XW = (p.X + 63) >> 6;
+    const size_t n = (size_t)XW * p.Y * nz;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int xw = (int)(i % XW), y = (int)((i / XW) % p.Y), z = (int)(i / ((size_t)XW * p.Y));
+    const int c = (int)ccode[coarse_of(p, xw, y >> 3, z >> 3)];
+    const unsigned long long w = bits[i];
+    const int r = (z & 7) * 8 + (y & 7);
+    uint16_t *rec = p.rec + rec_index(p, xw, y >> 3, z >> 3, 0) * kRecU16;
+    if (!(c & 0x7f)) {  // records hold the state
+        if (!w) return;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint16_t e = (uint16_t)(w >> (16 * k));
+            if (e) rec[k * kRecU16 + r] |= e;
+        }
+    } else if (c & kCodeWritten) {  // a coded tile that receives voxels: written out, row by row
+        const int code = c & 0x7f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            rec[k * kRecU16 + r] =
+                (uint16_t)(lazy_occ(p, code, xw, y >> 3, z >> 3, k, r) | (uint32_t)(uint16_t)(w >> (16 * k)));
+            rec[k * kRecU16 + 64 + r] = (uint16_t)lazy_seen(p, code, xw, y >> 3, z >> 3, k, r);
+        }
+    }
+}
+
 // Model::handleUnseen on records: occ |= ~seen (voxels outside the grid are kept "seen").  The
 // records of a coarse tile that exists only as its code (ccode, may be null; 2^rec_shift records
 // per coarse tile) are nobody's to read: skipped -- "carved and seen", "untouched and seen" and
@@ -276,7 +313,10 @@ __global__ __launch_bounds__(256) void rec_handle_unseen_kernel(uint32_t *__rest
                                                                 int rec_shift) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;  // record t / 32, word t % 32
     if (t >= nrec * 32) return;
-    if (ccode && ccode[(t >> 5) >> rec_shift]) return;
+    if (ccode) {
+        const int c = ccode[(t >> 5) >> rec_shift];
+        if (c && !(c & kCodeWritten)) return;
+    }
     uint32_t *r = rec32 + (t >> 5) * 64 + (t & 31);
     r[0] |= ~r[32];
 }

@@ -128,3 +128,56 @@ def test_closure_matches_golden(arvx, name):
     _, _, out, _ = pipeline(arvx, g["X"], g["Y"], g["Z"], g["s"], g["M"], g["campos"], g["masks"],
                             g["images"], 1, True)
     assert np.array_equal(out, g["closed_rgba"])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_closure_fills_into_tiles_that_exist_only_as_a_code(arvx, oracle, seed):
+    """Grids of whole tiles (Y, Z multiples of 8), fresh carve: most coarse tiles exist only as their
+    code when the closure runs, and some of the voxels it fills lie in tiles coded "carved".  Those
+    tiles -- and only those -- are written out by rec_or_bitgrid_lazy_kernel; everything that reads
+    the state afterwards (export, planes, packets, the cell list, a second carve of the same model,
+    handleUnseen) must see records and codes agree."""
+    rng = np.random.default_rng(700 + seed)
+    X = int(rng.choice([64, 96, 128, 200]))
+    Y = 8 * int(rng.integers(4, 20))
+    Z = 8 * int(rng.integers(4, 20))
+    V = int(rng.integers(2, 7))
+    W, H = 160, 120
+    s = np.float32(0.512 / max(X, Y, Z))
+    _, Rt, M = scenes.random_cameras(V, 0.512, seed=seed + 31, W=W, H=H)
+    campos = np.ascontiguousarray(Rt[:, :, 3], dtype=np.float32)
+    masks = scenes.noise_masks(V, H, W, block=int(rng.choice([12, 24, 48])), p_bg=float(rng.uniform(0.3, 0.6)),
+                               seed=seed + 5)
+    images = rng.integers(0, 256, size=(V, H, W, 3), dtype=np.uint8)
+    unseen = bool(seed % 2)
+    st = oracle.carve(X, Y, Z, s, M, masks)
+    model = oracle.color(X, Y, Z, s, M, campos, images, 1, oracle.model_from_state(st))
+    if unseen:
+        model = oracle.handle_unseen(st, model)
+    want = oracle.closure(X, Y, Z, model)
+    with arvx.Context(X, Y, Z, s) as ctx:
+        ctx.set_views(M, masks, campos=campos)
+        ctx.set_images(images)
+        ctx.carve()
+        ctx.color(arvx.COLOR_AVERAGE)
+        if unseen and seed % 4 == 1:
+            ctx.handle_unseen()  # (the closure then starts from the colour pass's planes)
+        ctx.closure(3, unseen)
+        assert np.array_equal(ctx.mc_cells(), oracle.mc_cells(X, Y, Z, want))
+        occ_want = (want[:, 3] != 0).reshape(Z, Y, X)
+        if X % 32 == 0:
+            po, ps, no, ns = ctx.download_packets()
+        occ, seen = ctx.download_planes()
+        got = np.unpackbits(occ.view(np.uint8), bitorder="little").reshape(Z, Y, -1)[:, :, :X].astype(bool)
+        handled = unseen and seed % 4 == 1  # handleUnseen ran on the device: unseen voxels ARE occupied
+        st_after = ctx.download_state()
+        occ_state = ((st_after & 1) == 1) | ((not handled) & unseen & ((st_after & 2) == 0))
+        assert np.array_equal(occ_state, occ_want)
+        assert np.array_equal(got, (st_after & 1) == 1)
+        assert np.array_equal(ctx.export_model(unseen), want)
+        # the same model carved again by other views (every record must exist and be right)
+        _, _, M2 = scenes.random_cameras(3, 0.512, seed=seed + 77, W=W, H=H)
+        masks2 = scenes.noise_masks(3, H, W, block=16, p_bg=0.4, seed=seed + 9)
+        ctx.set_views(M2, masks2)
+        ctx.carve()
+        assert np.array_equal(ctx.download_state(), oracle.carve(X, Y, Z, s, M2, masks2, state=st_after))
