@@ -26,8 +26,12 @@ needs_reference = pytest.mark.skipif(not os.path.exists(os.path.join(REF_SRC, "m
                                      reason="the reference checkout is not on this machine")
 
 
-def _syntax_only(source, *include_dirs, extra=()):
-    cmd = ["g++", "-std=c++17", "-fsyntax-only", *extra]
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+COMPILERS = ["g++"] + ([CLANG] if os.path.exists(CLANG) else [])
+
+
+def _syntax_only(source, *include_dirs, extra=(), cxx="g++"):
+    cmd = [cxx, "-std=c++17", "-fsyntax-only", *extra]
     for d in include_dirs:
         cmd.append("-I" + d)
     cmd.append(source)
@@ -39,11 +43,13 @@ MOCKS = (os.path.join(ROOT, "tests", "cpp", "mock_opencv"),
 
 
 @needs_reference
-def test_reference_main_compiles_unchanged(tmp_path):
-    """Zero source edits: include/arvx/dropin on the include path, the replaced files gone."""
+@pytest.mark.parametrize("cxx", COMPILERS)
+def test_reference_main_compiles_unchanged(tmp_path, cxx):
+    """Zero source edits: include/arvx/dropin on the include path, the replaced files gone
+    (g++, and ROCm's clang++ where it is installed)."""
     shutil.copy(os.path.join(REF_SRC, "main.cpp"), tmp_path / "main.cpp")
     r = _syntax_only(str(tmp_path / "main.cpp"), os.path.join(ROOT, "include", "arvx", "dropin"),
-                     os.path.join(ROOT, "include"), *MOCKS, REF_SRC)
+                     os.path.join(ROOT, "include"), *MOCKS, REF_SRC, cxx=cxx)
     assert r.returncode == 0, r.stderr[-4000:]
     # the headers under test were the ones read (not the reference's own, which sit in REF_SRC)
     deps = subprocess.run(["g++", "-std=c++17", "-MM", "-I" + os.path.join(ROOT, "include", "arvx", "dropin"),
@@ -80,8 +86,9 @@ def test_reference_main_needs_the_dropin_headers(tmp_path):
     assert r.returncode != 0
 
 
+@pytest.mark.parametrize("cxx", COMPILERS)
 @pytest.mark.parametrize("eigen", [False, True])
-def test_dropin_surface_type_checks(eigen):
+def test_dropin_surface_type_checks(eigen, cxx):
     """tests/cpp/dropin_typecheck.cpp: the five free functions and Model / SimpleMesh / Benchmark
     used the way the reference's replaced sources use them, with the stand-in vector types and
     with (mock) Eigen's; -Werror."""
@@ -89,5 +96,5 @@ def test_dropin_surface_type_checks(eigen):
     if eigen:
         dirs.append(MOCKS[1])
     r = _syntax_only(os.path.join(ROOT, "tests", "cpp", "dropin_typecheck.cpp"), *dirs,
-                     extra=("-Wall", "-Wextra", "-Werror"))
+                     extra=("-Wall", "-Wextra", "-Werror"), cxx=cxx)
     assert r.returncode == 0, r.stderr[-4000:]
