@@ -566,201 +566,7 @@ __device__ __forceinline__ void subtile_store_done(uint16_t *__restrict__ rec, i
     reinterpret_cast<uint32_t *>(rec)[lane] = lane < 32 ? 0u : 0xffffffffu;
 }
 
-template <bool LEFT>
-__global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p) {
-#ifdef ARVX_TIMELINE
-    TimelineScope timeline_scope(p.timeline);
-#endif
-    // Rows of tiles along x are dealt to the 8 XCDs cyclically (blocks b, b+8, b+16.. share
-    // an XCD), which spreads the expensive surface tiles evenly: contiguous z ranges per XCD
-    // left the XCDs that own the empty top and bottom of the grid idle (+40 % on the sphere
-    // scene).
-    const unsigned k = blockIdx.x >> 3;
-    const unsigned trow = (k / p.tilesX) * 8u + (blockIdx.x & 7u);
-    if (trow >= (unsigned)(p.tilesY * p.tilesZ)) return;
-    const int tx = k % p.tilesX;
-    const int ty = trow % p.tilesY;
-    const int tz = trow / p.tilesY;
-
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    const bool cull = !(p.flags & 1u);
-    const int ct =
-        cull ? tx + p.coarseX * ((ty >> p.cyShift) + p.coarseY * (tz >> p.czShift)) : 0;
-    const int code = cull ? p.coarseCarved[ct] : 0;  // workgroup-uniform (scalar load)
-    const bool coarse_carved = code == 1;
-    uint16_t *const rec = p.rec + rec_index(p, tx, ty, tz, wave) * kRecU16;
-    // Pure fill of a tile that the pre-pass decided: carved+seen (code 1), or, for a fresh
-    // model, untouched occupancy with (2) / without (3) the seen bit.
-    if (coarse_carved || (code >= 2 && (p.flags & 4u))) {
-        uint32_t pair = 0;  // entries 2 * (lane & 31), + 1 of the occ (lane < 32) / seen half
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint32_t in = row_inmask(p, tx, ty, tz, wave, 2 * (lane & 31) + h);
-            const uint32_t v = code == 1 ? (lane < 32 ? 0u : 0xffffu)
-                                         : (lane < 32 ? in : (code == 2 ? 0xffffu : (~in & 0xffffu)));
-            pair |= v << (16 * h);
-        }
-        reinterpret_cast<uint32_t *>(rec)[lane] = pair;
-        if ((p.flags & 2u) && lane == 0) {
-            atomicAdd(&p.stats[0], 1ull);
-            if (coarse_carved) atomicAdd(&p.stats[1], 1ull);
-        }
-        return;
-    }
-    const int sx0 = tx * kTileX + wave * kSubX;
-    if (sx0 >= p.X) return;  // wave-uniform
-    const int sy0 = ty * kTileY;
-    const int sz0 = tz * kTileZ;
-    const int sx1 = min(sx0 + kSubX - 1, p.X - 1);
-    const int sy1 = min(sy0 + kTileY - 1, p.Y - 1);
-    const int sz1 = min(sz0 + kTileZ - 1, p.Z - 1);
-
-    const int x = sx0 + 4 * (lane & 3);
-    const int y = sy0 + ((lane >> 2) & 7);
-    const int zb = sz0 + 4 * (lane >> 5);
-
-    // per-lane world coordinates, reference src/Model.h:134-140
-    const double dwy = (double)((float)y * p.s);
-    double dwx[4], dwz[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dwx[j] = (double)((float)(x + j) * p.s);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dwz[k] = (double)((float)(-global_z(p, zb + k)) * p.s);
-
-    uint32_t st[4] = {kDone4, kDone4, kDone4, kDone4};
-    bool loaded = false, all_carved = false, all_done = false;
-    if (coarse_carved) {
-        all_carved = true;
-        if ((p.flags & 2u) && lane == 0) {
-            atomicAdd(&p.stats[0], 1ull);
-            atomicAdd(&p.stats[1], 1ull);
-        }
-    }
-    const BoxW box = make_box(p.s, sx0, sx1, sy0, sy1, global_z(p, sz0), global_z(p, sz1));
-
-    int chunk = 0;
-    for (int vc = p.v0; vc < p.v1 && !all_done && !all_carved; vc += 64, ++chunk) {
-        const int myv = vc + lane;
-        int cls = kClsOut;
-        if (myv < p.v1) {
-            if (!cull) {
-                cls = kClsMixed;
-            } else {
-                const unsigned long long cm = p.coarseMixed[(size_t)ct * p.nchunks + chunk];
-                const unsigned long long cf = p.coarseFg[(size_t)ct * p.nchunks + chunk];
-                if ((cf >> lane) & 1ull)
-                    cls = kClsFg;  // inherited: the coarse rectangle contains this one
-                else if ((cm >> lane) & 1ull)
-                    cls = classify_box(p.M + 12 * myv, box, p.W, p.H,
-                                       p.sat + (size_t)myv * p.satStride, p.satW);
-            }
-        }
-        const unsigned long long fastdiv = __ballot((cls & kFastDiv) != 0);
-        cls &= 3;
-        const unsigned long long carved = __ballot(cls == kClsCarved);
-        unsigned long long mixed = __ballot(cls == kClsMixed);
-        const unsigned long long infg = __ballot(cls == kClsFg);
-        if (p.flags & 2u) {
-            if (lane == 0) {
-                if (vc == p.v0) atomicAdd(&p.stats[0], 1ull);
-                if (carved) atomicAdd(&p.stats[1], 1ull);
-                atomicAdd(&p.stats[2], (unsigned long long)__popcll(mixed));
-                atomicAdd(&p.stats[3], (unsigned long long)min(64, p.v1 - vc));
-            }
-        }
-        if (carved) {
-            all_carved = true;
-            break;
-        }
-        if (!loaded) {
-            loaded = true;
-            subtile_load(p, subtile_of(p, tx, ty, tz, wave, lane), rec, lane, st);
-        }
-        if (infg) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) st[k] |= kDone4;  // seen, src/VoxelCarving.cpp:54
-        }
-        while (mixed) {
-            const int b = __ffsll((long long)mixed) - 1;
-            mixed &= mixed - 1;
-            const int view = __builtin_amdgcn_readfirstlane(vc + b);
-            const float *__restrict__ Mv = p.M + 12 * view;
-            const uint32_t *__restrict__ bgv = p.bg + (size_t)view * p.bgWords;
-            // (row-wise lane map: 4 x, one y, 4 z per lane.  The products are hoisted; the
-            // sums follow row_sum's grouping, which the compiler hoists where it can)
-            double p0[3], p1[3][4], p3[3], m2[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                p0[r] = (double)Mv[4 * r] * dwy;
-                const double m1 = (double)Mv[4 * r + 1];
-                m2[r] = (double)Mv[4 * r + 2];
-                p3[r] = (double)Mv[4 * r + 3];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) p1[r][j] = m1 * dwx[j];
-            }
-            const bool fast = (fastdiv >> b) & 1ull;  // wave-uniform
-            const float wlim = (float)p.W - 0.5f, hlim = (float)p.H - 0.5f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!__any(st[k] != kDone4)) continue;  // these 256 voxels are finished
-                if (p.flags & 2u) {  // how many of the 256 evaluations were still open
-                    const uint32_t x4 = st[k] ^ kDone4;
-                    int open = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) open += ((x4 >> (8 * j)) & 0xffu) ? 1 : 0;
-#pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) open += __shfl_xor(open, d);
-                    if (lane == 0) {
-                        atomicAdd(&p.stats[5], 1ull);
-                        atomicAdd(&p.stats[6], (unsigned long long)open);
-                    }
-                }
-                const double p20 = m2[0] * dwz[k], p21 = m2[1] * dwz[k], p22 = m2[2] * dwz[k];
-                uint32_t w = st[k];
-                // project the four voxels first, then issue the four table reads together:
-                // the loop is bound by the latency of these dependent reads, not by VALU
-                int pix[4];
-                bool in[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float a0 = row_sum<LEFT>(p0[0], p1[0][j], p20, p3[0]);
-                    const float a1 = row_sum<LEFT>(p0[1], p1[1][j], p21, p3[1]);
-                    const float a2 = row_sum<LEFT>(p0[2], p1[2][j], p22, p3[2]);
-                    float u, v;
-                    if (fast) {
-                        divide2_shared_rcp(a0, a1, a2, u, v);
-                    } else {
-                        u = a0 / a2;
-                        v = a1 / a2;
-                    }
-                    in[j] = pixel_from_quotients(u, v, p.W, wlim, hlim, pix[j]);
-                }
-                uint32_t word[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) word[j] = bgv[(unsigned)pix[j] >> 5];  // pix = 0 outside
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t isbg = in[j] ? ((word[j] >> (pix[j] & 31)) & 1u) : 0u;
-                    const uint32_t seen = in[j] ? (2u << (8 * j)) : 0u;
-                    w = (w | seen) & ~(isbg << (8 * j));
-                }
-                st[k] = w;
-            }
-            if (__all(st[0] == kDone4 && st[1] == kDone4 && st[2] == kDone4 &&
-                      st[3] == kDone4)) {
-                all_done = true;
-                break;
-            }
-        }
-    }
-
-    if (all_carved) {
-        subtile_store_done(rec, lane);
-    } else if (loaded) {  // (else: empty view range, nothing changed)
-        subtile_store(rec, lane, st);
-    }
-}
+// (carve_fused_kernel, the brute-force form, follows exact_view_blocks below: it is built on it)
 
 // ---------------------------------------------------------------------------------
 // Split form of the same algorithm (the default when culling is on):
@@ -1529,6 +1335,175 @@ __device__ __forceinline__ bool exact_view_blocks(const CarveParams &p, const in
         st[m] = w;
     }
     return __all(st[0] == kDone4 && st[1] == kDone4 && st[2] == kDone4 && st[3] == kDone4);
+}
+
+// The brute-force form: every sub-tile, every view (ARVX_CARVE_NO_CULL: the ablation and the
+// yardstick of the tests; with the culling on, the one-kernel form ARVX_CARVE_FUSED and more than
+// 256 views).  One wave per sub-tile, the views one after the other through exact_view_blocks --
+// the exact kernel's own block-mapped evaluation: the matrix through the scalar cache, the (y, x)
+// part of the rows hoisted, all sixteen blocks projected before the table is read, ONE wait per view
+// (round 5; the row-mapped form before it waited four times per view and read the matrix with
+// vector loads: 2.16 -> EXPERIMENTS.md round 5).
+template <bool LEFT>
+__global__ __launch_bounds__(256, 4) void carve_fused_kernel(const CarveParams p) {
+#ifdef ARVX_TIMELINE
+    TimelineScope timeline_scope(p.timeline);
+#endif
+    // Rows of tiles along x are dealt to the 8 XCDs cyclically (blocks b, b+8, b+16.. share
+    // an XCD), which spreads the expensive surface tiles evenly: contiguous z ranges per XCD
+    // left the XCDs that own the empty top and bottom of the grid idle (+40 % on the sphere
+    // scene).
+    const unsigned k = blockIdx.x >> 3;
+    const unsigned trow = (k / p.tilesX) * 8u + (blockIdx.x & 7u);
+    if (trow >= (unsigned)(p.tilesY * p.tilesZ)) return;
+    const int tx = k % p.tilesX;
+    const int ty = trow % p.tilesY;
+    const int tz = trow / p.tilesY;
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const bool cull = !(p.flags & 1u);
+    const int ct =
+        cull ? tx + p.coarseX * ((ty >> p.cyShift) + p.coarseY * (tz >> p.czShift)) : 0;
+    const int code = cull ? p.coarseCarved[ct] : 0;  // workgroup-uniform (scalar load)
+    const bool coarse_carved = code == 1;
+    uint16_t *const rec = p.rec + rec_index(p, tx, ty, tz, wave) * kRecU16;
+    // Pure fill of a tile that the pre-pass decided: carved+seen (code 1), or, for a fresh
+    // model, untouched occupancy with (2) / without (3) the seen bit.
+    if (coarse_carved || (code >= 2 && (p.flags & 4u))) {
+        uint32_t pair = 0;  // entries 2 * (lane & 31), + 1 of the occ (lane < 32) / seen half
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t in = row_inmask(p, tx, ty, tz, wave, 2 * (lane & 31) + h);
+            const uint32_t v = code == 1 ? (lane < 32 ? 0u : 0xffffu)
+                                         : (lane < 32 ? in : (code == 2 ? 0xffffu : (~in & 0xffffu)));
+            pair |= v << (16 * h);
+        }
+        reinterpret_cast<uint32_t *>(rec)[lane] = pair;
+        if ((p.flags & 2u) && lane == 0) {
+            atomicAdd(&p.stats[0], 1ull);
+            if (coarse_carved) atomicAdd(&p.stats[1], 1ull);
+        }
+        return;
+    }
+    const SubTile t = subtile_of(p, tx, ty, tz, wave, lane);
+    if (t.sx0 >= p.X) return;  // wave-uniform
+    // block map: one voxel of each of the sixteen 4 x 4 x 4 blocks per lane (exact_view_blocks)
+    const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
+    float wx[4], wy[2], wz[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wx[j] = (float)(t.sx0 + 4 * j + lx) * p.s;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        wy[b] = (float)(t.sy0 + 4 * b + ly) * p.s;
+        wz[b] = (float)(-global_z(p, t.sz0 + 4 * b + lz)) * p.s;
+    }
+    uint32_t st[4] = {kDone4, kDone4, kDone4, kDone4};
+    bool loaded = false, all_carved = false, all_done = false;
+    const BoxW box = make_box(p.s, t.sx0, t.sx1, t.sy0, t.sy1, global_z(p, t.sz0), global_z(p, t.sz1));
+
+    int chunk = 0;
+    for (int vc = p.v0; vc < p.v1 && !all_done && !all_carved; vc += 64, ++chunk) {
+        const int myv = vc + lane;
+        int cls = kClsOut;
+        if (myv < p.v1) {
+            if (!cull) {
+                // every voxel is projected; the rectangle arithmetic only says whether the shared-
+                // reciprocal division is the IEEE one on this box (no table is looked at)
+                float Mr[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) Mr[i] = p.M[12 * myv + i];
+                cls = kClsMixed | rect_prepare(Mr, box, p.W, p.H, p.satW).fast;
+            } else {
+                const unsigned long long cm = p.coarseMixed[(size_t)ct * p.nchunks + chunk];
+                const unsigned long long cf = p.coarseFg[(size_t)ct * p.nchunks + chunk];
+                if ((cf >> lane) & 1ull)
+                    cls = kClsFg;  // inherited: the coarse rectangle contains this one
+                else if ((cm >> lane) & 1ull)
+                    cls = classify_box(p.M + 12 * myv, box, p.W, p.H,
+                                       p.sat + (size_t)myv * p.satStride, p.satW);
+            }
+        }
+        const unsigned long long fastdiv = __ballot((cls & kFastDiv) != 0);
+        cls &= 3;
+        const unsigned long long carved = __ballot(cls == kClsCarved);
+        unsigned long long mixed = __ballot(cls == kClsMixed);
+        const unsigned long long infg = __ballot(cls == kClsFg);
+        if (p.flags & 2u) {
+            if (lane == 0) {
+                if (vc == p.v0) atomicAdd(&p.stats[0], 1ull);
+                if (carved) atomicAdd(&p.stats[1], 1ull);
+                atomicAdd(&p.stats[2], (unsigned long long)__popcll(mixed));
+                atomicAdd(&p.stats[3], (unsigned long long)min(64, p.v1 - vc));
+            }
+        }
+        if (carved) {
+            all_carved = true;
+            break;
+        }
+        if (!loaded) {  // record -> blocks (as carve_exact_blocks_kernel)
+            loaded = true;
+#pragma unroll
+            for (int byi = 0; byi < 2; ++byi)
+#pragma unroll
+                for (int bzi = 0; bzi < 2; ++bzi) {
+                    const int r = (4 * bzi + lz) * 8 + 4 * byi + ly;
+                    uint32_t o, sn;
+                    if (p.flags & 4u) {  // fresh model, never written: all occupied, none seen
+                        o = row_inmask(p, tx, ty, tz, wave, r);
+                        sn = ~o & 0xffffu;
+                    } else {
+                        o = rec[r];
+                        sn = rec[64 + r];
+                    }
+                    st[2 * byi + bzi] = spread4((o >> lx) & 0x1111u) | (spread4((sn >> lx) & 0x1111u) << 1);
+                }
+        }
+        if (infg) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) st[m] |= kDone4;  // seen, src/VoxelCarving.cpp:54
+        }
+        while (mixed) {
+            const int b = __ffsll((long long)mixed) - 1;
+            mixed &= mixed - 1;
+            if (p.flags & 2u) {  // how many of the 1 024 evaluations were still open
+                int open = 0;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const uint32_t x4 = st[m] ^ kDone4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) open += ((x4 >> (8 * j)) & 0xffu) ? 1 : 0;
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) open += __shfl_xor(open, d);
+                if (lane == 0) {
+                    atomicAdd(&p.stats[5], 4ull);  // (in 256-voxel slices, as the row-mapped kernels count)
+                    atomicAdd(&p.stats[6], (unsigned long long)open);
+                }
+            }
+            all_done = exact_view_blocks<LEFT>(p, __builtin_amdgcn_readfirstlane(vc + b), (fastdiv >> b) & 1ull, wy,
+                                               wx, wz, st, 0xffffu);
+            if (all_done) break;
+        }
+    }
+
+    if (all_carved) {
+        subtile_store_done(rec, lane);
+    } else if (loaded) {  // (else: empty view range, nothing changed) blocks -> record
+#pragma unroll
+        for (int byi = 0; byi < 2; ++byi)
+#pragma unroll
+            for (int bzi = 0; bzi < 2; ++bzi) {
+                const uint32_t w = st[2 * byi + bzi];
+                uint32_t both = (gather4(w & 0x01010101u) << lx) | (gather4((w >> 1) & 0x01010101u) << (16 + lx));
+                both |= __shfl_xor(both, 1);
+                both |= __shfl_xor(both, 2);
+                if (lx != 0) continue;
+                const int r = (4 * bzi + lz) * 8 + 4 * byi + ly;
+                rec[r] = (uint16_t)both;
+                rec[64 + r] = (uint16_t)(both >> 16);
+            }
+    }
 }
 
 // ---- the fp32 filter (round 5; experiment builds only: it loses, EXPERIMENTS.md) -------------------
