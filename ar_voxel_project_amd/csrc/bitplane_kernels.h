@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void bit_compact_counted_kernel(
 }
 
 // The scans in ONE launch, the same way: a chunk of kScanChunk entries per workgroup and ticket.
-constexpr int kScanChunk = 4096;
+constexpr int kScanChunk = 4096;  // (8192: the triangle scan 19.8 -> 21.3 us, the column scan 10.1 -> 14.2: EXPERIMENTS.md round 5)
 
 // Exclusive scan of one small count per entry (counts[i] >= 0): offsets[i] (32 bits); the sum goes to
 // *total and *total_host.  kLookup: the count of entry i is table[keys[4 i + 3] & 255] (the triangles of
