@@ -582,6 +582,42 @@ class Model {
         sync_bits();
         expand_planes();
     }
+    // A state packet (include/arvx/arvx.h, arvx_state_download_packets) read on the host; n: 64-bit
+    // words of the plane, H: header words.  packet_bit: bit i of the plane -- its word is all-one, or
+    // mixed (then it is the popcount-th mixed word of its group of 64 words), or all-zero.
+    // expand_packet: the whole plane as 2 n 32-bit words.  (Pure functions of the packet: also what
+    // tests/test_cpp_host.py::test_packet_decoding_on_the_host checks without a GPU.)
+    static bool packet_bit(const uint64_t *pk, int64_t n, int64_t H, size_t i) {
+        const int64_t nb = (n + 63) / 64;
+        const size_t W = i >> 6, g = W >> 6;
+        const unsigned b = (unsigned)(W & 63);
+        if ((pk[1 + g] >> b) & 1u) return true;
+        const uint64_t m = pk[1 + nb + g];
+        if (!((m >> b) & 1u)) return false;
+        const uint32_t *goff = reinterpret_cast<const uint32_t *>(pk + 1 + 2 * nb);
+        const uint64_t w = pk[H + goff[g] + (uint32_t)__builtin_popcountll(m & ((1ull << b) - 1ull))];
+        return (w >> (i & 63)) & 1u;
+    }
+    static void expand_packet(const uint64_t *pk, int64_t n, int64_t H, uint32_t *out) {
+        const int64_t nb = (n + 63) / 64;
+        const uint32_t *goff = reinterpret_cast<const uint32_t *>(pk + 1 + 2 * nb);
+        for (int64_t g = 0; g < nb; ++g) {
+            const uint64_t ones = pk[1 + g], mixed = pk[1 + nb + g];
+            const uint64_t *mw = pk + H + goff[g];
+            const int64_t w0 = g * 64, w1 = std::min<int64_t>(w0 + 64, n);
+            if (!mixed && (ones == 0 || (ones == ~0ull && w1 - w0 == 64))) {  // a uniform group
+                std::fill(out + 2 * w0, out + 2 * w1, ones ? 0xffffffffu : 0u);
+                continue;
+            }
+            for (int64_t w = w0; w < w1; ++w) {
+                const unsigned b = (unsigned)(w - w0);
+                uint64_t v = ((ones >> b) & 1u) ? ~0ull : 0ull;
+                if ((mixed >> b) & 1u) v = *mw++;
+                out[2 * w] = (uint32_t)v;
+                out[2 * w + 1] = (uint32_t)(v >> 32);
+            }
+        }
+    }
     // does the host hold the state as packets only right now?  (tests, tools/dropin_times)
     bool planes_pending() const { return planes_stale_; }
     size_t packet_bytes() const { return planes_stale_ ? 8 * (size_t)(2 * pk_H_ + (int64_t)pk_occ_[0] + (int64_t)pk_seen_[0]) : 0; }
@@ -627,19 +663,6 @@ class Model {
         sync_bits();
         return occ_bit(x, y, z);
     }
-    // one voxel's bit from a packet: its 64-bit word is all-one, or mixed (then it is the
-    // popcount-th mixed word of its group of 64 words), or all-zero
-    static bool packet_bit(const uint64_t *pk, int64_t n, int64_t H, size_t i) {
-        const int64_t nb = (n + 63) / 64;
-        const size_t W = i >> 6, g = W >> 6;
-        const unsigned b = (unsigned)(W & 63);
-        if ((pk[1 + g] >> b) & 1u) return true;
-        const uint64_t m = pk[1 + nb + g];
-        if (!((m >> b) & 1u)) return false;
-        const uint32_t *goff = reinterpret_cast<const uint32_t *>(pk + 1 + 2 * nb);
-        const uint64_t w = pk[H + goff[g] + (uint32_t)__builtin_popcountll(m & ((1ull << b) - 1ull))];
-        return (w >> (i & 63)) & 1u;
-    }
     // (in-grid voxel; after sync_bits)
     bool occ_bit(int x, int y, int z) const {
         if (planes_stale_) return packet_bit(pk_occ_.data(), pk_n_, pk_H_, (size_t)flatten(x, y, z));
@@ -653,28 +676,8 @@ class Model {
     void expand_planes() const {
         if (!planes_stale_) return;
         planes_stale_ = false;
-        const int64_t n = pk_n_, nb = (n + 63) / 64, H = pk_H_;
-        for (int which = 0; which < 2; ++which) {
-            const uint64_t *pk = which ? pk_seen_.data() : pk_occ_.data();
-            uint32_t *out = which ? seen_.data() : occ_.data();
-            const uint32_t *goff = reinterpret_cast<const uint32_t *>(pk + 1 + 2 * nb);
-            for (int64_t g = 0; g < nb; ++g) {
-                const uint64_t ones = pk[1 + g], mixed = pk[1 + nb + g];
-                const uint64_t *mw = pk + H + goff[g];
-                const int64_t w0 = g * 64, w1 = std::min<int64_t>(w0 + 64, n);
-                if (!mixed && (ones == 0 || (ones == ~0ull && w1 - w0 == 64))) {  // a uniform group
-                    std::fill(out + 2 * w0, out + 2 * w1, ones ? 0xffffffffu : 0u);
-                    continue;
-                }
-                for (int64_t w = w0; w < w1; ++w) {
-                    const unsigned b = (unsigned)(w - w0);
-                    uint64_t v = ((ones >> b) & 1u) ? ~0ull : 0ull;
-                    if ((mixed >> b) & 1u) v = *mw++;
-                    out[2 * w] = (uint32_t)v;
-                    out[2 * w + 1] = (uint32_t)(v >> 32);
-                }
-            }
-        }
+        expand_packet(pk_occ_.data(), pk_n_, pk_H_, occ_.data());
+        expand_packet(pk_seen_.data(), pk_n_, pk_H_, seen_.data());
     }
     // merge a sorted list into the colour list, the new values win
     void merge_into_colors(const HostVector<int> &idx, const HostVector<Vec4f> &val) {

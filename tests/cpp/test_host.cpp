@@ -75,6 +75,29 @@ static int test_model() {
     return 0;
 }
 
+// packet file (tests/test_cpp_host.py): int64 n, H, total ; total uint64 packet words ; n uint64 plane
+// words.  Model::packet_bit for every bit and Model::expand_packet against the plane -- no GPU.
+static int test_packet_decode(const char *path) {
+    std::ifstream f(path, std::ios::binary);
+    int64_t hd[3];
+    f.read((char *)hd, sizeof hd);
+    const int64_t n = hd[0], H = hd[1], total = hd[2];
+    std::vector<uint64_t> pk((size_t)total), plane((size_t)n);
+    f.read((char *)pk.data(), (std::streamsize)(pk.size() * 8));
+    f.read((char *)plane.data(), (std::streamsize)(plane.size() * 8));
+    if (!f) { std::fprintf(stderr, "short packet file\n"); return 2; }
+    for (int64_t i = 0; i < 64 * n; ++i)
+        if (Model::packet_bit(pk.data(), n, H, (size_t)i) != (bool)((plane[(size_t)(i >> 6)] >> (i & 63)) & 1u)) {
+            std::fprintf(stderr, "packet_bit differs at bit %lld\n", (long long)i);
+            return 1;
+        }
+    std::vector<uint32_t> out((size_t)(2 * n), 0x5a5a5a5au);
+    Model::expand_packet(pk.data(), n, H, out.data());
+    if (std::memcmp(out.data(), plane.data(), (size_t)n * 8)) { std::fprintf(stderr, "expand_packet differs\n"); return 1; }
+    std::puts("packet decode ok");
+    return 0;
+}
+
 // scene file: int32 X,Y,Z,V,W,H,C ; float s ; float K[9] ; V*(float pose[12]) ;
 //             V*H*W*C mask bytes ; V*H*W*3 image bytes ; X*Y*Z initial state bytes
 static int run_carve(const char *scene, const char *out, const char *mode) {
@@ -315,6 +338,7 @@ static int test_calibration(const char *path) {
 
 int main(int argc, char **argv) {
     if (argc >= 2 && !std::strcmp(argv[1], "model")) return test_model();
+    if (argc >= 3 && !std::strcmp(argv[1], "packet_decode")) return test_packet_decode(argv[2]);
     if (argc == 3 && !std::strcmp(argv[1], "calibration")) return test_calibration(argv[2]);
     if (argc == 5 && !std::strcmp(argv[1], "carve")) return run_carve(argv[2], argv[3], argv[4]);
     if (argc == 9 && !std::strcmp(argv[1], "mc"))

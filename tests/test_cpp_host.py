@@ -38,6 +38,31 @@ def test_calibration_file_reader(host_bin):
     assert r.returncode == 0 and "calibration ok" in r.stdout, r.stderr
 
 
+@pytest.mark.parametrize("n,mix", [(1, (0.0, 0.0)), (63, (0.5, 0.3)), (64, (0.2, 0.2)), (65, (0.6, 0.3)),
+                                   (4096 + 7, (0.7, 0.25)), (1 << 14, (0.0, 1.0)), (5000, (1.0, 0.0))])
+def test_packet_decoding_on_the_host(host_bin, tmp_path, n, mix):
+    """Model::packet_bit / expand_packet (what the host accessors read once a carved model has come
+    over as packets, include/arvx/model.hpp) against the numpy restatement of the packet layout
+    (tests/occ_codec.py): every bit, the expansion, ragged last groups, all-zero / all-one / all-mixed
+    planes.  No GPU."""
+    from tests import occ_codec
+    rng = np.random.default_rng(n)
+    kind = rng.random(n)
+    w = rng.integers(1, 2 ** 63, n, dtype=np.uint64) | (rng.integers(0, 2, n, dtype=np.uint64) << np.uint64(63))
+    w[w == occ_codec.ONES] = 7
+    w[kind < mix[0]] = 0
+    w[(kind >= mix[0]) & (kind < mix[0] + mix[1])] = occ_codec.ONES
+    need = int(((w != 0) & (w != occ_codec.ONES)).sum())
+    pk = occ_codec.compress(w, need + 3)
+    path = tmp_path / "packet.bin"
+    with open(path, "wb") as f:
+        f.write(np.array([n, occ_codec.header_words(n), len(pk)], np.int64).tobytes())
+        f.write(pk.tobytes())
+        f.write(w.tobytes())
+    r = subprocess.run([host_bin, "packet_decode", str(path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "packet decode ok" in r.stdout, r.stderr
+
+
 @pytest.mark.gpu
 def test_opencv_dropin_self_pinning_runs():
     """dropin::run_self_pin (include/arvx/opencv_dropin.hpp) against the stand-ins of
